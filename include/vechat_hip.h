@@ -1,0 +1,154 @@
+/* libvechat_hip.so -- C ABI of the MI355X-native replacement for VeChat's per-window hot path
+ * (SPOA partial-order alignment + graph prune + consensus).
+ *
+ * Each entry point replaces a piece of the reference's C++ interface for this path; the
+ * reference file:line it stands in for is cited next to it (paths relative to the reference
+ * tree).  No C++ or torch types cross this boundary: plain pointers and sizes only.
+ *
+ * Threading: a vc_ctx is bound to one HIP device and one stream and must be driven by one host
+ * thread at a time (the reference gives each worker its own spoa engine, src/polisher.cpp:186-190;
+ * its GPU shim gives each batch processor its own stream, src/cuda/cudabatch.cpp:54).
+ */
+#ifndef VECHAT_HIP_H_
+#define VECHAT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vc_ctx vc_ctx;
+
+/* status codes returned by every call */
+enum {
+    VC_OK            = 0,
+    VC_ERR_ARG       = -1,   /* bad argument / malformed batch                                  */
+    VC_ERR_HIP       = -2,   /* a HIP runtime call failed (vc_last_error has the text)          */
+    VC_ERR_NO_DEVICE = -3,   /* no gfx950 device visible: the product path has NO CPU fallback  */
+    VC_ERR_STATE     = -4,   /* call out of order (e.g. vc_run before vc_submit)                */
+    VC_ERR_CAPACITY  = -5    /* caller buffer too small                                         */
+};
+
+/* per-window status written by vc_run (vc_result.status) */
+enum {
+    VC_WIN_OK          = 0,  /* consensus produced; generate_consensus() would return true      */
+    VC_WIN_UNPOLISHED  = 1,  /* < 3 sequences: backbone copied, returns false (window.cpp:188-192) */
+    VC_WIN_OVERFLOW    = 2,  /* graph outgrew max_nodes/max_edges/stack: resubmit with larger caps */
+    VC_WIN_UNSUPPORTED = 3,  /* outside the kernels' envelope (score range, in-degree, alphabet)  */
+    VC_WIN_INVALID     = 4   /* input the reference would throw on (graph.cpp:191-231)          */
+};
+
+/* Replaces the constructor arguments the reference threads from main.cpp:46-61 through
+ * createPolisher (src/polisher.cpp:59,140-157) into spoa::AlignmentEngine::Create
+ * (polisher.cpp:186-190) and Window::generate_consensus (polisher.cpp:501-515). */
+typedef struct vc_params {
+    int32_t  device;                        /* HIP device ordinal                                  */
+    int32_t  match, mismatch, gap;          /* -m -x -g (3,-5,-4)                                  */
+    int32_t  sw_match, sw_mismatch, sw_gap; /* local engine hard-coded at window.cpp:326 (3,-5,-4) */
+    double   min_confidence, min_support;   /* -d -s                                               */
+    uint32_t num_prune;                     /* -k                                                  */
+    int32_t  mode;                          /* 0 = haplotype overload (window.cpp:176)             */
+    int32_t  trim;                          /* ignored in mode 0 (window.cpp:399)                  */
+    int32_t  window_type;                   /* 0 kNGS / 1 kTGS (window.hpp:21-24)                  */
+    uint32_t max_nodes;                     /* per-window graph capacity; 0 = derive from batch    */
+    uint32_t max_edges;                     /* 0 = derive                                          */
+    uint32_t chunk_windows;                 /* windows resident per pass; 0 = derive from memory   */
+    uint64_t scratch_bytes;                 /* device scratch budget; 0 = 1/4 of free memory       */
+    int32_t  profile;                       /* 1 = bracket every kernel class with HIP events      */
+} vc_params;
+
+/* A batch of windows, the unit the reference's accelerated path fills with
+ * CUDABatchProcessor::addWindow (src/cuda/cudabatch.hpp:39-59, cudabatch.cpp:79-135).
+ * Sequence 0 of every window is the backbone (with its quality or the dummy '!' string,
+ * polisher.cpp:397-400); sequences 1.. are the layers in the reference's `rank` order
+ * (window.cpp:203-210) -- use vc_rank_layers() on the host to obtain it. */
+typedef struct vc_batch {
+    uint32_t        n_windows;
+    const uint32_t* win_seq_off;   /* [n_windows+1]                                            */
+    const uint64_t* seq_off;       /* [n_seqs+1] byte offsets into bases/quals                 */
+    const uint32_t* seq_begin;     /* [n_seqs] positions_.first  (backbone: 0)                 */
+    const uint32_t* seq_end;       /* [n_seqs] positions_.second (backbone: 0)                 */
+    const uint8_t*  seq_has_qual;  /* [n_seqs] 0 = qualities_[i].first == nullptr              */
+    const uint8_t*  bases;
+    const uint8_t*  quals;         /* same offsets as bases; don't-care where has_qual == 0    */
+    const uint8_t*  win_fasta;     /* [n_windows] window.cpp:223's `if_fasta` (vc_backbone_is_fasta) */
+} vc_batch;
+
+/* Result of a batch: Window::consensus() (window.hpp:43-45) of every window, concatenated, plus
+ * the bool generate_consensus() returns (status VC_WIN_OK <=> true, VC_WIN_UNPOLISHED <=> false). */
+typedef struct vc_result {
+    uint64_t* cons_off;    /* [n_windows+1] out                         */
+    uint8_t*  cons;        /* out, capacity cons_cap bytes              */
+    uint64_t  cons_cap;
+    uint8_t*  status;      /* [n_windows] out                           */
+} vc_result;
+
+typedef struct vc_stats {
+    uint64_t cells;          /* sum over Align calls of graph_nodes * sequence_len  */
+    uint64_t alignments;
+    uint64_t dp_rows;
+    uint32_t n_classes;      /* kernel classes below                                            */
+    double   ms[16];         /* accumulated HIP-event time per kernel class (profile=1)         */
+    uint64_t launches[16];
+    char     names[16][24];
+    uint32_t max_nodes, max_edges, chunk_windows;   /* what the context actually used          */
+} vc_stats;
+
+/* -- lifecycle: stands in for createCUDABatch / ~CUDABatchProcessor (cudabatch.hpp:26,33) ------ */
+int  vc_create(vc_ctx** out, const vc_params* p);
+void vc_destroy(vc_ctx* ctx);
+const char* vc_last_error(const vc_ctx* ctx);   /* ctx may be NULL: error of a failed vc_create */
+
+/* -- batch: addWindow()... / generateConsensus() / reset() (cudabatch.hpp:39-59) --------------- */
+int vc_submit(vc_ctx* ctx, const vc_batch* b);        /* validates, copies to HBM (H2D), retains nothing of b */
+int vc_run(vc_ctx* ctx);                              /* the whole hot path on the device; asynchronous       */
+int vc_sync(vc_ctx* ctx);                             /* waits for vc_run                                      */
+int vc_result_size(vc_ctx* ctx, uint64_t* cons_bytes);/* after vc_sync: total consensus bytes                  */
+int vc_collect(vc_ctx* ctx, vc_result* r);            /* D2H of consensus + status                             */
+/* device-side hand-over for the multi-GPU gather (RCCL lives in the caller, e.g. torch.distributed):
+ * compacts the consensus bytes into caller-owned DEVICE memory. */
+int vc_collect_device(vc_ctx* ctx, void* d_cons, uint64_t cons_cap, void* d_cons_off /*u64[n+1]*/,
+                      void* d_status /*u8[n]*/);
+int vc_get_stats(vc_ctx* ctx, vc_stats* s);
+void* vc_stream(vc_ctx* ctx);                         /* the hipStream_t the context launches on               */
+
+/* -- host helpers that keep reference semantics on the host side of the boundary ---------------- */
+/* rank[] as produced by window.cpp:203-210: rank[0]=0, rank[1..] = std::sort of 1..n-1 by begin
+ * (same libstdc++ introsort => same permutation for ties). */
+void vc_rank_layers(const uint32_t* begins, uint32_t n_seqs, uint32_t* rank_out);
+/* window.cpp:223: `qualities_.front().first == std::string(len,'!')` -- a C-string comparison that
+ * reads up to the NUL of the buffer `quality` points into. */
+int  vc_backbone_is_fasta(const char* quality_cstr, uint32_t backbone_len);
+/* graph.cpp:165-170 quality -> weight table as computed by this host's libm */
+void vc_weight_lut(uint32_t lut[256]);
+
+/* -- synthetic windows (SURVEY 8d generator; used by bench.py and the tests) -------------------- */
+typedef struct vc_synth_cfg {
+    uint64_t seed;
+    uint32_t backbone_len;      /* L                                   */
+    uint32_t n_layers;          /* D                                   */
+    double   error_rate;        /* total per-base error                */
+    double   frac_ins, frac_del, frac_sub;   /* split of the error      */
+    double   frac_partial;      /* fraction of layers that are partial-span */
+    int32_t  fastq;             /* 1 = layers carry qualities          */
+    int32_t  backbone_fastq;    /* 1 = backbone has real quality, 0 = dummy '!' (FASTA target) */
+    int32_t  n_haplotypes;      /* 1 or 2: reads drawn from this many variants of the truth    */
+    double   snp_rate;          /* divergence between haplotypes       */
+} vc_synth_cfg;
+
+typedef struct vc_synth vc_synth;
+/* generates windows [first, first+n) of the stream defined by cfg; layers are stored in rank order */
+vc_synth* vc_synth_generate(const vc_synth_cfg* cfg, uint64_t first, uint32_t n, uint32_t n_threads);
+void      vc_synth_batch(const vc_synth* s, vc_batch* out);   /* pointers stay owned by s */
+uint64_t  vc_synth_n_seqs(const vc_synth* s);
+/* [n_seqs] index each stored sequence had in add_layer() order (before the rank sort) */
+const uint32_t* vc_synth_orig_index(const vc_synth* s);
+uint64_t  vc_synth_n_bytes(const vc_synth* s);
+void      vc_synth_free(vc_synth* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,170 @@
+"""TEST INFRASTRUCTURE: ctypes access to the oracle (oracle/liboracle.so, our plain-C restatement)
+and, when present, to the real reference built in place (oracle/_ref/libvcref_*.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from vechat_amd.capi import Batch, VcBatch, VcParams
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class VcoParams(C.Structure):
+    _fields_ = [
+        ("match", C.c_int32), ("mismatch", C.c_int32), ("gap", C.c_int32),
+        ("sw_match", C.c_int32), ("sw_mismatch", C.c_int32), ("sw_gap", C.c_int32),
+        ("min_confidence", C.c_double), ("min_support", C.c_double),
+        ("num_prune", C.c_uint32),
+        ("mode", C.c_int32), ("trim", C.c_int32), ("window_type", C.c_int32),
+    ]
+
+
+class VcoStats(C.Structure):
+    _fields_ = [("cells", C.c_uint64), ("alignments", C.c_uint64)]
+
+
+def vco_params(p: VcParams):
+    return VcoParams(p.match, p.mismatch, p.gap, p.sw_match, p.sw_mismatch, p.sw_gap,
+                     p.min_confidence, p.min_support, p.num_prune, p.mode, p.trim, p.window_type)
+
+
+_oracle = None
+_ref = {}
+
+
+def load_oracle():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"])
+        lib = C.CDLL(path)
+        lib.vco_run.argtypes = [C.POINTER(VcBatch), C.POINTER(VcoParams), C.c_uint32, C.c_uint32,
+                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.c_uint64,
+                                C.POINTER(C.c_uint8), C.POINTER(VcoStats)]
+        lib.vco_run.restype = C.c_int
+        lib.vco_spoa_consensus.restype = C.c_int
+        lib.vco_spoa_align_probe.restype = C.c_int
+        lib.vco_weight_lut.argtypes = [C.POINTER(C.c_uint32)]
+        _oracle = lib
+    return _oracle
+
+
+def have_ref(kind="sse41"):
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", f"libvcref_{kind}.so"))
+
+
+def load_ref(kind="sse41"):
+    if kind not in _ref:
+        lib = C.CDLL(os.path.join(ORACLE_DIR, "_ref", f"libvcref_{kind}.so"))
+        lib.vcref_window.restype = C.c_int
+        lib.vcref_spoa_consensus.restype = C.c_int
+        lib.vcref_spoa_align_probe.restype = C.c_int
+        _ref[kind] = lib
+    return _ref[kind]
+
+
+def oracle_run(batch: Batch, params: VcParams, w0=0, w1=None):
+    """Oracle over windows [w0,w1): returns (list of consensus bytes, polished flags, stats)."""
+    lib = load_oracle()
+    w1 = batch.n_windows if w1 is None else w1
+    vb = batch.as_struct()
+    vp = vco_params(params)
+    cap = int(batch.bases.size) + 4096 * (w1 - w0) + 1024
+    cons = np.zeros(cap, np.uint8)
+    off = np.zeros(batch.n_windows + 1, np.uint64)
+    pol = np.zeros(batch.n_windows, np.uint8)
+    st = VcoStats()
+    rc = lib.vco_run(C.byref(vb), C.byref(vp), w0, w1, off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                     cons.ctypes.data_as(C.POINTER(C.c_uint8)), cap,
+                     pol.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"vco_run rc={rc}")
+    out = [cons[int(off[w]):int(off[w + 1])].tobytes() for w in range(w0, w1)]
+    return out, pol[w0:w1].copy(), st
+
+
+def ref_window(batch: Batch, w, params: VcParams, kind="sse41"):
+    """One window through the REAL reference.  Layers are handed over in their original
+    add_layer() order (batch.seq_orig) because the reference sorts internally."""
+    lib = load_ref(kind)
+    seqs, quals, b, e = batch.window(w)
+    s0 = int(batch.win_seq_off[w])
+    n = len(seqs)
+    orig = [int(x) for x in batch.seq_orig[s0:s0 + n]] if batch.seq_orig is not None else list(range(n))
+    inv = [0] * n
+    for k, o in enumerate(orig):
+        inv[o] = k
+    order = [inv[i] for i in range(1, n)]         # stored positions of add_layer index 1..n-1
+    L = len(seqs[0])
+    # backbone quality must be NUL-terminated where the reference's C-string compare stops:
+    # FASTA-style windows get exactly L '!' (if_fasta true), others the real quality.
+    bq = quals[0]
+    if bool(batch.win_fasta[w]) != (bq == b"!" * L):
+        # short last window of a FASTA target: dummy string longer than L (polisher.cpp:181,399)
+        bq = bq + b"!" * 8 if not batch.win_fasta[w] and bq == b"!" * L else bq
+    nl = n - 1
+    SeqArr = C.c_char_p * max(nl, 1)
+    U32 = C.c_uint32 * max(nl, 1)
+    sa = SeqArr(*[seqs[k] for k in order]) if nl else SeqArr()
+    qa = SeqArr(*[quals[k] for k in order]) if nl else SeqArr()
+    la = U32(*[len(seqs[k]) for k in order]) if nl else U32()
+    ba = U32(*[b[k] for k in order]) if nl else U32()
+    ea = U32(*[e[k] for k in order]) if nl else U32()
+    cap = sum(len(s) for s in seqs) + 4096
+    out = C.create_string_buffer(cap)
+    out_len = C.c_uint32(0)
+    pol = C.c_int(0)
+    rc = lib.vcref_window(C.c_char_p(seqs[0]), C.c_uint32(L), C.c_char_p(bq), C.c_uint32(nl), sa, la, qa, ba, ea,
+                          C.c_int(params.mode), C.c_int(params.window_type), C.c_int(params.trim),
+                          C.c_int(params.match), C.c_int(params.mismatch), C.c_int(params.gap),
+                          C.c_double(params.min_confidence), C.c_double(params.min_support),
+                          C.c_uint32(params.num_prune), out, C.c_uint32(cap), C.byref(out_len), C.byref(pol))
+    if rc != 0:
+        raise RuntimeError(f"vcref_window rc={rc}")
+    return out.raw[:out_len.value], pol.value
+
+
+def _seq_arrays(seqs, quals):
+    n = len(seqs)
+    SA = C.c_char_p * n
+    sa = SA(*seqs)
+    la = (C.c_uint32 * n)(*[len(s) for s in seqs])
+    qa = SA(*quals) if quals is not None else None
+    return n, sa, la, qa
+
+
+def spoa_consensus(lib, prefix, seqs, quals, atype, m, n_, g):
+    n, sa, la, qa = _seq_arrays(seqs, quals)
+    cap = max(len(s) for s in seqs) * 4 + 1024
+    out = C.create_string_buffer(cap)
+    out_len = C.c_uint32(0)
+    fn = getattr(lib, prefix + "_spoa_consensus")
+    rc = fn(C.c_uint32(n), sa, la, qa, C.c_int(atype), C.c_int(m), C.c_int(n_), C.c_int(g), out,
+            C.c_uint32(cap), C.byref(out_len))
+    if rc != 0:
+        raise RuntimeError(f"{prefix}_spoa_consensus rc={rc}")
+    return out.raw[:out_len.value]
+
+
+def spoa_align_probe(lib, prefix, seqs, quals, build_type, m, n_, g, query, query_type):
+    n, sa, la, qa = _seq_arrays(seqs, quals)
+    pcap = 4 * (sum(len(s) for s in seqs) + len(query)) + 64
+    rcap = sum(len(s) for s in seqs) + 64
+    pairs = (C.c_int32 * (2 * pcap))()
+    rank = (C.c_uint32 * rcap)()
+    npairs = C.c_uint32(0)
+    nnodes = C.c_uint32(0)
+    fn = getattr(lib, prefix + "_spoa_align_probe")
+    rc = fn(C.c_uint32(n), sa, la, qa, C.c_int(build_type), C.c_int(m), C.c_int(n_), C.c_int(g),
+            C.c_char_p(query), C.c_uint32(len(query)), C.c_int(query_type), pairs, C.c_uint32(pcap),
+            C.byref(npairs), rank, C.c_uint32(rcap), C.byref(nnodes))
+    if rc != 0:
+        raise RuntimeError(f"{prefix}_spoa_align_probe rc={rc}")
+    return list(pairs[:2 * npairs.value]), list(rank[:nnodes.value])
