@@ -1,0 +1,572 @@
+// libvechat_hip.so: C ABI (include/vechat_hip.h) over the HIP kernels in vc_kernels.h.
+//
+// Host side of the path: stands where the reference's Polisher::polish (src/polisher.cpp:491-517)
+// hands windows to Window::generate_consensus, shaped like its accelerated precedent
+// CUDABatchProcessor (src/cuda/cudabatch.cpp:79-270): fill a batch, run it, read statuses back.
+// There is no CPU fallback anywhere in this file: without a gfx950 device vc_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vc_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum KClass { KC_AVG = 0, KC_INIT, KC_TOPO, KC_FWD, KC_TRACE, KC_ADDALN, KC_PRUNE, KC_ADDW, KC_FINISH, KC_N };
+const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace", "k_addaln", "k_prune_lcc", "k_addw", "k_finish"};
+
+uint32_t topo_lds_bytes(uint32_t NC, uint32_t EC, uint32_t STK) {
+    return ((2 * NC + 15) & ~15u) + 4 * EC + 8 * NC + ((NC + 15) & ~15u) + 2 * STK + 2 * NC + 64;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct vc_ctx {
+    vc_params prm{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void*> allocs;          // everything hipMalloc'ed (freed in vc_destroy)
+    std::vector<void*> batch_allocs;    // per-batch allocations (freed on resubmit)
+    std::vector<void*> chunk_allocs;    // workspace (re-created when capacities change)
+
+    // batch
+    bool have_batch = false, ran = false;
+    VcBatchDev b{};
+    std::vector<uint32_t> h_win_seq_off;
+    uint32_t max_layers = 0, max_len = 0, max_nseq = 0;
+    uint64_t total_cons = 0;
+    std::vector<uint32_t> h_cons_len;
+    std::vector<uint8_t> h_status;
+    uint32_t *d_lut_w = nullptr; double* d_lut_d = nullptr;
+
+    // workspace
+    uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, jobs_cap = 0, group_max = 1;
+    uint64_t dir_bytes = 0;
+    VcGraph gr[2]{};
+    VcDp dp{};
+    uint8_t* d_dir = nullptr; uint8_t* d_dir0 = nullptr; uint2* d_spill = nullptr;
+    uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
+    uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
+    uint32_t* d_rpairs = nullptr; uint32_t* d_rnpairs = nullptr;     // realign: [CW*max_nseq*PC]
+    unsigned long long* d_stat = nullptr;                            // [2] cells, rows
+    uint32_t* d_maxn = nullptr;                                      // [1]
+
+    // stats
+    vc_stats stats{};
+    std::vector<hipEvent_t> ev_pool;
+    struct EvRec { int cls; hipEvent_t a, b; };
+    std::vector<EvRec> ev_recs;
+    size_t ev_next = 0;
+};
+
+namespace {
+
+int fail(vc_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return fail((c), VC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int dalloc(vc_ctx* c, std::vector<void*>& list, T** out, size_t n) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(n * sizeof(T), 256);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(c, VC_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    list.push_back(p);
+    *out = static_cast<T*>(p);
+    return VC_OK;
+}
+
+void free_list(std::vector<void*>& l) {
+    for (void* p : l) (void)hipFree(p);
+    l.clear();
+}
+
+int alloc_graph(vc_ctx* c, VcGraph* g) {
+    const size_t CW = c->CW, NC = c->NC, EC = c->EC;
+    int rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->n_nodes, CW))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->n_edges, CW))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->code, CW * NC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->in_first, CW * NC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->in_last, CW * NC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->out_first, CW * NC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->out_last, CW * NC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->al_cnt, CW * NC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->al, CW * NC * VC_MAXALN))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->e_tn, CW * EC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->e_hn, CW * EC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->e_w, CW * EC))) return rc;
+    return VC_OK;
+}
+
+struct Timer {
+    vc_ctx* c; int cls; hipEvent_t a = nullptr, b = nullptr;
+    Timer(vc_ctx* c_, int cls_) : c(c_), cls(cls_) {
+        c->stats.launches[cls]++;
+        if (!c->prm.profile) return;
+        if (c->ev_next + 2 > c->ev_pool.size()) {
+            for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
+        }
+        a = c->ev_pool[c->ev_next++]; b = c->ev_pool[c->ev_next++];
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~Timer() {
+        if (!c->prm.profile) return;
+        (void)hipEventRecord(b, c->stream);
+        c->ev_recs.push_back({cls, a, b});
+    }
+};
+
+void flush_events(vc_ctx* c) {
+    for (auto& r : c->ev_recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->stats.ms[r.cls] += ms;
+    }
+    c->ev_recs.clear();
+    c->ev_next = 0;
+}
+
+template <int CPL>
+void launch_fwd_t(vc_ctx* c, const VcFwdArgs& a, uint32_t jobs) {
+    hipLaunchKernelGGL(k_fwd<CPL>, dim3(jobs), dim3(64), 0, c->stream, a);
+}
+
+int launch_fwd(vc_ctx* c, const VcFwdArgs& a, uint32_t jobs) {
+    Timer t(c, KC_FWD);
+    switch (c->cpl) {
+        case 4:  launch_fwd_t<4>(c, a, jobs); break;
+        case 8:  launch_fwd_t<8>(c, a, jobs); break;
+        case 12: launch_fwd_t<12>(c, a, jobs); break;
+        case 16: launch_fwd_t<16>(c, a, jobs); break;
+        case 24: launch_fwd_t<24>(c, a, jobs); break;
+        case 32: launch_fwd_t<32>(c, a, jobs); break;
+        default: return fail(c, VC_ERR_ARG, "unsupported cells-per-lane %u", c->cpl);
+    }
+    return VC_OK;
+}
+
+uint32_t pick_cpl(uint32_t max_len) {
+    const uint32_t opts[] = {4, 8, 12, 16, 24, 32};
+    for (uint32_t o : opts) if (64 * o >= max_len) return o;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vc_last_error(const vc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int vc_create(vc_ctx** out, const vc_params* p) {
+    if (!out || !p) return fail(nullptr, VC_ERR_ARG, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, VC_ERR_NO_DEVICE, "no HIP device visible (%s); libvechat_hip has no CPU fallback",
+                    e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (p->device < 0 || p->device >= ndev) return fail(nullptr, VC_ERR_ARG, "device %d out of range (%d visible)", p->device, ndev);
+    if (p->mode != 0) return fail(nullptr, VC_ERR_ARG, "mode %d not implemented on the device yet (haplotype overload only)", p->mode);
+    if (p->num_prune == 0) return fail(nullptr, VC_ERR_ARG, "num_prune must be >= 1");
+    if (p->gap >= 0 || p->sw_gap >= 0) return fail(nullptr, VC_ERR_ARG, "gap penalties must be negative");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) return fail(nullptr, VC_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, VC_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only", p->device, prop.gcnArchName);
+    vc_ctx* c = new vc_ctx();
+    c->prm = *p;
+    c->device = p->device;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return fail(nullptr, VC_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
+    }
+    // lookup tables from this host's libm, like the reference computes them (graph.cpp:169, window.cpp:235)
+    uint32_t lw[256]; double ld[256];
+    vc_weight_lut(lw);
+    for (int ch = 0; ch < 256; ++ch) ld[ch] = 1 - pow(10, (33 - (int)(signed char)ch) / 10.0);
+    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) ||
+        dalloc(c, c->allocs, &c->d_stat, 2) || dalloc(c, c->allocs, &c->d_maxn, 1)) {
+        g_create_error = c->err; vc_destroy(c); return VC_ERR_HIP;
+    }
+    (void)hipMemcpy(c->d_lut_w, lw, sizeof(lw), hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->d_lut_d, ld, sizeof(ld), hipMemcpyHostToDevice);
+    c->stats.n_classes = KC_N;
+    for (int i = 0; i < KC_N; ++i) std::snprintf(c->stats.names[i], sizeof(c->stats.names[i]), "%s", kClassNames[i]);
+    *out = c;
+    return VC_OK;
+}
+
+void vc_destroy(vc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_list(c->chunk_allocs);
+    free_list(c->batch_allocs);
+    free_list(c->allocs);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* vc_stream(vc_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int vc_submit(vc_ctx* c, const vc_batch* hb) {
+    if (!c || !hb) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t nw = hb->n_windows;
+    if (nw == 0) return fail(c, VC_ERR_ARG, "empty batch");
+    if (!hb->win_seq_off || !hb->seq_off || !hb->seq_begin || !hb->seq_end || !hb->seq_has_qual || !hb->bases ||
+        !hb->quals || !hb->win_fasta) return fail(c, VC_ERR_ARG, "null array in batch");
+    const uint64_t nseq = hb->win_seq_off[nw];
+    const uint64_t nbytes = hb->seq_off[nseq];
+    // validation (what createWindow / add_layer enforce, window.cpp:22-27,56-67)
+    uint32_t max_layers = 0, max_len = 0, max_nseq = 0;
+    uint64_t need_nodes = 0;
+    for (uint32_t w = 0; w < nw; ++w) {
+        const uint32_t s0 = hb->win_seq_off[w], s1 = hb->win_seq_off[w + 1];
+        if (s1 <= s0) return fail(c, VC_ERR_ARG, "window %u has no backbone", w);
+        const uint64_t L = hb->seq_off[s0 + 1] - hb->seq_off[s0];
+        if (L == 0 || L >= 65535) return fail(c, VC_ERR_ARG, "window %u: backbone length %llu unsupported", w, (unsigned long long)L);
+        if (!hb->seq_has_qual[s0]) return fail(c, VC_ERR_ARG, "window %u: backbone needs a quality string (dummy '!' for FASTA targets)", w);
+        uint64_t sum = 0;
+        for (uint32_t s = s0; s < s1; ++s) {
+            const uint64_t len = hb->seq_off[s + 1] - hb->seq_off[s];
+            if (len == 0 || len >= 65535) return fail(c, VC_ERR_ARG, "window %u: sequence length %llu unsupported", w, (unsigned long long)len);
+            if (s > s0) {
+                const uint32_t b = hb->seq_begin[s], e2 = hb->seq_end[s];
+                if (b >= e2 || b > L || e2 >= L) return fail(c, VC_ERR_ARG, "window %u: invalid layer positions (%u,%u)", w, b, e2);
+                sum += len;
+            }
+            max_len = std::max<uint32_t>(max_len, (uint32_t)len);
+        }
+        max_layers = std::max(max_layers, s1 - s0 - 1);
+        max_nseq = std::max(max_nseq, s1 - s0);
+        need_nodes = std::max<uint64_t>(need_nodes, L + (uint64_t)std::ceil(0.045 * (double)sum) + 160);
+    }
+    free_list(c->batch_allocs);
+    c->have_batch = false; c->ran = false;
+    VcBatchDev& b = c->b;
+    b = VcBatchDev{};
+    b.n_windows = nw;
+    uint32_t* d_wso; uint64_t* d_so; uint32_t *d_sb, *d_se; uint8_t *d_hq, *d_ba, *d_qu, *d_wf;
+    int rc;
+    if ((rc = dalloc(c, c->batch_allocs, &d_wso, nw + 1)) || (rc = dalloc(c, c->batch_allocs, &d_so, nseq + 1)) ||
+        (rc = dalloc(c, c->batch_allocs, &d_sb, nseq)) || (rc = dalloc(c, c->batch_allocs, &d_se, nseq)) ||
+        (rc = dalloc(c, c->batch_allocs, &d_hq, nseq)) || (rc = dalloc(c, c->batch_allocs, &d_ba, nbytes + 16)) ||
+        (rc = dalloc(c, c->batch_allocs, &d_qu, nbytes + 16)) || (rc = dalloc(c, c->batch_allocs, &d_wf, nw)) ||
+        (rc = dalloc(c, c->batch_allocs, &b.win_avg, nw)) || (rc = dalloc(c, c->batch_allocs, &b.status, nw)) ||
+        (rc = dalloc(c, c->batch_allocs, &b.cons_len, nw)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(d_wso, hb->win_seq_off, (nw + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_so, hb->seq_off, (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_sb, hb->seq_begin, nseq * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_se, hb->seq_end, nseq * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_hq, hb->seq_has_qual, nseq, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_ba, hb->bases, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_qu, hb->quals, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_wf, hb->win_fasta, nw, hipMemcpyHostToDevice, c->stream));
+    b.win_seq_off = d_wso; b.seq_off = d_so; b.seq_begin = d_sb; b.seq_end = d_se; b.seq_has_qual = d_hq;
+    b.bases = d_ba; b.quals = d_qu; b.win_fasta = d_wf;
+    b.lut_w = c->d_lut_w; b.lut_d = c->d_lut_d;
+    c->h_win_seq_off.assign(hb->win_seq_off, hb->win_seq_off + nw + 1);
+    c->max_layers = max_layers; c->max_len = max_len; c->max_nseq = max_nseq;
+
+    // capacities
+    uint32_t NC = c->prm.max_nodes ? c->prm.max_nodes : (uint32_t)std::min<uint64_t>(need_nodes, 60000);
+    NC = (NC + 63) & ~63u;
+    uint32_t EC = c->prm.max_edges ? c->prm.max_edges : (uint32_t)std::min<uint64_t>((uint64_t)(2.4 * NC), 32000);
+    EC = (EC + 63) & ~63u;
+    if (EC > 32000) EC = 32000;
+    if (NC > 60000) return fail(c, VC_ERR_ARG, "max_nodes %u exceeds the 16-bit id space", NC);
+    const uint32_t cpl = pick_cpl(max_len);
+    if (!cpl) return fail(c, VC_ERR_ARG, "sequence length %u exceeds the kernels' 2048-column envelope", max_len);
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    const uint32_t lds_max = (uint32_t)prop.sharedMemPerBlock ? (uint32_t)std::max<size_t>(prop.sharedMemPerBlock, 65536) : 65536;
+    const uint32_t lds_cap = 160 * 1024;
+    (void)lds_max;
+    if (topo_lds_bytes(NC, EC, c->STK) > lds_cap || vc_prune_lds_bytes(NC, EC) > lds_cap)
+        return fail(c, VC_ERR_ARG, "graph capacity %u nodes / %u edges does not fit the 160 KB LDS", NC, EC);
+    const uint32_t PC = NC + max_len + 8;
+
+    // chunk size from the scratch budget
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6);
+    const uint64_t rowb = 64ull * cpl;
+    const uint64_t np_ = cpl / 4;
+    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
+                                    PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4);
+    const uint64_t per_job = NC * rowb + NC + (uint64_t)VC_SPILLCAP * (np_ * 64 + 1) * 8 + 8;
+    uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
+    CW = std::min(CW, nw);
+    while (CW > 64 && (per_slot_fixed + per_job) * CW > budget) CW /= 2;
+    if ((per_slot_fixed + per_job) * CW > budget) return fail(c, VC_ERR_ARG, "scratch budget %llu too small", (unsigned long long)budget);
+    // extra dir space lets re-alignment rounds run several sequences of a window per launch
+    uint64_t spare = budget - (per_slot_fixed + per_job) * CW;
+    uint32_t group_max = 1 + (uint32_t)std::min<uint64_t>(spare / (per_job * CW), 15);
+    if (group_max > max_nseq) group_max = max_nseq;
+
+    const bool same = c->NC == NC && c->EC == EC && c->CW == CW && c->cpl == cpl && c->PC == PC &&
+                      c->group_max == group_max && c->max_nseq == max_nseq && !c->chunk_allocs.empty();
+    if (!same) {
+        free_list(c->chunk_allocs);
+        c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max;
+        c->jobs_cap = CW * group_max;
+        if ((rc = alloc_graph(c, &c->gr[0])) || (rc = alloc_graph(c, &c->gr[1]))) return rc;
+        if ((rc = dalloc(c, c->chunk_allocs, &c->dp.nrows, CW)) || (rc = dalloc(c, c->chunk_allocs, &c->dp.flags, CW)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->dp.rec, (size_t)CW * NC)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->dp.rank2node, (size_t)CW * NC)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->dp.ovf, (size_t)CW * EC)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->dp.spill_slot, (size_t)CW * NC)))
+            return rc;
+        c->dir_bytes = (uint64_t)c->jobs_cap * NC * rowb;
+        if ((rc = dalloc(c, c->chunk_allocs, &c->d_dir, c->dir_bytes)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_dir0, (size_t)c->jobs_cap * NC)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_spill, (size_t)c->jobs_cap * VC_SPILLCAP * (np_ * 64 + 1))) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_job_end, c->jobs_cap)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_job_type, c->jobs_cap)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_pairs, (size_t)CW * PC)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_npairs, CW)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_rpairs, (size_t)CW * max_nseq * PC)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_rnpairs, (size_t)CW * max_nseq)))
+            return rc;
+    }
+    b.cons_cap = NC;
+    if ((rc = dalloc(c, c->batch_allocs, &b.cons, (size_t)nw * b.cons_cap))) return rc;
+    HIPCHK(c, hipMemsetAsync(b.status, 0, nw, c->stream));
+    HIPCHK(c, hipMemsetAsync(b.cons_len, 0, nw * 4, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stats.max_nodes = NC; c->stats.max_edges = EC; c->stats.chunk_windows = CW;
+    c->have_batch = true;
+    return VC_OK;
+}
+
+int vc_run(vc_ctx* c) {
+    if (!c) return VC_ERR_ARG;
+    if (!c->have_batch) return fail(c, VC_ERR_STATE, "vc_run before vc_submit");
+    HIPCHK(c, hipSetDevice(c->device));
+    const VcBatchDev& b = c->b;
+    const uint32_t NC = c->NC, EC = c->EC, CW = c->CW, PC = c->PC, cpl = c->cpl;
+    const uint32_t topo_lds = topo_lds_bytes(NC, EC, c->STK);
+    const uint32_t prune_lds = vc_prune_lds_bytes(NC, EC);
+    const uint32_t add_lds = 2 * PC + 64;
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)topo_lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)add_lds));
+    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
+    HIPCHK(c, hipMemsetAsync(b.cons_len, 0, (size_t)b.n_windows * 4, c->stream));
+    for (int i = 0; i < KC_N; ++i) { c->stats.ms[i] = 0; c->stats.launches[i] = 0; }
+    const uint64_t rowb = 64ull * cpl;
+
+    for (uint32_t w0 = 0; w0 < b.n_windows; w0 += CW) {
+        const uint32_t ns = std::min(CW, b.n_windows - w0);
+        uint32_t layers = 0, nseq_max = 0;
+        for (uint32_t w = w0; w < w0 + ns; ++w) {
+            const uint32_t n = c->h_win_seq_off[w + 1] - c->h_win_seq_off[w];
+            nseq_max = std::max(nseq_max, n);
+            if (n >= 3) layers = std::max(layers, n - 1);
+        }
+        { Timer t(c, KC_AVG); hipLaunchKernelGGL(k_avg, dim3((ns + 63) / 64), dim3(64), 0, c->stream, b, w0, ns); }
+        { Timer t(c, KC_INIT); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), 0, c->stream, b, c->gr[0], w0, ns, NC, EC); }
+        if (layers == 0) continue;
+
+        VcFwdArgs fa{};
+        fa.b = b; fa.dp = c->dp; fa.w0 = w0; fa.nslots = ns; fa.NC = NC; fa.EC = EC;
+        fa.m = c->prm.match; fa.n = c->prm.mismatch; fa.g = c->prm.gap;
+        fa.sm = c->prm.sw_match; fa.sn = c->prm.sw_mismatch; fa.sg = c->prm.sw_gap;
+        fa.dir = c->d_dir; fa.dir0 = c->d_dir0; fa.spill = c->d_spill;
+        fa.job_end = c->d_job_end; fa.job_type = c->d_job_type;
+        fa.stat_cells = c->d_stat; fa.stat_rows = c->d_stat + 1;
+        VcTraceArgs ta{};
+        ta.b = b; ta.dp = c->dp; ta.w0 = w0; ta.nslots = ns; ta.NC = NC; ta.EC = EC; ta.cpl = cpl;
+        ta.dir = c->d_dir; ta.dir0 = c->d_dir0; ta.job_end = c->d_job_end; ta.job_type = c->d_job_type; ta.PC = PC;
+
+        // ---- build loop (window.cpp:239-298): one layer of every window per iteration
+        int cur = 0;
+        for (uint32_t j = 1; j <= layers; ++j) {
+            { Timer t(c, KC_TOPO);
+              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, (int)j); }
+            fa.group = 1; fa.k0 = j; fa.mode = 0; fa.dir_stride = (uint64_t)NC * rowb;
+            int rc = launch_fwd(c, fa, ns);
+            if (rc) return rc;
+            ta.group = 1; ta.k0 = j; ta.dir_stride = fa.dir_stride;
+            ta.pairs = c->d_pairs; ta.npairs = c->d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
+            { Timer t(c, KC_TRACE); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, c->stream, ta); }
+            VcAddArgs aa{};
+            aa.b = b; aa.g = c->gr[cur]; aa.dp = c->dp; aa.w0 = w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
+            aa.pairs = c->d_pairs; aa.npairs = c->d_npairs; aa.PC = PC;
+            { Timer t(c, KC_ADDALN); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, c->stream, aa); }
+        }
+
+        // ---- prune rounds (window.cpp:318-386)
+        for (uint32_t r = 0; r < c->prm.num_prune; ++r) {
+            VcPruneArgs pa{};
+            pa.b = b; pa.src = c->gr[cur]; pa.dst = c->gr[cur ^ 1]; pa.w0 = w0; pa.nslots = ns; pa.NC = NC; pa.EC = EC;
+            pa.min_conf = c->prm.min_confidence; pa.min_supp = c->prm.min_support;
+            { Timer t(c, KC_PRUNE); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), prune_lds, c->stream, pa); }
+            cur ^= 1;
+            { Timer t(c, KC_TOPO);
+              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, -1); }
+            if (r + 1 == c->prm.num_prune) break;
+            // how many rows do the pruned graphs have?  sizes the per-job direction matrices
+            HIPCHK(c, hipMemsetAsync(c->d_maxn, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_max_u32, dim3((ns + 255) / 256), dim3(256), 0, c->stream, c->dp.nrows, ns, c->d_maxn);
+            uint32_t maxn = 0;
+            HIPCHK(c, hipMemcpyAsync(&maxn, c->d_maxn, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (maxn == 0) maxn = 1;
+            const uint64_t stride = (uint64_t)maxn * rowb;
+            uint32_t group = (uint32_t)std::min<uint64_t>(c->dir_bytes / (stride * ns), c->group_max);
+            if (group == 0) group = 1;
+            group = std::min(group, nseq_max);
+            for (uint32_t k0 = 0; k0 < nseq_max; k0 += group) {
+                const uint32_t gsz = std::min(group, nseq_max - k0);
+                fa.group = gsz; fa.k0 = k0; fa.mode = 1; fa.dir_stride = stride;
+                int rc = launch_fwd(c, fa, ns * gsz);
+                if (rc) return rc;
+                ta.group = gsz; ta.k0 = k0; ta.dir_stride = stride;
+                ta.pairs = c->d_rpairs; ta.npairs = c->d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
+                { Timer t(c, KC_TRACE); hipLaunchKernelGGL(k_trace, dim3((ns * gsz + 63) / 64), dim3(64), 0, c->stream, ta); }
+            }
+            VcAddwArgs wa{};
+            wa.b = b; wa.g = c->gr[cur]; wa.dp = c->dp; wa.w0 = w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
+            wa.pairs = c->d_rpairs; wa.npairs = c->d_rnpairs; wa.PC = PC; wa.pair_group = c->max_nseq;
+            { Timer t(c, KC_ADDW); hipLaunchKernelGGL(k_addw, dim3(ns), dim3(64), 0, c->stream, wa); }
+        }
+
+        // ---- final local alignment of the backbone + corrected sequence (window.cpp:391-394)
+        fa.group = 1; fa.k0 = 0; fa.mode = 2; fa.dir_stride = (uint64_t)NC * rowb;
+        int rc = launch_fwd(c, fa, ns);
+        if (rc) return rc;
+        ta.group = 1; ta.k0 = 0; ta.dir_stride = fa.dir_stride;
+        ta.pairs = c->d_pairs; ta.npairs = c->d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
+        { Timer t(c, KC_TRACE); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, c->stream, ta); }
+        VcFinishArgs fn{};
+        fn.b = b; fn.g = c->gr[cur]; fn.dp = c->dp; fn.w0 = w0; fn.nslots = ns; fn.NC = NC;
+        fn.pairs = c->d_pairs; fn.npairs = c->d_npairs; fn.PC = PC;
+        { Timer t(c, KC_FINISH); hipLaunchKernelGGL(k_finish, dim3(ns), dim3(64), 0, c->stream, fn); }
+    }
+    HIPCHK(c, hipGetLastError());
+    c->ran = true;
+    return VC_OK;
+}
+
+int vc_sync(vc_ctx* c) {
+    if (!c) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->prm.profile) flush_events(c);
+    return VC_OK;
+}
+
+static int fetch_lengths(vc_ctx* c) {
+    if (!c->ran) return fail(c, VC_ERR_STATE, "no finished run");
+    const uint32_t nw = c->b.n_windows;
+    c->h_cons_len.resize(nw); c->h_status.resize(nw);
+    HIPCHK(c, hipMemcpyAsync(c->h_cons_len.data(), c->b.cons_len, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_status.data(), c->b.status, nw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t tot = 0;
+    for (uint32_t w = 0; w < nw; ++w) {
+        if (c->h_status[w] > VC_WIN_UNPOLISHED) c->h_cons_len[w] = 0;
+        tot += c->h_cons_len[w];
+    }
+    c->total_cons = tot;
+    return VC_OK;
+}
+
+int vc_result_size(vc_ctx* c, uint64_t* cons_bytes) {
+    if (!c || !cons_bytes) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = fetch_lengths(c);
+    if (rc) return rc;
+    *cons_bytes = c->total_cons;
+    return VC_OK;
+}
+
+int vc_collect_device(vc_ctx* c, void* d_cons, uint64_t cons_cap, void* d_cons_off, void* d_status) {
+    if (!c || !d_cons || !d_cons_off) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = fetch_lengths(c);
+    if (rc) return rc;
+    if (c->total_cons > cons_cap) return fail(c, VC_ERR_CAPACITY, "consensus needs %llu bytes, buffer has %llu",
+                                              (unsigned long long)c->total_cons, (unsigned long long)cons_cap);
+    const uint32_t nw = c->b.n_windows;
+    std::vector<uint64_t> off(nw + 1, 0);
+    for (uint32_t w = 0; w < nw; ++w) off[w + 1] = off[w] + c->h_cons_len[w];
+    HIPCHK(c, hipMemcpyAsync(d_cons_off, off.data(), (size_t)(nw + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    // statuses > UNPOLISHED publish no bytes: zero their lengths on the device view used by the gather
+    HIPCHK(c, hipMemcpyAsync(c->b.cons_len, c->h_cons_len.data(), (size_t)nw * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_gather_cons, dim3(nw), dim3(64), 0, c->stream, c->b, (const uint64_t*)d_cons_off, (uint8_t*)d_cons, cons_cap);
+    if (d_status) HIPCHK(c, hipMemcpyAsync(d_status, c->b.status, nw, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VC_OK;
+}
+
+int vc_collect(vc_ctx* c, vc_result* r) {
+    if (!c || !r || !r->cons_off || !r->status) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = fetch_lengths(c);
+    if (rc) return rc;
+    if (c->total_cons > r->cons_cap || (c->total_cons && !r->cons))
+        return fail(c, VC_ERR_CAPACITY, "consensus needs %llu bytes, buffer has %llu",
+                    (unsigned long long)c->total_cons, (unsigned long long)r->cons_cap);
+    const uint32_t nw = c->b.n_windows;
+    uint8_t* d_out = nullptr; uint64_t* d_off = nullptr;
+    std::vector<void*> tmp;
+    if ((rc = dalloc(c, tmp, &d_out, c->total_cons + 16)) || (rc = dalloc(c, tmp, &d_off, nw + 1))) { free_list(tmp); return rc; }
+    rc = vc_collect_device(c, d_out, c->total_cons + 16, d_off, nullptr);
+    if (rc == VC_OK) {
+        hipError_t e = hipMemcpy(r->cons, d_out, c->total_cons, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, VC_ERR_HIP, "D2H of consensus failed: %s", hipGetErrorString(e));
+    }
+    free_list(tmp);
+    if (rc) return rc;
+    r->cons_off[0] = 0;
+    for (uint32_t w = 0; w < nw; ++w) {
+        r->cons_off[w + 1] = r->cons_off[w] + c->h_cons_len[w];
+        r->status[w] = c->h_status[w];
+    }
+    return VC_OK;
+}
+
+int vc_get_stats(vc_ctx* c, vc_stats* s) {
+    if (!c || !s) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long st[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(st, c->d_stat, 16, hipMemcpyDeviceToHost));
+    c->stats.cells = st[0]; c->stats.dp_rows = st[1];
+    c->stats.alignments = c->stats.launches[KC_FWD];
+    *s = c->stats;
+    return VC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// Device-side data layout of libvechat_hip.so (gfx950).  Everything is SoA over "slots": the
+// windows of the chunk that is resident in HBM.  Ids are 16-bit (graph capacity < 65535 nodes/edges).
+//
+// Graph (mirrors spoa::Graph, vendor/spoa/include/spoa/graph.hpp:46-100, as index arrays):
+//   code[v]                     the base itself (the reference's coder/decoder is a bijection on bytes,
+//                               graph.cpp:198-205, and codes are only ever compared for equality)
+//   in-list / out-list of v     singly linked through the edges, append order == edge id order
+//                               (Graph::AddEdge appends to edges_, tail->outedges, head->inedges at once,
+//                               graph.cpp:94-107), so "list order" is reproduced by following next links
+//   al[v][0..al_cnt)            Node::aligned_nodes in append order (<= VC_MAXALN entries)
+//   e_tn[e] = tail | next_in<<16,  e_hn[e] = head | next_out<<16,  e_w[e] = Edge::weight
+#pragma once
+#include <stdint.h>
+
+#define VC_NONE16   0xFFFFu
+#define VC_MAXALN   4          // aligned group <= 5 members (A,C,G,T,N)
+#define VC_RING     16         // DP rows kept in LDS per alignment
+#define VC_SPILLCAP 96         // rows per alignment that may be parked in HBM for far successors
+#define VC_INLINE_PRED 6       // predecessors stored inline in a row record
+
+// dir-code byte written by the forward DP, read by the traceback
+//   bits 7:6 kind (0 diagonal, 1 vertical, 2 horizontal, 3 stop)
+//   bits 5:0 payload: < 48 -> predecessor row = row - (payload+1); >= 48 -> predecessor list index payload-48
+#define VC_K_DIAG 0u
+#define VC_K_VERT 1u
+#define VC_K_HORZ 2u
+#define VC_K_STOP 3u
+#define VC_PAYLOAD_NEAR 48u
+
+// row record flags
+#define VC_RF_SINK  1u
+#define VC_RF_SPILL 2u
+#define VC_RF_OVF   4u
+
+struct VcGraph {
+    uint32_t* n_nodes;    // [CW]
+    uint32_t* n_edges;    // [CW]
+    uint8_t*  code;       // [CW*NC]
+    uint16_t* in_first;   // [CW*NC]
+    uint16_t* in_last;
+    uint16_t* out_first;
+    uint16_t* out_last;
+    uint8_t*  al_cnt;     // [CW*NC]
+    uint16_t* al;         // [CW*NC*VC_MAXALN]
+    uint32_t* e_tn;       // [CW*EC]
+    uint32_t* e_hn;       // [CW*EC]
+    uint32_t* e_w;        // [CW*EC]
+};
+
+// Input of the alignment kernel for one graph, produced by k_topo in rank order.
+// rec[r] (16 B): byte0 code, byte1 flags, byte2 npred, byte3 unused, then 6 x u16 predecessor
+// row distances (delta = row - pred_row; the virtual row 0 is at delta == row).  With VC_RF_OVF the
+// first two u16 hold a u32 offset into ovf[] where all npred deltas live.
+struct VcDp {
+    uint32_t* nrows;      // [CW]
+    uint32_t* flags;      // [CW] bit0: outside the kernel envelope
+    uint4*    rec;        // [CW*NC]
+    uint16_t* rank2node;  // [CW*NC]
+    uint16_t* ovf;        // [CW*EC]
+    uint16_t* spill_slot; // [CW*NC]
+};
+
+struct VcBatchDev {
+    uint32_t n_windows;
+    const uint32_t* win_seq_off;
+    const uint64_t* seq_off;
+    const uint32_t* seq_begin;
+    const uint32_t* seq_end;
+    const uint8_t*  seq_has_qual;
+    const uint8_t*  bases;
+    const uint8_t*  quals;
+    const uint8_t*  win_fasta;
+    double*   win_avg;     // [n_windows] average_weight (window.cpp:301-309)
+    uint8_t*  status;      // [n_windows]
+    uint8_t*  cons;        // [n_windows*cons_cap]
+    uint32_t* cons_len;    // [n_windows]
+    uint32_t  cons_cap;
+    const uint32_t* lut_w; // [256]
+    const double*   lut_d; // [256]
+};

@@ -1,0 +1,1199 @@
+// Hand-written HIP kernels (gfx950 / CDNA4, wave64) for VeChat's per-window hot path.
+// Written for this target only: DPP wave scans, LDS row ring, 16-byte coalesced HBM traffic.
+//
+// Kernel            parallelism           restates (reference file:line)
+//   k_avg           thread / window       window.cpp:216-236,283,292-309 (average_weight, fp64, in order)
+//   k_init          wave / window         window.cpp:188-201 + graph.cpp:109-130,182-212 (backbone chain)
+//   k_topo          wave / window         graph.cpp:301-371 TopologicalSort, :640-732 Subgraph (as a mask),
+//                                         + builds the row records the DP consumes
+//   k_fwd<CPL>      wave / alignment      sisd_alignment_engine.cpp:118-254 Initialize, :292-360 Linear (NW/SW)
+//   k_trace         thread / alignment    sisd_alignment_engine.cpp:362-459 (backtrack)
+//   k_addaln        wave / window         graph.cpp:182-299 AddAlignment (+ :94-107 AddEdge)
+//   k_prune_lcc     wave / window         graph.cpp:811-982 PruneGraph, :984-1102 DfsUtil/LargestSubgraph
+//   k_addw          wave / window         graph.cpp:1104-1165 AddWeights (+ window.cpp:351-372 weights)
+//   k_finish        wave / window         graph.cpp:1167-1179 GenerateCorrectedSequence
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vc_device.h"
+#include "vechat_hip.h"
+
+#define VC_INT_MIN (-2147483647 - 1)
+
+__device__ __forceinline__ int vc_lane() { return (int)(threadIdx.x & 63); }
+
+// exclusive prefix sum over the 64 lanes of the wave; total returned through `total`
+__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t x, uint32_t& total) {
+    uint32_t v = x;
+    const int lane = vc_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    total = __shfl(v, 63, 64);
+    return v - x;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t vc_weight(const VcBatchDev& b, uint64_t off, uint32_t q, bool has_qual) {
+    return has_qual ? b.lut_w[b.quals[off + q]] : 1u;
+}
+
+__device__ __forceinline__ bool vc_full_span(uint32_t begin, uint32_t end, uint32_t L) {
+    uint32_t offset = (uint32_t)(0.01 * (double)L);          // window.cpp:212
+    return begin < offset && end > L - offset;              // window.cpp:253-254
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_avg: average_weight per window -- a strictly ordered fp64 sum (window.cpp:225-236,283,292-309)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_avg(VcBatchDev b, uint32_t w0, uint32_t nw) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nw) return;
+    uint32_t w = w0 + t;
+    uint32_t s0 = b.win_seq_off[w], s1 = b.win_seq_off[w + 1];
+    uint64_t o0 = b.seq_off[s0];
+    uint32_t L = (uint32_t)(b.seq_off[s0 + 1] - o0);
+    bool fasta = b.win_fasta[w] != 0;
+    double total = 0.0;
+    if (fasta) {
+        total += (double)L;
+    } else {
+        for (uint32_t q = 0; q < L; ++q) total += b.lut_d[b.quals[o0 + q]];
+    }
+    for (uint32_t s = s0 + 1; s < s1; ++s) {
+        uint64_t o = b.seq_off[s];
+        uint32_t len = (uint32_t)(b.seq_off[s + 1] - o);
+        if (!b.seq_has_qual[s]) {
+            total += (double)len;
+        } else {
+            for (uint32_t q = 0; q < len; ++q) total += b.lut_d[b.quals[o + q]];
+        }
+    }
+    uint16_t wl = (uint16_t)L;                                // window.cpp:216
+    double avg = fasta ? 2.0 * total / wl : 2.0 * total / wl * 1000;
+    b.win_avg[w] = avg;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_init: backbone chain graph (AddAlignment with an empty alignment, graph.cpp:207-212)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, uint32_t w0, uint32_t nslots,
+                                             uint32_t NC, uint32_t EC) {
+    uint32_t slot = blockIdx.x;
+    if (slot >= nslots) return;
+    uint32_t w = w0 + slot;
+    const int lane = vc_lane();
+    uint32_t s0 = b.win_seq_off[w], ns = b.win_seq_off[w + 1] - s0;
+    uint64_t o0 = b.seq_off[s0];
+    uint32_t L = (uint32_t)(b.seq_off[s0 + 1] - o0);
+    if (ns < 3) {                                             // window.cpp:188-192
+        uint32_t n = L < b.cons_cap ? L : b.cons_cap;
+        for (uint32_t i = lane; i < n; i += 64) b.cons[(uint64_t)w * b.cons_cap + i] = b.bases[o0 + i];
+        if (lane == 0) { b.cons_len[w] = n; b.status[w] = L <= b.cons_cap ? VC_WIN_UNPOLISHED : VC_WIN_OVERFLOW; }
+        return;
+    }
+    if (L > NC || L > EC + 1 || L >= 0xFFFF) { if (lane == 0) b.status[w] = VC_WIN_OVERFLOW; return; }
+    uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
+    for (uint32_t i = lane; i < L; i += 64) {
+        g.code[nb + i] = b.bases[o0 + i];
+        uint16_t ein = i > 0 ? (uint16_t)(i - 1) : VC_NONE16;
+        uint16_t eout = i + 1 < L ? (uint16_t)i : VC_NONE16;
+        g.in_first[nb + i] = ein; g.in_last[nb + i] = ein;
+        g.out_first[nb + i] = eout; g.out_last[nb + i] = eout;
+        g.al_cnt[nb + i] = 0;
+        if (i + 1 < L) {
+            uint32_t wgt = b.lut_w[b.quals[o0 + i]] + b.lut_w[b.quals[o0 + i + 1]];
+            g.e_tn[eb + i] = i | ((uint32_t)VC_NONE16 << 16);
+            g.e_hn[eb + i] = (i + 1) | ((uint32_t)VC_NONE16 << 16);
+            g.e_w[eb + i] = wgt;
+        }
+    }
+    if (lane == 0) { g.n_nodes[slot] = L; g.n_edges[slot] = L - 1; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_topo: exact TopologicalSort (graph.cpp:301-371) of the graph -- or of the Subgraph the next
+// partial-span layer will be aligned to (graph.cpp:640-732, expressed as a node mask) -- followed
+// by the construction of the row records k_fwd streams.  The order-defining DFS is inherently
+// serial; it runs on lane 0 out of LDS, everything around it is wave-parallel.
+//   next_layer >= 0 : build phase, prepare for sequence index `next_layer` of each window
+//   next_layer <  0 : whole graph (pruned graphs)
+// LDS carve (bytes): in_first 2*NC | etn 4*EC | al 8*NC | flag NC | stack 2*STK | rank 2*NC
+// ------------------------------------------------------------------------------------------------
+#define TF_MARK  0x03
+#define TF_IGN   0x04
+#define TF_SUB   0x08
+#define TF_CNTSH 4
+
+__global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+                                             uint32_t NC, uint32_t EC, uint32_t STK, int next_layer) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t slot = blockIdx.x;
+    if (slot >= nslots) return;
+    uint32_t w = w0 + slot;
+    if (b.status[w] != VC_WIN_OK) return;
+    const int lane = vc_lane();
+    uint32_t s0 = b.win_seq_off[w], ns = b.win_seq_off[w + 1] - s0;
+    bool masked = false;
+    uint32_t mb = 0, me = 0;
+    if (next_layer >= 0) {
+        if ((uint32_t)next_layer >= ns) return;
+        uint32_t L = (uint32_t)(b.seq_off[s0 + 1] - b.seq_off[s0]);
+        mb = b.seq_begin[s0 + next_layer]; me = b.seq_end[s0 + next_layer];
+        masked = !vc_full_span(mb, me, L);
+    }
+    const uint32_t N = g.n_nodes[slot], E = g.n_edges[slot];
+    const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
+
+    uint16_t* s_in_first = (uint16_t*)smem;
+    uint32_t* s_etn = (uint32_t*)(smem + ((2 * NC + 15) & ~15u));
+    uint16_t* s_al = (uint16_t*)((uint8_t*)s_etn + 4 * EC);
+    uint8_t*  s_flag = (uint8_t*)s_al + 8 * NC;
+    uint16_t* s_stack = (uint16_t*)(s_flag + ((NC + 15) & ~15u));
+    uint16_t* s_rank = s_stack + STK;
+
+    for (uint32_t i = lane; i < N; i += 64) {
+        s_in_first[i] = g.in_first[nb + i];
+        s_flag[i] = (uint8_t)(g.al_cnt[nb + i] << TF_CNTSH);
+    }
+    for (uint32_t i = lane; i < E; i += 64) s_etn[i] = g.e_tn[eb + i];
+    {
+        const uint2* src = (const uint2*)(g.al + nb * VC_MAXALN);
+        uint2* dst = (uint2*)s_al;
+        for (uint32_t i = lane; i < N; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    __shared__ uint32_t s_nrows;
+    __shared__ int s_err;
+    if (lane == 0) {
+        int err = 0;
+        uint32_t nr = 0;
+        if (masked) {
+            // ExtractSubgraph(nodes_[end], nodes_[begin]), graph.cpp:640-666
+            if (me >= N || mb >= N) { err = VC_WIN_INVALID; }
+            else {
+                uint32_t sp = 0;
+                s_stack[sp++] = (uint16_t)me;
+                while (sp && !err) {
+                    uint32_t c = s_stack[--sp];
+                    if (!(s_flag[c] & TF_SUB) && c >= mb) {
+                        for (uint32_t e = s_in_first[c]; e != VC_NONE16; ) {
+                            uint32_t tn = s_etn[e];
+                            if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
+                            s_stack[sp++] = (uint16_t)(tn & 0xFFFF);
+                            e = tn >> 16;
+                        }
+                        uint32_t cnt = s_flag[c] >> TF_CNTSH;
+                        for (uint32_t k = 0; k < cnt; ++k) {
+                            if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
+                            s_stack[sp++] = s_al[c * VC_MAXALN + k];
+                        }
+                        s_flag[c] |= TF_SUB;
+                    }
+                }
+            }
+        }
+        const uint8_t need = masked ? TF_SUB : 0;
+        for (uint32_t s = 0; s < N && !err; ++s) {
+            uint8_t fs = s_flag[s];
+            if ((fs & need) != need) continue;
+            if ((fs & TF_MARK) != 0) continue;
+            uint32_t sp = 0;
+            s_stack[sp++] = (uint16_t)s;
+            while (sp) {
+                uint32_t c = s_stack[sp - 1];
+                uint8_t fc = s_flag[c];
+                bool valid = true;
+                if ((fc & TF_MARK) != 2) {
+                    for (uint32_t e = s_in_first[c]; e != VC_NONE16; ) {
+                        uint32_t tn = s_etn[e];
+                        uint32_t t = tn & 0xFFFF;
+                        e = tn >> 16;
+                        uint8_t ft = s_flag[t];
+                        if ((ft & need) != need) continue;
+                        if ((ft & TF_MARK) != 2) {
+                            if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
+                            s_stack[sp++] = (uint16_t)t;
+                            valid = false;
+                        }
+                    }
+                    if (err) break;
+                    uint32_t cnt = fc >> TF_CNTSH;
+                    if (!(fc & TF_IGN)) {
+                        for (uint32_t k = 0; k < cnt; ++k) {
+                            uint32_t a = s_al[c * VC_MAXALN + k];
+                            uint8_t fa = s_flag[a];
+                            if ((fa & need) != need) continue;
+                            if ((fa & TF_MARK) != 2) {
+                                if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
+                                s_stack[sp++] = (uint16_t)a;
+                                s_flag[a] = fa | TF_IGN;
+                                valid = false;
+                            }
+                        }
+                        if (err) break;
+                    }
+                    fc = s_flag[c];
+                    if (valid) {
+                        s_flag[c] = (fc & ~TF_MARK) | 2;
+                        if (!(fc & TF_IGN)) {
+                            s_rank[nr++] = (uint16_t)c;
+                            for (uint32_t k = 0; k < cnt; ++k) {
+                                uint32_t a = s_al[c * VC_MAXALN + k];
+                                if ((s_flag[a] & need) != need) continue;
+                                s_rank[nr++] = (uint16_t)a;
+                            }
+                        }
+                    } else {
+                        if ((fc & TF_MARK) == 1) { err = VC_WIN_INVALID; break; }   // not a DAG
+                        s_flag[c] = (fc & ~TF_MARK) | 1;
+                    }
+                }
+                if (valid) sp--;
+            }
+        }
+        s_nrows = nr;
+        s_err = err;
+    }
+    __syncthreads();
+    if (s_err) { if (lane == 0) b.status[w] = (uint8_t)s_err; return; }
+    const uint32_t nrows = s_nrows;
+
+    // ---- row records (wave-parallel).  s_al is dead now: alias node->rank and two byte maps into it.
+    uint16_t* s_noderank = s_al;                       // [NC]
+    uint8_t*  s_hasout = (uint8_t*)(s_al + NC);        // [NC] by node
+    uint8_t*  s_spill = s_hasout + NC;                 // [NC] by rank
+    for (uint32_t i = lane; i < N; i += 64) { s_hasout[i] = 0; s_spill[i] = 0; }
+    __syncthreads();
+    for (uint32_t r = lane; r < nrows; r += 64) {
+        uint32_t v = s_rank[r];
+        s_noderank[v] = (uint16_t)r;
+        dp.rank2node[nb + r] = (uint16_t)v;
+    }
+    __syncthreads();
+    const uint8_t need = masked ? TF_SUB : 0;
+    // pass 1: out-degree and far-successor marks
+    for (uint32_t r = lane; r < nrows; r += 64) {
+        uint32_t v = s_rank[r];
+        for (uint32_t e = s_in_first[v]; e != VC_NONE16; ) {
+            uint32_t tn = s_etn[e];
+            uint32_t t = tn & 0xFFFF;
+            e = tn >> 16;
+            if ((s_flag[t] & need) != need) continue;
+            s_hasout[t] = 1;
+            uint32_t delta = r - s_noderank[t];
+            if (delta > VC_RING) s_spill[s_noderank[t]] = 1;
+        }
+    }
+    __syncthreads();
+    // pass 2: records, overflow lists, spill slots
+    uint32_t ovf_base = 0, spill_base = 0;
+    int bad = 0;
+    for (uint32_t r0 = 0; r0 < nrows; r0 += 64) {
+        uint32_t r = r0 + lane;
+        bool act = r < nrows;
+        uint32_t v = act ? s_rank[r] : 0;
+        uint32_t np = 0;
+        uint16_t dl[VC_INLINE_PRED];
+#pragma unroll
+        for (int k = 0; k < VC_INLINE_PRED; ++k) dl[k] = 0;
+        if (act) {
+            for (uint32_t e = s_in_first[v]; e != VC_NONE16; ) {
+                uint32_t tn = s_etn[e];
+                uint32_t t = tn & 0xFFFF;
+                e = tn >> 16;
+                if ((s_flag[t] & need) != need) continue;
+                uint32_t delta = r - s_noderank[t];
+#pragma unroll
+                for (int k = 0; k < VC_INLINE_PRED; ++k) if (np == (uint32_t)k) dl[k] = (uint16_t)delta;
+                np++;
+            }
+        }
+        bool is_ovf = np > VC_INLINE_PRED;
+        uint32_t tot_ovf;
+        uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
+        uint32_t sp_flag = act ? s_spill[r] : 0u;
+        uint32_t tot_sp;
+        uint32_t my_sp = wave_excl_sum(sp_flag, tot_sp) + spill_base;
+        if (act) {
+            if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }   // virtual row 0 is `row` rows above
+            if (np > 255) bad = 1;
+            if (is_ovf) {
+                if (my_ovf + np > EC) bad = 1;
+                else {
+                    uint32_t k = 0;
+                    for (uint32_t e = s_in_first[v]; e != VC_NONE16; ) {
+                        uint32_t tn = s_etn[e];
+                        uint32_t t = tn & 0xFFFF;
+                        e = tn >> 16;
+                        if ((s_flag[t] & need) != need) continue;
+                        uint32_t delta = r - s_noderank[t];
+                        if (delta > VC_PAYLOAD_NEAR && k >= 16) bad = 1;
+                        dp.ovf[eb + my_ovf + k] = (uint16_t)delta;
+                        k++;
+                    }
+                }
+                dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
+            }
+            uint32_t fl = (s_hasout[v] ? 0u : VC_RF_SINK) | (sp_flag ? VC_RF_SPILL : 0u) | (is_ovf ? VC_RF_OVF : 0u);
+            uint4 rec;
+            rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
+            rec.y = dl[0] | ((uint32_t)dl[1] << 16);
+            rec.z = dl[2] | ((uint32_t)dl[3] << 16);
+            rec.w = dl[4] | ((uint32_t)dl[5] << 16);
+            dp.rec[nb + r] = rec;
+            dp.spill_slot[nb + r] = sp_flag ? (uint16_t)my_sp : VC_NONE16;
+        }
+        ovf_base += tot_ovf;
+        spill_base += tot_sp;
+    }
+    if (spill_base > VC_SPILLCAP) bad = 1;
+    bad = __any(bad);
+    if (lane == 0) {
+        dp.nrows[slot] = nrows;
+        dp.flags[slot] = bad ? 1u : 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fwd: linear-gap graph DP, one alignment per wavefront.
+//   columns: lane l owns columns l*CPL+1 .. l*CPL+CPL (contiguous), column 0 is a per-row scalar
+//   scores:  32-bit lanes hold H<<16; the low 16 bits of a candidate carry a tie-break tag
+//            ((255 - p) << 8 | payload) so that one v_max picks "largest score, first predecessor in
+//            in-edge order" -- exactly the order sisd_alignment_engine.cpp:392-448 scans when it backtracks
+//   rows:    the last VC_RING rows live in LDS as packed int16; rows a far successor needs go to HBM
+//   output:  one direction byte per cell (HBM, coalesced dwords) + the end cell
+// mode: 0 build (NW), 1 re-alignment (NW for backbone/full-span else SW), 2 final SW of the backbone
+// ------------------------------------------------------------------------------------------------
+struct VcFwdArgs {
+    VcBatchDev b;
+    VcDp dp;
+    uint32_t w0, nslots, NC, EC;
+    uint32_t group, k0;            // jobs per slot in this launch, first sequence index
+    int mode;
+    int m, n, g;                   // NW scores
+    int sm, sn, sg;                // SW scores
+    uint8_t*  dir;                 // [jobs * dir_stride]
+    uint64_t  dir_stride;          // bytes
+    uint8_t*  dir0;                // [jobs * NC]
+    uint2*    spill;               // [jobs * VC_SPILLCAP * (NP*64 + 64)]
+    uint32_t* job_end;             // [jobs] (row << 16) | col ; 0 = empty alignment
+    uint8_t*  job_type;            // [jobs] 0 SW, 1 NW, 255 skipped
+    unsigned long long* stat_cells;
+    unsigned long long* stat_rows;
+};
+
+#define VC_DPP_SHR(v, old, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xF, false)
+
+template <int CPL>
+__global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
+    constexpr int NP = CPL / 4;
+    __shared__ uint2 ring[VC_RING][NP][64];
+    __shared__ int ring_c0[VC_RING];
+    const int lane = vc_lane();
+    const uint32_t job = blockIdx.x;
+    const uint32_t slot = job / a.group;
+    if (slot >= a.nslots) return;
+    const uint32_t k = a.k0 + job % a.group;
+    const uint32_t w = a.w0 + slot;
+    if (lane == 0) { a.job_type[job] = 255; a.job_end[job] = 0; }
+    if (a.b.status[w] != VC_WIN_OK) return;
+    const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
+    if (k >= ns) return;
+    const uint64_t so = a.b.seq_off[s0 + k];
+    const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k + 1] - so);
+    const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
+    bool nw = true;
+    if (a.mode == 2) nw = false;
+    else if (a.mode == 1) nw = (k == 0) || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L);   // window.cpp:336-349
+    const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
+    const uint32_t nrows = a.dp.nrows[slot];
+    const uint64_t nb = (uint64_t)slot * a.NC;
+    // envelope: int16 scores like the reference's int16 lanes (simd impl:699-754), tag-able predecessors
+    {
+        long long li = (long long)len + 8, lj = nrows;
+        long long d = li > lj ? li - lj : lj - li, mn = li < lj ? li : lj;
+        long long wc1 = -1 * ((long long)m * mn + (d == 0 ? 0 : (long long)g * d));
+        long long wc2 = (long long)g * li + (long long)g * lj;
+        long long wc = wc1 < wc2 ? wc1 : wc2;
+        bool ok = wc >= -31744 && ((long long)(m - g) * (64 * CPL + 1) < 32767) && len <= 64u * CPL && len > 0 &&
+                  nrows > 0 && !(a.dp.flags[slot] & 1u);
+        if (!ok) {
+            if (lane == 0) a.b.status[w] = (len == 0 || nrows == 0) ? VC_WIN_INVALID : VC_WIN_UNSUPPORTED;
+            return;
+        }
+    }
+    if (lane == 0) {
+        a.job_type[job] = nw ? 1 : 0;
+        atomicAdd(a.stat_cells, (unsigned long long)nrows * len);
+        atomicAdd(a.stat_rows, (unsigned long long)nrows);
+    }
+
+    // sequence bytes of my columns (0xFF beyond the end: matches nothing)
+    uint32_t sb[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint32_t idx = lane * CPL + q * 4 + t;
+            uint32_t c = idx < len ? a.b.bases[so + idx] : 0xFFu;
+            v |= c << (8 * t);
+        }
+        sb[q] = v;
+    }
+    const int gs = g * 65536, ms = m * 65536, nsc = n * 65536;
+    int jgs[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) jgs[c] = (lane * CPL + c + 1) * g * 65536;
+
+    uint8_t* dirp = a.dir + (uint64_t)job * a.dir_stride;
+    uint8_t* dir0p = a.dir0 + (uint64_t)job * a.NC;
+    uint2* spillp = a.spill + (uint64_t)job * VC_SPILLCAP * (NP * 64 + 1);
+
+    // end-cell tracking
+    int best = nw ? VC_INT_MIN : 0;          // NW: uniform; SW: per lane, tagged with (CPL-1-c)
+    uint32_t best_row = 0;
+    const uint32_t lane_e = (len - 1) / CPL, c_e = (len - 1) % CPL;
+    uint32_t spill_cnt = 0;
+    int bad = 0;
+
+    uint4 myrec = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = 1; i <= nrows; ++i) {
+        const uint32_t ri = (i - 1) & 63;
+        if (ri == 0) {
+            uint32_t r = i - 1 + lane;
+            if (r < nrows) myrec = a.dp.rec[nb + r];
+        }
+        const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
+        const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
+        const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
+        const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
+        const uint32_t x = r0 & 0xFF, fl = (r0 >> 8) & 0xFF, np = (r0 >> 16) & 0xFF;
+
+        int prof[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) prof[c] = (((sb[c / 4] >> (8 * (c % 4))) & 0xFF) == x) ? ms : nsc;
+
+        int bd[CPL], bv[CPL];
+        int b0 = VC_INT_MIN;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { bd[c] = VC_INT_MIN; bv[c] = VC_INT_MIN; }
+
+        for (uint32_t p = 0; p < np; ++p) {
+            uint32_t delta;
+            if (fl & VC_RF_OVF) {
+                delta = a.dp.ovf[(uint64_t)slot * a.EC + r1 + p];
+            } else {
+                uint32_t wsel = p < 2 ? r1 : (p < 4 ? r2 : r3);
+                delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
+            }
+            const uint32_t pr = i - delta;
+            const uint32_t payload = delta <= VC_PAYLOAD_NEAR ? delta - 1 : (p < 16 ? VC_PAYLOAD_NEAR + p : 63u);
+            const int tag = (int)(((255u - p) << 8) | payload);
+            int hp[CPL];
+            int c0p;
+            if (pr == 0) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) hp[c] = nw ? jgs[c] : 0;     // H[0][j] = j*g (NW) / 0 (SW)
+                c0p = 0;
+            } else {
+                uint2 pc[NP];
+                if (delta <= VC_RING) {
+                    const uint32_t rs = pr % VC_RING;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) pc[q] = ring[rs][q][lane];
+                    c0p = ring_c0[rs];
+                } else {
+                    const uint32_t ss = a.dp.spill_slot[nb + pr - 1];
+                    const uint2* sp = spillp + (uint64_t)ss * (NP * 64 + 1);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) pc[q] = sp[q * 64 + lane];
+                    c0p = (int)sp[NP * 64].x;
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    hp[4 * q + 0] = (int)(pc[q].x << 16);
+                    hp[4 * q + 1] = (int)(pc[q].x & 0xFFFF0000u);
+                    hp[4 * q + 2] = (int)(pc[q].y << 16);
+                    hp[4 * q + 3] = (int)(pc[q].y & 0xFFFF0000u);
+                }
+            }
+            // left neighbour of my first column: lane-1's last cell, lane 0 takes the pred's column 0
+            const int hl = VC_DPP_SHR(hp[CPL - 1], c0p, 0x138, 0xF);
+            const int gt = gs + tag;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int dsrc = c == 0 ? hl : hp[c - 1];
+                bd[c] = max(bd[c], dsrc + prof[c] + tag);
+                bv[c] = max(bv[c], hp[c] + gt);
+            }
+            b0 = max(b0, c0p + gt);
+        }
+
+        // column 0: NW max over predecessors (Initialize, sisd :210-222); SW 0
+        const int col0 = nw ? (int)((uint32_t)b0 & 0xFFFF0000u) : 0;
+        // horizontal pass H[j] = max(H[j], H[j-1]+g) as a prefix max of H[j] - j*g  (sisd :347-349)
+        int P[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            int mx = (int)((uint32_t)max(bd[c], bv[c]) & 0xFFFF0000u);
+            if (!nw) mx = max(mx, 0);
+            P[c] = mx - jgs[c];
+        }
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) P[c] = max(P[c], P[c - 1]);
+        int sc = P[CPL - 1];
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x111, 0xF));
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x112, 0xF));
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x114, 0xF));
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x118, 0xF));
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x142, 0xA));
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x143, 0xC));
+        int carry = VC_DPP_SHR(sc, VC_INT_MIN, 0x138, 0xF);
+        carry = max(carry, col0);
+        int H[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) H[c] = max(P[c], carry) + jgs[c];
+
+        // direction codes
+        uint32_t dcode[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            uint32_t dwv = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = 4 * q + t;
+                const bool eqd = (uint32_t)(bd[c] - H[c]) < 0x10000u;
+                const bool eqv = (uint32_t)(bv[c] - H[c]) < 0x10000u;
+                uint32_t code = eqd ? ((uint32_t)bd[c] & 63u)
+                                    : (eqv ? (0x40u | ((uint32_t)bv[c] & 63u)) : 0x80u);
+                if (!nw) code = H[c] == 0 ? 0xC0u : code;
+                dwv |= code << (8 * t);
+            }
+            dcode[q] = dwv;
+        }
+        {
+            uint32_t* drow = (uint32_t*)(dirp + (uint64_t)(i - 1) * (64 * CPL));
+#pragma unroll
+            for (int q = 0; q < NP; ++q) drow[q * 64 + lane] = dcode[q];
+            if (lane == 0) dir0p[i - 1] = nw ? (uint8_t)(0x40u | ((uint32_t)b0 & 63u)) : (uint8_t)0xC0u;
+        }
+
+        // end cell
+        if (nw) {
+            if (fl & VC_RF_SINK) {                           // sisd :353-355
+                int v = H[0];
+#pragma unroll
+                for (int c = 1; c < CPL; ++c) v = (c_e == (uint32_t)c) ? H[c] : v;
+                v = __builtin_amdgcn_readlane(v, lane_e);
+                if (v > best) { best = v; best_row = i; }
+            }
+        } else {                                             // sisd :350-352
+            int rm = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const bool in = (uint32_t)(lane * CPL + c) < len;
+                const int t = in ? (H[c] | (CPL - 1 - c)) : 0;
+                rm = max(rm, t);
+            }
+            if ((int)((uint32_t)rm & 0xFFFF0000u) > (int)((uint32_t)best & 0xFFFF0000u)) { best = rm; best_row = i; }
+        }
+
+        // keep the row: LDS ring (+ HBM when a successor is more than VC_RING rows away)
+        uint2 pk[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            pk[q].x = __builtin_amdgcn_perm((uint32_t)H[4 * q + 1], (uint32_t)H[4 * q + 0], 0x07060302u);
+            pk[q].y = __builtin_amdgcn_perm((uint32_t)H[4 * q + 3], (uint32_t)H[4 * q + 2], 0x07060302u);
+        }
+        const uint32_t ws = i % VC_RING;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NP; ++q) ring[ws][q][lane] = pk[q];
+        if (lane == 0) ring_c0[ws] = col0;
+        if (fl & VC_RF_SPILL) {
+            if (spill_cnt < VC_SPILLCAP) {
+                uint2* sp = spillp + (uint64_t)spill_cnt * (NP * 64 + 1);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) sp[q * 64 + lane] = pk[q];
+                if (lane == 0) sp[NP * 64] = make_uint2((uint32_t)col0, 0u);
+            } else bad = 1;
+            spill_cnt++;
+            __threadfence_block();
+        }
+        __syncthreads();
+    }
+
+    // publish the end cell
+    uint32_t end = 0;
+    if (nw) {
+        end = (best_row << 16) | len;
+    } else {
+        const int bval = (int)((uint32_t)best & 0xFFFF0000u);
+        const int gmax = wave_max_i32(bval);
+        if (gmax > 0) {
+            const uint32_t rowc = (bval == gmax) ? best_row : 0xFFFFFFFFu;
+            const uint32_t rstar = wave_min_u32(rowc);
+            const unsigned long long msk = __ballot(bval == gmax && best_row == rstar);
+            const int lstar = __ffsll((long long)msk) - 1;
+            const uint32_t cstar = (CPL - 1) - ((uint32_t)__builtin_amdgcn_readlane(best, lstar) & 0xFFFFu);
+            end = (rstar << 16) | (uint32_t)(lstar * CPL + cstar + 1);
+        }
+    }
+    if (bad) { if (lane == 0) a.b.status[w] = VC_WIN_OVERFLOW; }
+    if (lane == 0) a.job_end[job] = end;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_trace: backtrack (sisd_alignment_engine.cpp:362-459), one alignment per thread.  Pairs are
+// emitted tail-first as (row << 16) | column, 0 meaning "-1"; consumers read them back to front.
+// ------------------------------------------------------------------------------------------------
+struct VcTraceArgs {
+    VcBatchDev b;
+    VcDp dp;
+    uint32_t w0, nslots, NC, EC, group, cpl;
+    const uint8_t* dir; uint64_t dir_stride;
+    const uint8_t* dir0;
+    const uint32_t* job_end;
+    const uint8_t* job_type;
+    uint32_t* pairs;          // [pair_jobs * PC]
+    uint32_t* npairs;         // [pair_jobs]
+    uint32_t PC;
+    uint32_t pair_group, pair_k0;   // pairs index = slot*pair_group + (k - pair_k0)
+    uint32_t k0;
+};
+
+__device__ __forceinline__ uint32_t vc_pred_row(const VcDp& dp, uint64_t nb, uint64_t eb, uint32_t i, uint32_t payload) {
+    if (payload < VC_PAYLOAD_NEAR) return i - (payload + 1);
+    const uint32_t p = payload - VC_PAYLOAD_NEAR;
+    const uint4 rec = dp.rec[nb + i - 1];
+    uint32_t delta;
+    if ((rec.x >> 8) & VC_RF_OVF) delta = dp.ovf[eb + rec.y + p];
+    else {
+        uint32_t wsel = p < 2 ? rec.y : (p < 4 ? rec.z : rec.w);
+        delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
+    }
+    return i - delta;
+}
+
+__global__ void k_trace(VcTraceArgs a) {
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= a.nslots * a.group) return;
+    const uint32_t slot = job / a.group, k = a.k0 + job % a.group;
+    const uint32_t w = a.w0 + slot;
+    const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
+    const uint8_t type = a.job_type[job];
+    if (type == 255) return;
+    if (a.b.status[w] != VC_WIN_OK) return;
+    uint32_t* out = a.pairs + pj * a.PC;
+    const uint32_t end = a.job_end[job];
+    uint32_t i = end >> 16, j = end & 0xFFFF;
+    const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
+    const uint8_t* dirp = a.dir + (uint64_t)job * a.dir_stride;
+    const uint8_t* dir0p = a.dir0 + (uint64_t)job * a.NC;
+    const uint32_t rowb = 64 * a.cpl;
+    uint32_t n = 0;
+    bool ovf = false;
+    if (end != 0) {
+        for (;;) {
+            if (type == 1) { if (i == 0 && j == 0) break; }
+            else           { if (i == 0 || j == 0) break; }
+            uint32_t pi_, pj_;
+            if (i == 0) { pi_ = 0; pj_ = j - 1; }                        // row 0: only the horizontal move matches
+            else {
+                uint32_t code;
+                if (j == 0) code = dir0p[i - 1];
+                else {
+                    const uint32_t ci = j - 1, lc = ci / a.cpl, c = ci % a.cpl;
+                    code = dirp[(uint64_t)(i - 1) * rowb + ((c >> 2) * 64 + lc) * 4 + (c & 3)];
+                }
+                const uint32_t kind = code >> 6, payload = code & 63;
+                if (kind == VC_K_STOP) break;
+                if (kind == VC_K_DIAG)      { pi_ = vc_pred_row(a.dp, nb, eb, i, payload); pj_ = j - 1; }
+                else if (kind == VC_K_VERT) { pi_ = vc_pred_row(a.dp, nb, eb, i, payload); pj_ = j; }
+                else                        { pi_ = i; pj_ = j - 1; }
+            }
+            if (n >= a.PC) { ovf = true; break; }
+            out[n++] = ((i == pi_ ? 0u : i) << 16) | (j == pj_ ? 0u : j);
+            i = pi_; j = pj_;
+        }
+    }
+    if (ovf) { a.b.status[w] = VC_WIN_OVERFLOW; n = 0; }
+    a.npairs[pj] = n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_addaln: Graph::AddAlignment (graph.cpp:182-299) for the layer just aligned, wave-parallel.
+// The reference walks the alignment serially; every decision it takes depends only on the graph
+// BEFORE the call (a path visits a node, and an aligned group, at most once), so node/edge ids are
+// reproduced with prefix sums over the pair list: new ids are handed out in alignment order exactly
+// as nodes_.size()/edges_.size() would grow.
+// ------------------------------------------------------------------------------------------------
+struct VcAddArgs {
+    VcBatchDev b;
+    VcGraph g;
+    VcDp dp;
+    uint32_t w0, nslots, NC, EC, layer;
+    const uint32_t* pairs; const uint32_t* npairs; uint32_t PC;
+};
+
+__global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t* s_curr = (uint16_t*)smem;                 // [PC] node chosen for each pair (forward order)
+    const uint32_t slot = blockIdx.x;
+    if (slot >= a.nslots) return;
+    const uint32_t w = a.w0 + slot;
+    if (a.b.status[w] != VC_WIN_OK) return;
+    const int lane = vc_lane();
+    const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
+    if (a.layer >= ns) return;
+    const uint64_t so = a.b.seq_off[s0 + a.layer];
+    const uint32_t len = (uint32_t)(a.b.seq_off[s0 + a.layer + 1] - so);
+    const bool hq = a.b.seq_has_qual[s0 + a.layer] != 0;
+    const uint32_t P = a.npairs[slot];
+    const uint32_t* pr = a.pairs + (uint64_t)slot * a.PC;
+    const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
+    const uint32_t N0 = a.g.n_nodes[slot], E0 = a.g.n_edges[slot];
+    int err = 0;
+
+    // pass A: choose the node of every aligned base; count new nodes
+    uint32_t nnew = 0, nvalid = 0;
+    for (uint32_t f0 = 0; f0 < P; f0 += 64) {
+        const uint32_t f = f0 + lane;
+        const bool act = f < P;
+        uint32_t pv = act ? pr[P - 1 - f] : 0;
+        const uint32_t row = pv >> 16, col = pv & 0xFFFF;
+        const bool valid = act && col != 0;
+        uint32_t curr = VC_NONE16;
+        bool isnew = false;
+        if (valid) {
+            const uint8_t c = a.b.bases[so + col - 1];
+            if (row == 0) isnew = true;                                    // graph.cpp:249-251
+            else {
+                const uint32_t nd = a.dp.rank2node[nb + row - 1];
+                if (a.g.code[nb + nd] == c) curr = nd;                     // :254-257
+                else {
+                    const uint32_t cnt = a.g.al_cnt[nb + nd];
+                    for (uint32_t t = 0; t < cnt; ++t) {                   // :258-266
+                        const uint32_t al = a.g.al[(nb + nd) * VC_MAXALN + t];
+                        if (a.g.code[nb + al] == c) { curr = al; break; }
+                    }
+                    if (curr == VC_NONE16) isnew = true;                   // :267-277
+                }
+            }
+        }
+        uint32_t tot;
+        const uint32_t my = wave_excl_sum(isnew ? 1u : 0u, tot);
+        if (isnew) curr = N0 + nnew + my;
+        if (act) s_curr[f] = valid ? (uint16_t)curr : VC_NONE16;
+        nnew += tot;
+        nvalid += __popcll(__ballot(valid));
+    }
+    // every base must be aligned (NW alignments always are); otherwise the reference would add
+    // unaligned prefix/suffix chains (graph.cpp:233-236), which this flow never produces
+    if (nvalid != len || P == 0) err = VC_WIN_INVALID;
+    if (N0 + nnew > a.NC || N0 + nnew >= 0xFFFF) err = VC_WIN_OVERFLOW;
+    if (err) { if (lane == 0) a.b.status[w] = (uint8_t)err; return; }
+    __syncthreads();
+
+    // pass B: create nodes, extend aligned groups
+    for (uint32_t f0 = 0; f0 < P; f0 += 64) {
+        const uint32_t f = f0 + lane;
+        if (f >= P) continue;
+        const uint32_t pv = pr[P - 1 - f];
+        const uint32_t row = pv >> 16, col = pv & 0xFFFF;
+        if (col == 0) continue;
+        const uint32_t curr = s_curr[f];
+        if (curr < N0) continue;
+        a.g.code[nb + curr] = a.b.bases[so + col - 1];
+        a.g.in_first[nb + curr] = VC_NONE16; a.g.in_last[nb + curr] = VC_NONE16;
+        a.g.out_first[nb + curr] = VC_NONE16; a.g.out_last[nb + curr] = VC_NONE16;
+        uint32_t mycnt = 0;
+        if (row != 0) {
+            const uint32_t nd = a.dp.rank2node[nb + row - 1];
+            const uint32_t cnt = a.g.al_cnt[nb + nd];
+            if (cnt + 1 > VC_MAXALN) { err = VC_WIN_UNSUPPORTED; }
+            else {
+                for (uint32_t t = 0; t < cnt; ++t) {
+                    const uint32_t al = a.g.al[(nb + nd) * VC_MAXALN + t];
+                    const uint32_t ac = a.g.al_cnt[nb + al];
+                    if (ac + 1 > VC_MAXALN) { err = VC_WIN_UNSUPPORTED; break; }
+                    a.g.al[(nb + al) * VC_MAXALN + ac] = (uint16_t)curr;
+                    a.g.al_cnt[nb + al] = (uint8_t)(ac + 1);
+                    a.g.al[(nb + curr) * VC_MAXALN + t] = (uint16_t)al;
+                }
+                a.g.al[(nb + nd) * VC_MAXALN + cnt] = (uint16_t)curr;
+                a.g.al_cnt[nb + nd] = (uint8_t)(cnt + 1);
+                a.g.al[(nb + curr) * VC_MAXALN + cnt] = (uint16_t)nd;
+                mycnt = cnt + 1;
+            }
+        }
+        a.g.al_cnt[nb + curr] = (uint8_t)mycnt;
+    }
+    if (__any(err)) { if (lane == 0) a.b.status[w] = VC_WIN_UNSUPPORTED; return; }
+    __syncthreads();      // pass B's stores are complete before pass C touches the same nodes
+
+    // pass C: edges between consecutive aligned bases (graph.cpp:282-290 -> AddEdge :94-107)
+    uint32_t enew = 0;
+    uint32_t carry_prev = VC_NONE16;                   // node of the last aligned base of earlier chunks
+    for (uint32_t f0 = 0; f0 < P; f0 += 64) {
+        const uint32_t f = f0 + lane;
+        const bool act = f < P;
+        const uint32_t pv = act ? pr[P - 1 - f] : 0;
+        const uint32_t col = pv & 0xFFFF;
+        const uint32_t curr = act ? s_curr[f] : VC_NONE16;
+        const bool valid = act && col != 0;
+        // previous aligned base: nearest lower lane with valid, else carry
+        const unsigned long long vm = __ballot(valid);
+        const unsigned long long below = vm & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __clzll((long long)below) : lane;
+        const uint32_t pv_prev = (uint32_t)__shfl((int)curr, src, 64);     // outside divergent code
+        const uint32_t prev = below ? pv_prev : carry_prev;
+        bool make = false;
+        uint32_t wgt = 0;
+        if (valid && prev != VC_NONE16) {
+            const uint32_t q = col - 1;
+            wgt = vc_weight(a.b, so, q - 1, hq) + vc_weight(a.b, so, q, hq);
+            uint32_t found = VC_NONE16;
+            if (prev < N0 && curr < N0) {
+                for (uint32_t e = a.g.out_first[nb + prev]; e != VC_NONE16; ) {
+                    const uint32_t hn = a.g.e_hn[eb + e];
+                    if ((hn & 0xFFFF) == curr) { found = e; break; }
+                    e = hn >> 16;
+                }
+            }
+            if (found != VC_NONE16) a.g.e_w[eb + found] += wgt;
+            else make = true;
+        }
+        uint32_t tot;
+        const uint32_t my = wave_excl_sum(make ? 1u : 0u, tot);
+        if (make) {
+            const uint32_t e = E0 + enew + my;
+            if (e >= a.EC || e >= 0xFFFF) err = VC_WIN_OVERFLOW;
+            else {
+                a.g.e_tn[eb + e] = prev | ((uint32_t)VC_NONE16 << 16);
+                a.g.e_hn[eb + e] = curr | ((uint32_t)VC_NONE16 << 16);
+                a.g.e_w[eb + e] = wgt;
+                // append to prev's out-list
+                const uint32_t ol = prev < N0 ? a.g.out_last[nb + prev] : VC_NONE16;
+                if (ol == VC_NONE16) a.g.out_first[nb + prev] = (uint16_t)e;
+                else a.g.e_hn[eb + ol] = (a.g.e_hn[eb + ol] & 0xFFFF) | (e << 16);
+                a.g.out_last[nb + prev] = (uint16_t)e;
+                // append to curr's in-list
+                const uint32_t il = curr < N0 ? a.g.in_last[nb + curr] : VC_NONE16;
+                if (il == VC_NONE16) a.g.in_first[nb + curr] = (uint16_t)e;
+                else a.g.e_tn[eb + il] = (a.g.e_tn[eb + il] & 0xFFFF) | (e << 16);
+                a.g.in_last[nb + curr] = (uint16_t)e;
+            }
+        }
+        enew += tot;
+        if (vm) {
+            const int last = 63 - __clzll((long long)vm);
+            carry_prev = (uint32_t)__shfl((int)curr, last, 64);
+        }
+    }
+    if (__any(err)) { if (lane == 0) a.b.status[w] = VC_WIN_OVERFLOW; return; }
+    if (lane == 0) { a.g.n_nodes[slot] = N0 + nnew; a.g.n_edges[slot] = E0 + enew; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_prune_lcc: PruneGraph (graph.cpp:811-982) + LargestSubgraph (graph.cpp:984-1102): src -> dst.
+// LDS carve: adj_off 2*(NC+1) | adj 4*EC (u16 x 2E) | vis/newid 2*NC | nin 2*NC | keep EC |
+//            { osum 4*NC, isum 4*NC }  aliased later by { frames 4*NC, comp 2*NC, best 2*NC }
+// ------------------------------------------------------------------------------------------------
+struct VcPruneArgs {
+    VcBatchDev b;
+    VcGraph src, dst;
+    uint32_t w0, nslots, NC, EC;
+    double min_conf, min_supp;
+};
+
+__host__ __device__ inline uint32_t vc_prune_lds_bytes(uint32_t NC, uint32_t EC) {
+    return ((2 * (NC + 1) + 15) & ~15u) + 4 * EC + 2 * NC + 2 * NC + ((EC + 15) & ~15u) + 8 * NC + 64;
+}
+
+__global__ __launch_bounds__(64) void k_prune_lcc(VcPruneArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t slot = blockIdx.x;
+    if (slot >= a.nslots) return;
+    const uint32_t w = a.w0 + slot;
+    if (a.b.status[w] != VC_WIN_OK) return;
+    const int lane = vc_lane();
+    const uint32_t NC = a.NC, EC = a.EC;
+    const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
+    const uint32_t N = a.src.n_nodes[slot], E = a.src.n_edges[slot];
+    const double avg = a.b.win_avg[w];
+
+    uint16_t* s_adj_off = (uint16_t*)smem;                                     // [NC+1]
+    uint16_t* s_adj = (uint16_t*)(smem + ((2 * (NC + 1) + 15) & ~15u));        // [2*EC]
+    uint16_t* s_vis = s_adj + 2 * EC;                                          // [NC] visited, later newid
+    uint16_t* s_nin = s_vis + NC;                                              // [NC] live in-degree
+    uint8_t*  s_keep = (uint8_t*)(s_nin + NC);                                 // [EC]
+    uint32_t* s_osum = (uint32_t*)(s_keep + ((EC + 15) & ~15u));               // [NC]
+    uint32_t* s_isum = s_osum + NC;                                            // [NC]
+    uint32_t* s_frame = s_osum;                                                // [NC] (v | cursor << 16)
+    uint16_t* s_comp = (uint16_t*)(s_frame + NC);                              // [NC]
+    uint16_t* s_best = s_comp + NC;                                            // [NC]
+
+    // 1. weight totals around every node (the reference re-sums them per edge, graph.cpp:845-872)
+    for (uint32_t v = lane; v < N; v += 64) {
+        uint32_t so_ = 0, si_ = 0;
+        for (uint32_t e = a.src.out_first[nb + v]; e != VC_NONE16; e = a.src.e_hn[eb + e] >> 16) so_ += a.src.e_w[eb + e];
+        for (uint32_t e = a.src.in_first[nb + v]; e != VC_NONE16; e = a.src.e_tn[eb + e] >> 16) si_ += a.src.e_w[eb + e];
+        s_osum[v] = so_; s_isum[v] = si_;
+    }
+    __syncthreads();
+    // 2. keep / prune decision per edge, fp64 exactly as graph.cpp:861-904 (0/0 = NaN compares false)
+    for (uint32_t e = lane; e < E; e += 64) {
+        const uint32_t t = a.src.e_tn[eb + e] & 0xFFFF, h = a.src.e_hn[eb + e] & 0xFFFF;
+        const double wv = (double)(long long)a.src.e_w[eb + e];
+        const double cuv = wv / (double)(long long)s_osum[t];
+        const double sup = wv / avg;
+        const double cvu = wv / (double)(long long)s_isum[h];
+        s_keep[e] = (cuv >= a.min_conf && cvu >= a.min_conf && sup >= a.min_supp) ? 1 : 0;
+    }
+    __syncthreads();
+    // 3. adjacency of the pruned graph: live in-edge tails (list order) then live out-edge heads (list order)
+    uint32_t base = 0;
+    for (uint32_t v0 = 0; v0 < N; v0 += 64) {
+        const uint32_t v = v0 + lane;
+        uint32_t din = 0, dout = 0;
+        if (v < N) {
+            for (uint32_t e = a.src.in_first[nb + v]; e != VC_NONE16; e = a.src.e_tn[eb + e] >> 16) din += s_keep[e];
+            for (uint32_t e = a.src.out_first[nb + v]; e != VC_NONE16; e = a.src.e_hn[eb + e] >> 16) dout += s_keep[e];
+        }
+        uint32_t tot;
+        const uint32_t off = wave_excl_sum(din + dout, tot) + base;
+        if (v < N) {
+            s_adj_off[v] = (uint16_t)off;
+            s_nin[v] = (uint16_t)din;
+            uint32_t k = off;
+            for (uint32_t e = a.src.in_first[nb + v]; e != VC_NONE16; ) {
+                const uint32_t tn = a.src.e_tn[eb + e];
+                if (s_keep[e]) s_adj[k++] = (uint16_t)(tn & 0xFFFF);
+                e = tn >> 16;
+            }
+            for (uint32_t e = a.src.out_first[nb + v]; e != VC_NONE16; ) {
+                const uint32_t hn = a.src.e_hn[eb + e];
+                if (s_keep[e]) s_adj[k++] = (uint16_t)(hn & 0xFFFF);
+                e = hn >> 16;
+            }
+            s_vis[v] = 0;
+        }
+        base += tot;
+    }
+    if (lane == 0) s_adj_off[N] = (uint16_t)base;
+    __syncthreads();
+
+    // 4. components by recursive preorder DFS (DfsUtil, graph.cpp:984-1019); `>=` keeps the later one (:1049)
+    __shared__ uint32_t s_nbest;
+    if (lane == 0) {
+        uint32_t nbest = 0;
+        for (uint32_t r = 0; r < N; ++r) {
+            if (s_vis[r]) continue;
+            uint32_t nc = 0, sp = 0;
+            s_vis[r] = 1; s_comp[nc++] = (uint16_t)r;
+            s_frame[sp++] = r | ((uint32_t)s_adj_off[r] << 16);
+            while (sp) {
+                const uint32_t fr = s_frame[sp - 1];
+                const uint32_t v = fr & 0xFFFF;
+                uint32_t k = fr >> 16;
+                const uint32_t kend = s_adj_off[v + 1];
+                uint32_t u = VC_NONE16;
+                while (k < kend) {
+                    const uint32_t cand = s_adj[k++];
+                    if (!s_vis[cand]) { u = cand; break; }
+                }
+                if (u == VC_NONE16) { sp--; continue; }
+                s_frame[sp - 1] = v | (k << 16);
+                s_vis[u] = 1; s_comp[nc++] = (uint16_t)u;
+                s_frame[sp++] = u | ((uint32_t)s_adj_off[u] << 16);
+            }
+            if (nc >= nbest) {
+                nbest = nc;
+                for (uint32_t k = 0; k < nc; ++k) s_best[k] = s_comp[k];
+            }
+        }
+        s_nbest = nbest;
+    }
+    __syncthreads();
+    const uint32_t nbest = s_nbest;
+
+    // 5. the new graph: nodes in DFS preorder, edges per node in out-list order with weight 0 (:1069-1085)
+    uint16_t* s_newid = s_vis;
+    for (uint32_t v = lane; v < N; v += 64) s_newid[v] = VC_NONE16;
+    __syncthreads();
+    for (uint32_t k = lane; k < nbest; k += 64) s_newid[s_best[k]] = (uint16_t)k;
+    __syncthreads();
+    uint16_t* s_obase = s_comp;                       // first new edge id of every new node
+    uint32_t ebase = 0;
+    for (uint32_t k0 = 0; k0 < nbest; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        uint32_t od = 0, v = 0, ob = 0;
+        if (k < nbest) {
+            v = s_best[k];
+            ob = s_adj_off[v] + s_nin[v];
+            od = s_adj_off[v + 1] - ob;
+        }
+        uint32_t tot;
+        const uint32_t my = wave_excl_sum(od, tot) + ebase;
+        if (k < nbest) {
+            s_obase[k] = (uint16_t)my;
+            a.dst.code[nb + k] = a.src.code[nb + v];
+            a.dst.al_cnt[nb + k] = 0;
+            a.dst.out_first[nb + k] = od ? (uint16_t)my : VC_NONE16;
+            a.dst.out_last[nb + k] = od ? (uint16_t)(my + od - 1) : VC_NONE16;
+            for (uint32_t t = 0; t < od; ++t) {
+                const uint32_t hnew = s_newid[s_adj[ob + t]];
+                const uint32_t nxt = t + 1 < od ? my + t + 1 : VC_NONE16;
+                a.dst.e_hn[eb + my + t] = hnew | (nxt << 16);
+                a.dst.e_w[eb + my + t] = 0;
+            }
+        }
+        ebase += tot;
+    }
+    __syncthreads();
+    // in-lists: edges into h' ordered by new edge id == by the preorder position of their tails
+    for (uint32_t k = lane; k < nbest; k += 64) {
+        const uint32_t v = s_best[k];
+        const uint32_t nin = s_nin[v];
+        const uint32_t ib = s_adj_off[v];
+        uint32_t prev_e = VC_NONE16, prev_t = 0, first_e = VC_NONE16;
+        uint32_t last_t = 0;
+        for (uint32_t t = 0; t < nin; ++t) {
+            uint32_t bt = 0xFFFFFFFFu;                 // next smallest tail (new numbering) not yet placed
+            for (uint32_t u = 0; u < nin; ++u) {
+                const uint32_t tl = s_newid[s_adj[ib + u]];
+                if ((t == 0 || tl > last_t) && tl < bt) bt = tl;
+            }
+            last_t = bt;
+            const uint32_t tv = s_best[bt];            // its edge id: position of v among tv's live out-heads
+            const uint32_t tob = s_adj_off[tv] + s_nin[tv], toe = s_adj_off[tv + 1];
+            uint32_t eid = VC_NONE16;
+            for (uint32_t x = tob; x < toe; ++x) if (s_adj[x] == v) { eid = s_obase[bt] + (x - tob); break; }
+            if (prev_e == VC_NONE16) first_e = eid;
+            else a.dst.e_tn[eb + prev_e] = prev_t | (eid << 16);
+            prev_e = eid; prev_t = bt;
+        }
+        if (prev_e != VC_NONE16) a.dst.e_tn[eb + prev_e] = prev_t | ((uint32_t)VC_NONE16 << 16);
+        a.dst.in_first[nb + k] = (uint16_t)first_e;
+        a.dst.in_last[nb + k] = (uint16_t)prev_e;
+    }
+    if (lane == 0) { a.dst.n_nodes[slot] = nbest; a.dst.n_edges[slot] = ebase; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_addw: Graph::AddWeights (graph.cpp:1104-1165) for every re-aligned sequence of the window.
+// Consecutive fully matched pairs are always joined by an existing edge (a diagonal move is a step
+// along an in-edge), so this is a scatter-add; the sum is order-independent.
+// ------------------------------------------------------------------------------------------------
+struct VcAddwArgs {
+    VcBatchDev b;
+    VcGraph g;
+    VcDp dp;
+    uint32_t w0, nslots, NC, EC;
+    const uint32_t* pairs; const uint32_t* npairs; uint32_t PC; uint32_t pair_group;
+};
+
+__global__ __launch_bounds__(64) void k_addw(VcAddwArgs a) {
+    const uint32_t slot = blockIdx.x;
+    if (slot >= a.nslots) return;
+    const uint32_t w = a.w0 + slot;
+    if (a.b.status[w] != VC_WIN_OK) return;
+    const int lane = vc_lane();
+    const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
+    const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
+    int err = 0;
+    for (uint32_t k = 0; k < ns && k < a.pair_group; ++k) {
+        const uint64_t pj = (uint64_t)slot * a.pair_group + k;
+        const uint32_t P = a.npairs[pj];
+        const uint32_t* pr = a.pairs + pj * a.PC;
+        const uint64_t so = a.b.seq_off[s0 + k];
+        const bool hq = a.b.seq_has_qual[s0 + k] != 0;
+        // stored tail-first: forward neighbours (f-1, f) are stored at (x+1, x)
+        for (uint32_t x = lane; x + 1 < P; x += 64) {
+            const uint32_t cur = pr[x], prv = pr[x + 1];
+            if ((cur >> 16) == 0 || (cur & 0xFFFF) == 0 || (prv >> 16) == 0 || (prv & 0xFFFF) == 0) continue;
+            const uint32_t nprev = a.dp.rank2node[nb + (prv >> 16) - 1];
+            const uint32_t ncur = a.dp.rank2node[nb + (cur >> 16) - 1];
+            const uint32_t q = (cur & 0xFFFF) - 1;
+            const uint32_t wgt = vc_weight(a.b, so, q - 1, hq) + vc_weight(a.b, so, q, hq);
+            uint32_t found = VC_NONE16;
+            for (uint32_t e = a.g.out_first[nb + nprev]; e != VC_NONE16; ) {
+                const uint32_t hn = a.g.e_hn[eb + e];
+                if ((hn & 0xFFFF) == ncur) { found = e; break; }
+                e = hn >> 16;
+            }
+            if (found == VC_NONE16) err = 1;
+            else atomicAdd(&a.g.e_w[eb + found], wgt);
+        }
+    }
+    if (__any(err)) { if (lane == 0) a.b.status[w] = VC_WIN_INVALID; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finish: GenerateCorrectedSequence (graph.cpp:1167-1179) from the final local alignment
+// ------------------------------------------------------------------------------------------------
+struct VcFinishArgs {
+    VcBatchDev b;
+    VcGraph g;
+    VcDp dp;
+    uint32_t w0, nslots, NC;
+    const uint32_t* pairs; const uint32_t* npairs; uint32_t PC;
+};
+
+__global__ __launch_bounds__(64) void k_finish(VcFinishArgs a) {
+    const uint32_t slot = blockIdx.x;
+    if (slot >= a.nslots) return;
+    const uint32_t w = a.w0 + slot;
+    if (a.b.status[w] != VC_WIN_OK) return;
+    const int lane = vc_lane();
+    const uint64_t nb = (uint64_t)slot * a.NC;
+    const uint32_t P = a.npairs[slot];
+    const uint32_t* pr = a.pairs + (uint64_t)slot * a.PC;
+    uint32_t outn = 0;
+    int err = 0;
+    for (uint32_t f0 = 0; f0 < P; f0 += 64) {
+        const uint32_t f = f0 + lane;
+        const uint32_t pv = f < P ? pr[P - 1 - f] : 0;
+        const bool has = (pv >> 16) != 0;
+        uint32_t tot;
+        const uint32_t my = wave_excl_sum(has ? 1u : 0u, tot);
+        if (has) {
+            const uint32_t pos = outn + my;
+            if (pos < a.b.cons_cap) a.b.cons[(uint64_t)w * a.b.cons_cap + pos] = a.g.code[nb + a.dp.rank2node[nb + (pv >> 16) - 1]];
+            else err = 1;
+        }
+        outn += tot;
+    }
+    if (__any(err)) { if (lane == 0) { a.b.status[w] = VC_WIN_OVERFLOW; a.b.cons_len[w] = 0; } return; }
+    if (lane == 0) a.b.cons_len[w] = outn;
+}
+
+__global__ void k_max_u32(const uint32_t* v, uint32_t n, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicMax(out, v[i]);
+}
+
+// compacts the per-window consensus slots into one contiguous buffer (offsets from an exclusive scan)
+__global__ void k_gather_cons(VcBatchDev b, const uint64_t* off, uint8_t* out, uint64_t cap) {
+    const uint32_t w = blockIdx.x;
+    if (w >= b.n_windows) return;
+    const uint64_t o = off[w];
+    const uint32_t n = b.cons_len[w];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (o + i < cap) out[o + i] = b.cons[(uint64_t)w * b.cons_cap + i];
+}

@@ -1,0 +1,159 @@
+"""Python mirror of the reference's accelerated batch interface for the hot path.
+
+`HipBatchProcessor` keeps the four-method shape of the reference's CUDABatchProcessor
+(src/cuda/cudabatch.hpp:39-59: addWindow / hasWindows / generateConsensus / reset) and `Window`
+mirrors racon::Window (src/window.hpp:27-55: createWindow / add_layer / consensus).  All compute
+goes through libvechat_hip.so's C ABI; nothing here computes consensus on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class VcError(RuntimeError):
+    pass
+
+
+class HipContext:
+    """Owns a vc_ctx (one device, one stream)."""
+
+    def __init__(self, params=None, **kw):
+        self.lib = capi.load_hip()
+        self.params = params or capi.default_params(**kw)
+        h = C.c_void_p()
+        rc = self.lib.vc_create(C.byref(h), C.byref(self.params))
+        if rc != 0:
+            raise VcError(f"vc_create failed ({rc}): {self.lib.vc_last_error(None).decode()}")
+        self.h = h
+        self._batch = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise VcError(f"{what} failed ({rc}): {self.lib.vc_last_error(self.h).decode()}")
+
+    def submit(self, batch: capi.Batch):
+        self._batch = batch                     # keep the numpy arrays alive during the H2D copies
+        vb = batch.as_struct()
+        self._chk(self.lib.vc_submit(self.h, C.byref(vb)), "vc_submit")
+
+    def run(self):
+        self._chk(self.lib.vc_run(self.h), "vc_run")
+
+    def sync(self):
+        self._chk(self.lib.vc_sync(self.h), "vc_sync")
+
+    def collect(self):
+        """-> (list of consensus bytes per window, status array)"""
+        n = self._batch.n_windows
+        size = C.c_uint64(0)
+        self._chk(self.lib.vc_result_size(self.h, C.byref(size)), "vc_result_size")
+        cons = np.zeros(max(int(size.value), 1), np.uint8)
+        off = np.zeros(n + 1, np.uint64)
+        status = np.zeros(n, np.uint8)
+        r = capi.VcResult(off.ctypes.data_as(C.POINTER(C.c_uint64)), cons.ctypes.data_as(C.POINTER(C.c_uint8)),
+                          cons.size, status.ctypes.data_as(C.POINTER(C.c_uint8)))
+        self._chk(self.lib.vc_collect(self.h, C.byref(r)), "vc_collect")
+        out = [cons[int(off[w]):int(off[w + 1])].tobytes() for w in range(n)]
+        return out, status
+
+    def stats(self):
+        s = capi.VcStats()
+        self._chk(self.lib.vc_get_stats(self.h, C.byref(s)), "vc_get_stats")
+        d = dict(cells=int(s.cells), alignments=int(s.alignments), dp_rows=int(s.dp_rows),
+                 max_nodes=int(s.max_nodes), max_edges=int(s.max_edges), chunk_windows=int(s.chunk_windows),
+                 kernels={})
+        for i in range(s.n_classes):
+            d["kernels"][s.names[i].value.decode()] = dict(ms=float(s.ms[i]), launches=int(s.launches[i]))
+        return d
+
+    def consensus(self, batch: capi.Batch):
+        self.submit(batch)
+        self.run()
+        self.sync()
+        return self.collect()
+
+
+class Window:
+    """racon::Window (src/window.hpp:27-55): backbone + layers as borrowed byte strings."""
+
+    def __init__(self, id_, rank, window_type, backbone, quality):
+        if len(backbone) == 0 or len(backbone) != len(quality.rstrip(b"\0")[:len(backbone)]):
+            raise ValueError("[racon::createWindow] error: empty backbone sequence/unequal quality length!")
+        self.id, self.rank, self.type = id_, rank, window_type
+        self.sequences = [backbone]
+        self.qualities = [quality]          # may be longer than the backbone (pointer into a longer buffer)
+        self.positions = [(0, 0)]
+        self.consensus = b""
+
+    def add_layer(self, sequence, quality, begin, end):
+        """Window::add_layer (src/window.cpp:47-72)."""
+        if len(sequence) == 0 or begin == end:
+            return
+        if quality is not None and len(sequence) != len(quality):
+            raise ValueError("[racon::Window::add_layer] error: unequal quality size!")
+        L = len(self.sequences[0])
+        if begin >= end or begin > L or end > L:
+            raise ValueError("[racon::Window::add_layer] error: layer begin and end positions are invalid!")
+        self.sequences.append(sequence)
+        self.qualities.append(quality)
+        self.positions.append((begin, end))
+
+
+def create_window(id_, rank, window_type, backbone, quality):
+    """racon::createWindow (src/window.cpp:17-31)."""
+    return Window(id_, rank, window_type, backbone, quality)
+
+
+class HipBatchProcessor:
+    """addWindow / hasWindows / generateConsensus / reset, as src/cuda/cudabatch.hpp:39-59."""
+
+    def __init__(self, ctx: HipContext, max_windows=1 << 20):
+        self.ctx = ctx
+        self.max_windows = max_windows
+        self.windows = []
+
+    def addWindow(self, window: Window) -> bool:
+        if len(self.windows) >= self.max_windows:
+            return False
+        self.windows.append(window)
+        return True
+
+    def hasWindows(self) -> bool:
+        return bool(self.windows)
+
+    def reset(self):
+        self.windows = []
+
+    def generateConsensus(self):
+        """Runs the batch; sets window.consensus; returns the list of bools
+        Window::generate_consensus would have returned."""
+        host = self.ctx.lib
+        wins, fasta = [], []
+        for w in self.windows:
+            L = len(w.sequences[0])
+            q0 = w.qualities[0]
+            fasta.append(host.vc_backbone_is_fasta(q0, L))
+            quals = [q0[:L]] + w.qualities[1:]
+            wins.append((w.sequences, quals, [p[0] for p in w.positions], [p[1] for p in w.positions]))
+        batch = capi.Batch.from_windows(wins, fasta, host=host)
+        cons, status = self.ctx.consensus(batch)
+        flags = []
+        for w, c, s in zip(self.windows, cons, status):
+            if s > capi.VC_WIN_UNPOLISHED:
+                raise VcError(f"window {w.id}/{w.rank}: device status {int(s)} (no CPU fallback)")
+            w.consensus = c
+            flags.append(s == capi.VC_WIN_OK)
+        return flags
