@@ -112,6 +112,8 @@ int vc_collect(vc_ctx* ctx, vc_result* r);            /* D2H of consensus + stat
 int vc_collect_device(vc_ctx* ctx, void* d_cons, uint64_t cons_cap, void* d_cons_off /*u64[n+1]*/,
                       void* d_status /*u8[n]*/);
 int vc_get_stats(vc_ctx* ctx, vc_stats* s);
+/* diagnostics: per-window (site << 16) | detail of the kernel that took the window out of VC_WIN_OK */
+int vc_debug_errinfo(vc_ctx* ctx, uint32_t* out /*[n_windows]*/);
 void* vc_stream(vc_ctx* ctx);                         /* the hipStream_t the context launches on               */
 
 /* -- host helpers that keep reference semantics on the host side of the boundary ---------------- */

@@ -676,6 +676,10 @@ static int window_hap(const seqview* sv, uint32_t nseq, int fasta, const vco_par
     double total = 0.0;
     int rc = build_graph(&G, sv, nseq, L, p, &total, fasta, stats);
     if (rc) { g_free(&G); return rc; }
+    if (stats) {
+        if (G.n_nodes > stats->max_nodes) stats->max_nodes = G.n_nodes;
+        if (G.n_edges > stats->max_edges) stats->max_edges = G.n_edges;
+    }
     uint16_t window_len = (uint16_t)L;                    /* :216 */
     double avg = fasta ? 2.0 * total / window_len : 2.0 * total / window_len * 1000;   /* :301-309 */
 

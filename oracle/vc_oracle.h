@@ -46,6 +46,8 @@ typedef struct vco_params {
 typedef struct vco_stats {
     uint64_t cells;        /* sum over every Align call of nodes_in_graph * sequence_len */
     uint64_t alignments;   /* number of Align calls                                               */
+    uint64_t max_nodes;    /* largest build graph seen (nodes / edges), for capacity planning     */
+    uint64_t max_edges;
 } vco_stats;
 
 /* Runs windows [w0, w1) of the batch.  cons_off[n_windows+1] / cons (capacity cons_cap bytes)

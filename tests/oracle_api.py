@@ -26,7 +26,7 @@ class VcoParams(C.Structure):
 
 
 class VcoStats(C.Structure):
-    _fields_ = [("cells", C.c_uint64), ("alignments", C.c_uint64)]
+    _fields_ = [("cells", C.c_uint64), ("alignments", C.c_uint64), ("max_nodes", C.c_uint64), ("max_edges", C.c_uint64)]
 
 
 def vco_params(p: VcParams):

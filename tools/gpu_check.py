@@ -30,13 +30,14 @@ for name, cfg, n in cases:
     ref, pol, st = oa.oracle_run(b, ctx.params)
     s = ctx.stats()
     nbad = 0
+    ei = ctx.errinfo()
     for w in range(n):
         ok = cons[w] == ref[w] and int(status[w]) == (0 if pol[w] else 1)
         if not ok:
             nbad += 1
             # first difference
             d = next((i for i, (x, y) in enumerate(zip(cons[w], ref[w])) if x != y), min(len(cons[w]), len(ref[w])))
-            print(f"   window {w}: status={int(status[w])} len hip={len(cons[w])} oracle={len(ref[w])} first diff at {d}")
+            print(f"   window {w}: status={int(status[w])} len hip={len(cons[w])} oracle={len(ref[w])} first diff at {d} errinfo={ei[w]}")
     allok = allok and nbad == 0
     km = {k: round(v['ms'], 2) for k, v in s['kernels'].items()}
     print(f"{name}: {n} windows, mismatches={nbad}, hip {t1-t0:.2f}s cells hip={s['cells']} oracle={st.cells} NC={s['max_nodes']} EC={s['max_edges']} ms={km}")

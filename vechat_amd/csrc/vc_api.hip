@@ -267,7 +267,11 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         }
         max_layers = std::max(max_layers, s1 - s0 - 1);
         max_nseq = std::max(max_nseq, s1 - s0);
-        need_nodes = std::max<uint64_t>(need_nodes, L + (uint64_t)std::ceil(0.045 * (double)sum) + 160);
+        // graph growth saturates with depth: nodes ~ L + c * mean_layer_len * depth^0.55 (measured on
+        // 8..128-read PacBio/ONT-profile windows; windows that still outgrow it report VC_WIN_OVERFLOW)
+        const double depth = (double)(s1 - s0 - 1);
+        const double est = depth > 0 ? 0.36 * ((double)sum / depth) * std::pow(depth, 0.55) : 0.0;
+        need_nodes = std::max<uint64_t>(need_nodes, L + (uint64_t)std::ceil(est) + 64);
     }
     free_list(c->batch_allocs);
     c->have_batch = false; c->ran = false;
@@ -281,7 +285,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         (rc = dalloc(c, c->batch_allocs, &d_hq, nseq)) || (rc = dalloc(c, c->batch_allocs, &d_ba, nbytes + 16)) ||
         (rc = dalloc(c, c->batch_allocs, &d_qu, nbytes + 16)) || (rc = dalloc(c, c->batch_allocs, &d_wf, nw)) ||
         (rc = dalloc(c, c->batch_allocs, &b.win_avg, nw)) || (rc = dalloc(c, c->batch_allocs, &b.status, nw)) ||
-        (rc = dalloc(c, c->batch_allocs, &b.cons_len, nw)))
+        (rc = dalloc(c, c->batch_allocs, &b.cons_len, nw)) || (rc = dalloc(c, c->batch_allocs, &b.errinfo, nw)))
         return rc;
     HIPCHK(c, hipMemcpyAsync(d_wso, hb->win_seq_off, (nw + 1) * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_so, hb->seq_off, (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
@@ -300,7 +304,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     // capacities
     uint32_t NC = c->prm.max_nodes ? c->prm.max_nodes : (uint32_t)std::min<uint64_t>(need_nodes, 60000);
     NC = (NC + 63) & ~63u;
-    uint32_t EC = c->prm.max_edges ? c->prm.max_edges : (uint32_t)std::min<uint64_t>((uint64_t)(2.4 * NC), 32000);
+    uint32_t EC = c->prm.max_edges ? c->prm.max_edges : (uint32_t)std::min<uint64_t>((uint64_t)(2.6 * NC), 32000);
     EC = (EC + 63) & ~63u;
     if (EC > 32000) EC = 32000;
     if (NC > 60000) return fail(c, VC_ERR_ARG, "max_nodes %u exceeds the 16-bit id space", NC);
@@ -382,6 +386,7 @@ int vc_run(vc_ctx* c) {
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)add_lds));
     HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 16, c->stream));
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
+    HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, (size_t)b.n_windows * 4, c->stream));
     for (int i = 0; i < KC_N; ++i) { c->stats.ms[i] = 0; c->stats.launches[i] = 0; }
     const uint64_t rowb = 64ull * cpl;
@@ -555,6 +560,13 @@ int vc_collect(vc_ctx* c, vc_result* r) {
         r->cons_off[w + 1] = r->cons_off[w] + c->h_cons_len[w];
         r->status[w] = c->h_status[w];
     }
+    return VC_OK;
+}
+
+int vc_debug_errinfo(vc_ctx* c, uint32_t* out) {
+    if (!c || !out || !c->have_batch) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out, c->b.errinfo, (size_t)c->b.n_windows * 4, hipMemcpyDeviceToHost));
     return VC_OK;
 }
 

@@ -72,6 +72,7 @@ struct VcBatchDev {
     const uint8_t*  win_fasta;
     double*   win_avg;     // [n_windows] average_weight (window.cpp:301-309)
     uint8_t*  status;      // [n_windows]
+    uint32_t* errinfo;     // [n_windows] (site << 16) | detail of the first non-OK status, for diagnostics
     uint8_t*  cons;        // [n_windows*cons_cap]
     uint32_t* cons_len;    // [n_windows]
     uint32_t  cons_cap;

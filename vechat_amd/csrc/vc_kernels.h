@@ -21,6 +21,12 @@
 
 __device__ __forceinline__ int vc_lane() { return (int)(threadIdx.x & 63); }
 
+// record why a window left the OK state (site id, detail) -- diagnostics only
+__device__ __forceinline__ void vc_fail(const VcBatchDev& b, uint32_t w, int status, uint32_t site, uint32_t detail) {
+    b.status[w] = (uint8_t)status;
+    b.errinfo[w] = (site << 16) | (detail & 0xFFFF);
+}
+
 // exclusive prefix sum over the 64 lanes of the wave; total returned through `total`
 __device__ __forceinline__ uint32_t wave_excl_sum(uint32_t x, uint32_t& total) {
     uint32_t v = x;
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, uint32_t w
         if (lane == 0) { b.cons_len[w] = n; b.status[w] = L <= b.cons_cap ? VC_WIN_UNPOLISHED : VC_WIN_OVERFLOW; }
         return;
     }
-    if (L > NC || L > EC + 1 || L >= 0xFFFF) { if (lane == 0) b.status[w] = VC_WIN_OVERFLOW; return; }
+    if (L > NC || L > EC + 1 || L >= 0xFFFF) { if (lane == 0) vc_fail(b, w, VC_WIN_OVERFLOW, 1, L); return; }
     uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
     for (uint32_t i = lane; i < L; i += 64) {
         g.code[nb + i] = b.bases[o0 + i];
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         s_err = err;
     }
     __syncthreads();
-    if (s_err) { if (lane == 0) b.status[w] = (uint8_t)s_err; return; }
+    if (s_err) { if (lane == 0) vc_fail(b, w, s_err, 2, s_nrows); return; }
     const uint32_t nrows = s_nrows;
 
     // ---- row records (wave-parallel).  s_al is dead now: alias node->rank and two byte maps into it.
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
     if (lane == 0) {
         dp.nrows[slot] = nrows;
         dp.flags[slot] = bad ? 1u : 0u;
+        if (bad) b.errinfo[w] = (11u << 16) | (spill_base & 0xFFFF);
     }
 }
 
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
         bool ok = wc >= -31744 && ((long long)(m - g) * (64 * CPL + 1) < 32767) && len <= 64u * CPL && len > 0 &&
                   nrows > 0 && !(a.dp.flags[slot] & 1u);
         if (!ok) {
-            if (lane == 0) a.b.status[w] = (len == 0 || nrows == 0) ? VC_WIN_INVALID : VC_WIN_UNSUPPORTED;
+            if (lane == 0) vc_fail(a.b, w, (len == 0 || nrows == 0) ? VC_WIN_INVALID : VC_WIN_UNSUPPORTED, 3, (a.dp.flags[slot] & 1u) ? 1 : 2);
             return;
         }
     }
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
             end = (rstar << 16) | (uint32_t)(lstar * CPL + cstar + 1);
         }
     }
-    if (bad) { if (lane == 0) a.b.status[w] = VC_WIN_OVERFLOW; }
+    if (bad) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 4, spill_cnt); }
     if (lane == 0) a.job_end[job] = end;
 }
 
@@ -731,7 +738,7 @@ __global__ void k_trace(VcTraceArgs a) {
             i = pi_; j = pj_;
         }
     }
-    if (ovf) { a.b.status[w] = VC_WIN_OVERFLOW; n = 0; }
+    if (ovf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, n); n = 0; }
     a.npairs[pj] = n;
 }
 
@@ -806,7 +813,7 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
     // unaligned prefix/suffix chains (graph.cpp:233-236), which this flow never produces
     if (nvalid != len || P == 0) err = VC_WIN_INVALID;
     if (N0 + nnew > a.NC || N0 + nnew >= 0xFFFF) err = VC_WIN_OVERFLOW;
-    if (err) { if (lane == 0) a.b.status[w] = (uint8_t)err; return; }
+    if (err) { if (lane == 0) vc_fail(a.b, w, err, 6, nvalid != len || P == 0 ? 1 : 2); return; }
     __syncthreads();
 
     // pass B: create nodes, extend aligned groups
@@ -843,7 +850,7 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
         }
         a.g.al_cnt[nb + curr] = (uint8_t)mycnt;
     }
-    if (__any(err)) { if (lane == 0) a.b.status[w] = VC_WIN_UNSUPPORTED; return; }
+    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_UNSUPPORTED, 7, 0); return; }
     __syncthreads();      // pass B's stores are complete before pass C touches the same nodes
 
     // pass C: edges between consecutive aligned bases (graph.cpp:282-290 -> AddEdge :94-107)
@@ -905,7 +912,7 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
             carry_prev = (uint32_t)__shfl((int)curr, last, 64);
         }
     }
-    if (__any(err)) { if (lane == 0) a.b.status[w] = VC_WIN_OVERFLOW; return; }
+    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 8, E0 + enew); return; }
     if (lane == 0) { a.g.n_nodes[slot] = N0 + nnew; a.g.n_edges[slot] = E0 + enew; }
 }
 
@@ -1141,7 +1148,7 @@ __global__ __launch_bounds__(64) void k_addw(VcAddwArgs a) {
             else atomicAdd(&a.g.e_w[eb + found], wgt);
         }
     }
-    if (__any(err)) { if (lane == 0) a.b.status[w] = VC_WIN_INVALID; }
+    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 9, 0); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1179,7 +1186,7 @@ __global__ __launch_bounds__(64) void k_finish(VcFinishArgs a) {
         }
         outn += tot;
     }
-    if (__any(err)) { if (lane == 0) { a.b.status[w] = VC_WIN_OVERFLOW; a.b.cons_len[w] = 0; } return; }
+    if (__any(err)) { if (lane == 0) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 10, outn); a.b.cons_len[w] = 0; } return; }
     if (lane == 0) a.b.cons_len[w] = outn;
 }
 

@@ -69,6 +69,12 @@ class HipContext:
         out = [cons[int(off[w]):int(off[w + 1])].tobytes() for w in range(n)]
         return out, status
 
+    def errinfo(self):
+        n = self._batch.n_windows
+        out = np.zeros(n, np.uint32)
+        self._chk(self.lib.vc_debug_errinfo(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32))), "vc_debug_errinfo")
+        return [(int(x) >> 16, int(x) & 0xFFFF) for x in out]
+
     def stats(self):
         s = capi.VcStats()
         self._chk(self.lib.vc_get_stats(self.h, C.byref(s)), "vc_get_stats")
