@@ -1,0 +1,167 @@
+"""Generates the committed golden fixtures.  Runs ONLY where /root/reference exists (the build
+container): expected outputs come from the REAL reference compiled in place (oracle/_ref, built by
+oracle/Makefile from the reference's own sources -- nothing of the reference is copied here except
+DATA: the spoa test reads sample.fastq.gz and the known-answer consensus strings its tests assert).
+
+  python tests/golden/make_golden.py        ->  tests/golden/spoa_kat.json, tests/golden/windows.json
+"""
+import gzip
+import json
+import os
+import random
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from vechat_amd import capi  # noqa: E402
+import oracle_api as oa  # noqa: E402
+
+REF = "/root/reference"
+
+
+def spoa_kats():
+    """Known-answer strings asserted by vendor/spoa/test/spoa_test.cpp (linear-gap cases only:
+    the hot path never reaches affine/convex)."""
+    src = open(os.path.join(REF, "vendor/spoa/test/spoa_test.cpp")).read()
+    out = {}
+    for name in ("Local", "LocalWithQualities", "Global", "GlobalWithQualities"):
+        m = re.search(r"TEST_F\(SpoaTest, %s\) \{(.*?)Check\(c\);" % name, src, re.S)
+        body = m.group(1)
+        setup = re.search(r"Setup\(AlignmentType::k(\w+), (-?\d+), (-?\d+), (-?\d+), (-?\d+), (-?\d+), (-?\d+), (\w+)\)", body)
+        cons = "".join(re.findall(r'"([ACGT]+)"', body))
+        out[name] = dict(type=setup.group(1), m=int(setup.group(2)), n=int(setup.group(3)), g=int(setup.group(4)),
+                         quality=setup.group(8) == "true", consensus=cons)
+    return out
+
+
+def window_dict(batch, w, bq=None):
+    """One window of a Batch in add_layer() order."""
+    seqs, quals, b, e = batch.window(w)
+    s0 = int(batch.win_seq_off[w])
+    orig = [int(x) for x in batch.seq_orig[s0:s0 + len(seqs)]]
+    inv = sorted(range(len(seqs)), key=lambda k: orig[k])
+    return dict(
+        backbone=seqs[0].decode(), backbone_quality=(bq or quals[0]).decode(),
+        layers=[dict(seq=seqs[k].decode(), qual=None if quals[k] is None else quals[k].decode(), begin=b[k], end=e[k])
+                for k in inv if k != 0])
+
+
+def to_batch(win):
+    """fixture dict -> (Batch, original-order bookkeeping) using the host helpers."""
+    host = capi.load_host()
+    bb = win["backbone"].encode()
+    bq = win["backbone_quality"].encode()
+    seqs = [bb] + [l["seq"].encode() for l in win["layers"]]
+    quals = [bq[:len(bb)]] + [None if l["qual"] is None else l["qual"].encode() for l in win["layers"]]
+    b = [0] + [l["begin"] for l in win["layers"]]
+    e = [0] + [l["end"] for l in win["layers"]]
+    fasta = host.vc_backbone_is_fasta(bq, len(bb))
+    return capi.Batch.from_windows([(seqs, quals, b, e)], [fasta], host=host)
+
+
+def reference_answers(win):
+    batch = to_batch(win)
+    ans = {}
+    for mode, key in ((0, "hap"), (1, "linear")):
+        p = capi.default_params(mode=mode)
+        lib = oa.load_ref("sse41")
+        # call the reference with the ORIGINAL buffers (quality buffer may be longer than the backbone)
+        import ctypes as C
+        L = len(win["backbone"])
+        layers = win["layers"]
+        n = len(layers)
+        SA = C.c_char_p * max(n, 1)
+        U = C.c_uint32 * max(n, 1)
+        sa = SA(*[l["seq"].encode() for l in layers]) if n else SA()
+        qa = SA(*[None if l["qual"] is None else l["qual"].encode() for l in layers]) if n else SA()
+        la = U(*[len(l["seq"]) for l in layers]) if n else U()
+        ba = U(*[l["begin"] for l in layers]) if n else U()
+        ea = U(*[l["end"] for l in layers]) if n else U()
+        cap = sum(len(l["seq"]) for l in layers) + L + 4096
+        out = C.create_string_buffer(cap)
+        olen = C.c_uint32(0)
+        pol = C.c_int(0)
+        rc = lib.vcref_window(C.c_char_p(win["backbone"].encode()), C.c_uint32(L), C.c_char_p(win["backbone_quality"].encode()),
+                              C.c_uint32(n), sa, la, qa, ba, ea, C.c_int(mode), C.c_int(p.window_type), C.c_int(p.trim),
+                              C.c_int(p.match), C.c_int(p.mismatch), C.c_int(p.gap), C.c_double(p.min_confidence),
+                              C.c_double(p.min_support), C.c_uint32(p.num_prune), out, C.c_uint32(cap), C.byref(olen), C.byref(pol))
+        assert rc == 0, rc
+        ans[key] = dict(consensus=out.raw[:olen.value].decode(), polished=bool(pol.value))
+    return ans
+
+
+def main():
+    assert os.path.isdir(REF), "fixtures are generated in the build container only"
+    kats = spoa_kats()
+    json.dump(kats, open(os.path.join(HERE, "spoa_kat.json"), "w"), indent=1)
+
+    rnd = random.Random(20260929)
+    cases = []
+
+    def add(name, cfg, n, mutate=None):
+        b = capi.synth_batch(cfg, 0, n, n_threads=1)
+        for w in range(n):
+            win = window_dict(b, w)
+            if mutate:
+                mutate(win)
+            win["name"] = f"{name}/{w}"
+            win["expected"] = reference_answers(win)
+            cases.append(win)
+
+    add("fastq_full", capi.synth_cfg(101, 120, 10), 2)
+    add("fasta_all", capi.synth_cfg(102, 120, 8, fastq=0, backbone_fastq=0), 2)
+    add("partial_mix", capi.synth_cfg(103, 150, 12, frac_partial=0.4), 3)
+    add("two_haplotypes", capi.synth_cfg(104, 200, 16, n_haplotypes=2, snp_rate=0.03, frac_partial=0.2), 2)
+    add("ont_fasta_layers", capi.synth_cfg(105, 300, 20, profile=capi.ONT, fastq=0, backbone_fastq=1, frac_partial=0.2), 1)
+
+    def quirk(win):   # short last window of a FASTA target: dummy quality buffer longer than the backbone
+        win["backbone_quality"] = "!" * (len(win["backbone"]) + 380)
+    add("fasta_short_last_window_quirk", capi.synth_cfg(106, 120, 9, fastq=0, backbone_fastq=0), 2, quirk)
+
+    def few(win):
+        win["layers"] = win["layers"][:1]
+    add("lt3_sequences", capi.synth_cfg(107, 100, 4), 1, few)
+
+    def only_backbone(win):
+        win["layers"] = []
+    add("backbone_only", capi.synth_cfg(108, 80, 3), 1, only_backbone)
+
+    def with_n(win):
+        def nz(s):
+            s = list(s)
+            for i in range(len(s)):
+                if rnd.random() < 0.03:
+                    s[i] = "N"
+            return "".join(s)
+        win["backbone"] = nz(win["backbone"])
+        for l in win["layers"]:
+            l["seq"] = nz(l["seq"])
+    add("n_bases", capi.synth_cfg(109, 140, 10, frac_partial=0.2), 2, with_n)
+
+    def mixed_q(win):
+        for i, l in enumerate(win["layers"]):
+            if i % 3 == 0:
+                l["qual"] = None
+    add("mixed_fasta_fastq_layers", capi.synth_cfg(110, 130, 11, frac_partial=0.3), 2, mixed_q)
+
+    def low_q(win):    # very low and very high qualities incl. '!' (weight 0) and '~'
+        for l in win["layers"]:
+            if l["qual"]:
+                l["qual"] = "".join(rnd.choice("!\"#+5?IS~") for _ in l["qual"])
+    add("extreme_qualities", capi.synth_cfg(111, 110, 9), 2, low_q)
+
+    add("deep_64", capi.synth_cfg(112, 100, 64), 1)
+    add("pacbio_500x32", capi.synth_cfg(1001, 500, 32), 1)
+
+    json.dump(dict(params=dict(match=3, mismatch=-5, gap=-4, min_confidence=0.2, min_support=0.2, num_prune=3,
+                               window_type=1, trim=1), windows=cases),
+              open(os.path.join(HERE, "windows.json"), "w"), indent=0)
+    print(len(cases), "window fixtures;", sum(1 for c in cases if c["expected"]["hap"]["polished"]), "polished")
+
+
+if __name__ == "__main__":
+    main()

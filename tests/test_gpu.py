@@ -1,0 +1,143 @@
+"""GPU suite (-m gpu): the HIP path, driven through the C ABI, against the oracle and the golden
+fixtures.  Bar: bit-exact consensus bytes and status for every window."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import fixtures
+import oracle_api as oa
+from vechat_amd import capi
+from vechat_amd.engine import HipBatchProcessor, HipContext, VcError, create_window
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(built):
+    c = HipContext(device=0)
+    yield c
+    c.close()
+
+
+def _check(ctx, batch, label=""):
+    cons, status = ctx.consensus(batch)
+    ref, pol, st = oa.oracle_run(batch, ctx.params)
+    for w in range(batch.n_windows):
+        assert int(status[w]) == (capi.VC_WIN_OK if pol[w] else capi.VC_WIN_UNPOLISHED), (label, w, int(status[w]), ctx.errinfo()[w])
+        assert cons[w] == ref[w], (label, w, len(cons[w]), len(ref[w]))
+    return st
+
+
+def test_golden_windows_through_the_c_abi(ctx):
+    gold = fixtures.load_windows()
+    batch = fixtures.fixture_batch(gold["windows"])
+    cons, status = ctx.consensus(batch)
+    for w, win in enumerate(gold["windows"]):
+        exp = win["expected"]["hap"]
+        assert cons[w].decode() == exp["consensus"], win["name"]
+        assert (int(status[w]) == capi.VC_WIN_OK) == exp["polished"], win["name"]
+        assert int(status[w]) in (capi.VC_WIN_OK, capi.VC_WIN_UNPOLISHED)
+
+
+@pytest.mark.parametrize("seed,L,D,n,kw", [
+    (1, 60, 4, 8, {}),
+    (2, 60, 5, 8, dict(fastq=0, backbone_fastq=0)),
+    (3, 200, 12, 16, dict(frac_partial=0.3)),
+    (1001, 500, 32, 8, {}),                                   # BASELINE config B shape
+    (1002, 500, 64, 6, {}),                                   # BASELINE config C shape
+    (13, 500, 40, 6, dict(n_haplotypes=2, snp_rate=0.02, frac_partial=0.2)),
+    (1005, 1000, 48, 2, dict(profile=capi.ONT)),              # ONT-profile 1 kb windows (config E shape, shallower)
+    (17, 250, 20, 8, dict(fastq=0, backbone_fastq=1, frac_partial=0.25)),
+])
+def test_parity_with_oracle_on_seeded_windows(ctx, seed, L, D, n, kw):
+    batch = capi.synth_batch(capi.synth_cfg(seed, L, D, **kw), 0, n)
+    st = _check(ctx, batch, f"seed{seed}")
+    assert ctx.stats()["cells"] == st.cells                   # same DP work counted on both sides
+
+
+def test_prune_parameters_and_rounds(built):
+    batch = capi.synth_batch(capi.synth_cfg(41, 180, 14, n_haplotypes=2, snp_rate=0.03), 0, 6)
+    for kw in (dict(num_prune=1), dict(num_prune=2), dict(num_prune=4, min_confidence=0.22, min_support=0.19),
+               dict(min_confidence=0.0, min_support=0.0), dict(match=5, mismatch=-4, gap=-8)):
+        c = HipContext(device=0, **kw)
+        _check(c, batch, str(kw))
+        c.close()
+
+
+def test_ragged_batch_and_edge_windows(ctx):
+    """Windows of different depth/length in one batch, incl. <3 sequences and backbone-only."""
+    parts = [capi.synth_batch(capi.synth_cfg(50 + i, L, D, frac_partial=fp), 0, 2)
+             for i, (L, D, fp) in enumerate([(80, 1, 0), (300, 30, 0.2), (64, 2, 0), (150, 3, 0.5), (500, 9, 0)])]
+    wins, fl = [], []
+    for p in parts:
+        for w in range(p.n_windows):
+            wins.append(p.window(w)); fl.append(int(p.win_fasta[w]))
+    batch = capi.Batch.from_windows(wins, fl, presorted=True)
+    _check(ctx, batch, "ragged")
+
+
+def test_result_is_independent_of_chunking(built):
+    batch = capi.synth_batch(capi.synth_cfg(61, 150, 10, frac_partial=0.2), 0, 150)
+    a = HipContext(device=0, chunk_windows=64)
+    b = HipContext(device=0, chunk_windows=150)
+    ca, sa = a.consensus(batch)
+    cb, sb = b.consensus(batch)
+    assert ca == cb and (sa == sb).all()
+    assert a.stats()["chunk_windows"] == 64
+    a.close(); b.close()
+
+
+def test_overflow_is_reported_not_hidden(built):
+    batch = capi.synth_batch(capi.synth_cfg(71, 200, 30), 0, 4)
+    c = HipContext(device=0, max_nodes=256, max_edges=640)
+    cons, status = c.consensus(batch)
+    assert all(int(s) == capi.VC_WIN_OVERFLOW for s in status) and all(len(x) == 0 for x in cons)
+    c.close()
+
+
+def test_batch_processor_mirror(ctx):
+    """addWindow / generateConsensus with the reference's Window shape (cudabatch.hpp:39-59)."""
+    gold = fixtures.load_windows()["windows"][:6]
+    proc = HipBatchProcessor(ctx)
+    for i, win in enumerate(gold):
+        w = create_window(i, 0, 1, win["backbone"].encode(), win["backbone_quality"].encode())
+        for l in win["layers"]:
+            w.add_layer(l["seq"].encode(), None if l["qual"] is None else l["qual"].encode(), l["begin"], l["end"])
+        assert proc.addWindow(w)
+    assert proc.hasWindows()
+    flags = proc.generateConsensus()
+    for w, win, f in zip(proc.windows, gold, flags):
+        assert w.consensus.decode() == win["expected"]["hap"]["consensus"] and f == win["expected"]["hap"]["polished"]
+    proc.reset()
+    assert not proc.hasWindows()
+
+
+def test_full_size_config_b_properties(built):
+    """BASELINE config B at full size (10k windows, 500 bp x 32): size-independent properties --
+    determinism, all windows polished, plausible lengths, a checksum of checksums that does not
+    depend on how the batch is chunked, and a random sample re-checked against the oracle."""
+    n = 10000
+    batch = capi.synth_batch(capi.synth_cfg(1001, 500, 32), 0, n)
+    c1 = HipContext(device=0)
+    cons, status = c1.consensus(batch)
+    assert (status == capi.VC_WIN_OK).all()
+    lens = np.array([len(x) for x in cons])
+    assert 470 < np.median(lens) < 510 and lens.max() < 600
+    # outliers (pruning can fragment a window's graph) are legitimate only if the oracle agrees
+    for w in list(np.argsort(lens)[:4]) + list(np.argsort(lens)[-2:]):
+        ref, pol, _ = oa.oracle_run(batch, capi.default_params(), int(w), int(w) + 1)
+        assert cons[int(w)] == ref[0] and pol[0], int(w)
+    h1 = hashlib.sha256(b"".join(hashlib.sha256(x).digest() for x in cons)).hexdigest()
+    c1.run(); c1.sync()
+    cons2, _ = c1.collect()
+    assert hashlib.sha256(b"".join(hashlib.sha256(x).digest() for x in cons2)).hexdigest() == h1
+    c1.close()
+    c2 = HipContext(device=0, chunk_windows=3000)
+    cons3, _ = c2.consensus(batch)
+    assert hashlib.sha256(b"".join(hashlib.sha256(x).digest() for x in cons3)).hexdigest() == h1
+    c2.close()
+    rng = np.random.default_rng(7)
+    for w in rng.choice(n, size=12, replace=False):
+        ref, pol, _ = oa.oracle_run(batch, capi.default_params(), int(w), int(w) + 1)
+        assert cons[int(w)] == ref[0] and pol[0]

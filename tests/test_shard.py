@@ -1,0 +1,55 @@
+"""CPU suite, part 3: the N>1 path (window sharding + final gather) over gloo, world_size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from vechat_amd.shard import gather_consensus, shard_range
+
+
+def test_shard_range_partitions_in_order():
+    for n in (0, 1, 7, 8, 100003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(1234)
+    lens_all = rng.integers(0, 40, size=n)
+    blob = rng.integers(65, 85, size=int(lens_all.sum()), dtype=np.uint8)
+    off = np.concatenate([[0], np.cumsum(lens_all)])
+    lo, hi = shard_range(n, rank, world)
+    cons = torch.from_numpy(blob[off[lo]:off[hi]].copy())
+    lens = torch.from_numpy(lens_all[lo:hi].astype(np.int64))
+    c, l = gather_consensus(cons, lens, dst=0)
+    if rank == 0:
+        q.put((c.numpy().tobytes() == blob.tobytes(), l.numpy().tolist() == lens_all.tolist()))
+    else:
+        assert c is None and l is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gather_over_gloo_world_size_2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 101, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=90)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert ok == (True, True)
