@@ -20,8 +20,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum KClass { KC_AVG = 0, KC_INIT, KC_TOPO, KC_FWD, KC_TRACE, KC_ADDALN, KC_PRUNE, KC_ADDW, KC_FINISH, KC_N };
-const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace", "k_addaln", "k_prune_lcc", "k_addw", "k_finish"};
+enum KClass { KC_AVG = 0, KC_INIT, KC_TOPO, KC_FWD, KC_TRACE, KC_ADDALN, KC_PRUNE, KC_ADDW, KC_FINISH, KC_ROWS, KC_RESOLVE, KC_N };
+const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace", "k_addaln", "k_prune_lcc", "k_addw", "k_finish", "k_rows", "k_resolve"};
 
 uint32_t topo_lds_bytes(uint32_t NC, uint32_t EC, uint32_t STK) {
     return ((2 * NC + 15) & ~15u) + 4 * EC + 8 * NC + ((NC + 15) & ~15u) + 2 * STK + 2 * NC + 64;
@@ -60,6 +60,8 @@ struct vc_ctx {
     VcDp dp{};
     uint8_t* d_dir = nullptr; uint8_t* d_dir0 = nullptr; uint2* d_spill = nullptr;
     uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
+    uint16_t* d_tie_rows = nullptr; uint8_t* d_tie_cnt = nullptr;
+    std::vector<uint8_t> h_layer_partial;   // [layer] does any window have a partial-span layer at this index?
     uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
     uint32_t* d_rpairs = nullptr; uint32_t* d_rnpairs = nullptr;     // realign: [CW*max_nseq*PC]
     unsigned long long* d_stat = nullptr;                            // [2] cells, rows
@@ -122,6 +124,8 @@ int alloc_graph(vc_ctx* c, VcGraph* g) {
     if ((rc = dalloc(c, c->chunk_allocs, &g->e_tn, CW * EC))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &g->e_hn, CW * EC))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &g->e_w, CW * EC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->ord, CW * NC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->pos, CW * NC))) return rc;
     return VC_OK;
 }
 
@@ -248,6 +252,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     // validation (what createWindow / add_layer enforce, window.cpp:22-27,56-67)
     uint32_t max_layers = 0, max_len = 0, max_nseq = 0;
     uint64_t need_nodes = 0;
+    std::vector<uint8_t> layer_partial;
     for (uint32_t w = 0; w < nw; ++w) {
         const uint32_t s0 = hb->win_seq_off[w], s1 = hb->win_seq_off[w + 1];
         if (s1 <= s0) return fail(c, VC_ERR_ARG, "window %u has no backbone", w);
@@ -262,6 +267,11 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
                 const uint32_t b = hb->seq_begin[s], e2 = hb->seq_end[s];
                 if (b >= e2 || b > L || e2 >= L) return fail(c, VC_ERR_ARG, "window %u: invalid layer positions (%u,%u)", w, b, e2);
                 sum += len;
+                const uint32_t offset = (uint32_t)(0.01 * (double)L);          // window.cpp:212,253-254
+                const bool full = b < offset && e2 > L - offset;
+                const uint32_t j = s - s0;
+                if (layer_partial.size() <= j) layer_partial.resize(j + 1, 0);
+                if (!full) layer_partial[j] = 1;
             }
             max_len = std::max<uint32_t>(max_len, (uint32_t)len);
         }
@@ -300,6 +310,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     b.lut_w = c->d_lut_w; b.lut_d = c->d_lut_d;
     c->h_win_seq_off.assign(hb->win_seq_off, hb->win_seq_off + nw + 1);
     c->max_layers = max_layers; c->max_len = max_len; c->max_nseq = max_nseq;
+    c->h_layer_partial = layer_partial;
+    c->h_layer_partial.resize(max_nseq + 2, 0);
 
     // capacities
     uint32_t NC = c->prm.max_nodes ? c->prm.max_nodes : (uint32_t)std::min<uint64_t>(need_nodes, 60000);
@@ -325,7 +337,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint64_t budget = c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6);
     const uint64_t rowb = 64ull * cpl;
     const uint64_t np_ = cpl / 4;
-    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
+    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN + 4) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4);
     const uint64_t per_job = NC * rowb + NC + (uint64_t)VC_SPILLCAP * (np_ * 64 + 1) * 8 + 8;
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
@@ -356,6 +368,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
             (rc = dalloc(c, c->chunk_allocs, &c->d_spill, (size_t)c->jobs_cap * VC_SPILLCAP * (np_ * 64 + 1))) ||
             (rc = dalloc(c, c->chunk_allocs, &c->d_job_end, c->jobs_cap)) ||
             (rc = dalloc(c, c->chunk_allocs, &c->d_job_type, c->jobs_cap)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_tie_rows, (size_t)c->jobs_cap * VC_MAXTIE)) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_tie_cnt, c->jobs_cap)) ||
             (rc = dalloc(c, c->chunk_allocs, &c->d_pairs, (size_t)CW * PC)) ||
             (rc = dalloc(c, c->chunk_allocs, &c->d_npairs, CW)) ||
             (rc = dalloc(c, c->chunk_allocs, &c->d_rpairs, (size_t)CW * max_nseq * PC)) ||
@@ -380,10 +394,12 @@ int vc_run(vc_ctx* c) {
     const uint32_t NC = c->NC, EC = c->EC, CW = c->CW, PC = c->PC, cpl = c->cpl;
     const uint32_t topo_lds = topo_lds_bytes(NC, EC, c->STK);
     const uint32_t prune_lds = vc_prune_lds_bytes(NC, EC);
-    const uint32_t add_lds = 2 * PC + 64;
+    const uint32_t add_lds = 12 * PC + 2 * NC + 64;
+    const uint32_t rows_lds = NC + 64;
     HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)topo_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)add_lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)topo_lds));
     HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 16, c->stream));
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
     HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
@@ -408,7 +424,7 @@ int vc_run(vc_ctx* c) {
         fa.m = c->prm.match; fa.n = c->prm.mismatch; fa.g = c->prm.gap;
         fa.sm = c->prm.sw_match; fa.sn = c->prm.sw_mismatch; fa.sg = c->prm.sw_gap;
         fa.dir = c->d_dir; fa.dir0 = c->d_dir0; fa.spill = c->d_spill;
-        fa.job_end = c->d_job_end; fa.job_type = c->d_job_type;
+        fa.job_end = c->d_job_end; fa.job_type = c->d_job_type; fa.tie_rows = c->d_tie_rows; fa.tie_cnt = c->d_tie_cnt;
         fa.stat_cells = c->d_stat; fa.stat_rows = c->d_stat + 1;
         VcTraceArgs ta{};
         ta.b = b; ta.dp = c->dp; ta.w0 = w0; ta.nslots = ns; ta.NC = NC; ta.EC = EC; ta.cpl = cpl;
@@ -417,11 +433,19 @@ int vc_run(vc_ctx* c) {
         // ---- build loop (window.cpp:239-298): one layer of every window per iteration
         int cur = 0;
         for (uint32_t j = 1; j <= layers; ++j) {
-            { Timer t(c, KC_TOPO);
-              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, (int)j); }
+            // full-span layers: rows from the incrementally kept order; partial-span layers: exact DFS on the Subgraph
+            { Timer t(c, KC_ROWS);
+              hipLaunchKernelGGL(k_rows, dim3(ns), dim3(64), rows_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, (int)j); }
+            if (c->h_layer_partial[j]) {
+                Timer t(c, KC_TOPO);
+                hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, (int)j, 1);
+            }
             fa.group = 1; fa.k0 = j; fa.mode = 0; fa.dir_stride = (uint64_t)NC * rowb;
             int rc = launch_fwd(c, fa, ns);
             if (rc) return rc;
+            { Timer t(c, KC_RESOLVE);
+              hipLaunchKernelGGL(k_resolve, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK,
+                                 (const uint16_t*)c->d_tie_rows, (const uint8_t*)c->d_tie_cnt, c->d_job_end); }
             ta.group = 1; ta.k0 = j; ta.dir_stride = fa.dir_stride;
             ta.pairs = c->d_pairs; ta.npairs = c->d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
             { Timer t(c, KC_TRACE); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, c->stream, ta); }
@@ -439,7 +463,7 @@ int vc_run(vc_ctx* c) {
             { Timer t(c, KC_PRUNE); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), prune_lds, c->stream, pa); }
             cur ^= 1;
             { Timer t(c, KC_TOPO);
-              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, -1); }
+              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, -1, 0); }
             if (r + 1 == c->prm.num_prune) break;
             // how many rows do the pruned graphs have?  sizes the per-job direction matrices
             HIPCHK(c, hipMemsetAsync(c->d_maxn, 0, 4, c->stream));

@@ -17,6 +17,7 @@
 #define VC_RING     16         // DP rows kept in LDS per alignment
 #define VC_SPILLCAP 96         // rows per alignment that may be parked in HBM for far successors
 #define VC_INLINE_PRED 6       // predecessors stored inline in a row record
+#define VC_MAXTIE   16         // NW end-cell ties remembered for the exact-rank resolver
 
 // dir-code byte written by the forward DP, read by the traceback
 //   bits 7:6 kind (0 diagonal, 1 vertical, 2 horizontal, 3 stop)
@@ -45,6 +46,8 @@ struct VcGraph {
     uint32_t* e_tn;       // [CW*EC]
     uint32_t* e_hn;       // [CW*EC]
     uint32_t* e_w;        // [CW*EC]
+    uint16_t* ord;        // [CW*NC] a valid DP order of the nodes (aligned groups contiguous), kept incrementally
+    uint16_t* pos;        // [CW*NC] inverse of ord
 };
 
 // Input of the alignment kernel for one graph, produced by k_topo in rank order.
@@ -53,7 +56,7 @@ struct VcGraph {
 // first two u16 hold a u32 offset into ovf[] where all npred deltas live.
 struct VcDp {
     uint32_t* nrows;      // [CW]
-    uint32_t* flags;      // [CW] bit0: outside the kernel envelope
+    uint32_t* flags;      // [CW] bit0: outside the kernel envelope; bit1: rows follow VcGraph::ord, not the reference's rank
     uint4*    rec;        // [CW*NC]
     uint16_t* rank2node;  // [CW*NC]
     uint16_t* ovf;        // [CW*EC]

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, uint32_t w
         g.in_first[nb + i] = ein; g.in_last[nb + i] = ein;
         g.out_first[nb + i] = eout; g.out_last[nb + i] = eout;
         g.al_cnt[nb + i] = 0;
+        g.ord[nb + i] = (uint16_t)i; g.pos[nb + i] = (uint16_t)i;
         if (i + 1 < L) {
             uint32_t wgt = b.lut_w[b.quals[o0 + i]] + b.lut_w[b.quals[o0 + i + 1]];
             g.e_tn[eb + i] = i | ((uint32_t)VC_NONE16 << 16);
@@ -142,8 +143,130 @@ __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, uint32_t w
 #define TF_SUB   0x08
 #define TF_CNTSH 4
 
+struct VcTopoLds {
+    uint16_t* in_first; uint32_t* etn; uint16_t* al; uint8_t* flag; uint16_t* stack; uint16_t* rank;
+};
+
+__device__ __forceinline__ VcTopoLds vc_topo_carve(uint8_t* smem, uint32_t NC, uint32_t EC, uint32_t STK) {
+    VcTopoLds t;
+    t.in_first = (uint16_t*)smem;
+    t.etn = (uint32_t*)(smem + ((2 * NC + 15) & ~15u));
+    t.al = (uint16_t*)((uint8_t*)t.etn + 4 * EC);
+    t.flag = (uint8_t*)t.al + 8 * NC;
+    t.stack = (uint16_t*)(t.flag + ((NC + 15) & ~15u));
+    t.rank = t.stack + STK;
+    return t;
+}
+
+// cooperative copy of the order-defining part of the graph (in-lists, aligned lists) into LDS
+__device__ __forceinline__ void vc_topo_load(const VcGraph& g, uint64_t nb, uint64_t eb, uint32_t N, uint32_t E,
+                                             const VcTopoLds& t, int lane) {
+    for (uint32_t i = lane; i < N; i += 64) {
+        t.in_first[i] = g.in_first[nb + i];
+        t.flag[i] = (uint8_t)(g.al_cnt[nb + i] << TF_CNTSH);
+    }
+    for (uint32_t i = lane; i < E; i += 64) t.etn[i] = g.e_tn[eb + i];
+    const uint2* src = (const uint2*)(g.al + nb * VC_MAXALN);
+    uint2* dst = (uint2*)t.al;
+    for (uint32_t i = lane; i < N; i += 64) dst[i] = src[i];
+}
+
+// The serial, order-defining part: ExtractSubgraph flood (when masked) + TopologicalSort DFS.
+// Runs on ONE lane; returns 0 or a VC_WIN_* status, the number of emitted rows through nrows_out.
+__device__ int vc_topo_dfs(const VcTopoLds& ls, uint32_t N, uint32_t STK, bool masked, uint32_t mb, uint32_t me,
+                           uint32_t* nrows_out) {
+    int err = 0;
+    uint32_t nr = 0;
+    if (masked) {
+        // ExtractSubgraph(nodes_[end], nodes_[begin]), graph.cpp:640-666
+        if (me >= N || mb >= N) { err = VC_WIN_INVALID; }
+        else {
+            uint32_t sp = 0;
+            ls.stack[sp++] = (uint16_t)me;
+            while (sp && !err) {
+                uint32_t c = ls.stack[--sp];
+                if (!(ls.flag[c] & TF_SUB) && c >= mb) {
+                    for (uint32_t e = ls.in_first[c]; e != VC_NONE16; ) {
+                        uint32_t tn = ls.etn[e];
+                        if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
+                        ls.stack[sp++] = (uint16_t)(tn & 0xFFFF);
+                        e = tn >> 16;
+                    }
+                    uint32_t cnt = ls.flag[c] >> TF_CNTSH;
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
+                        ls.stack[sp++] = ls.al[c * VC_MAXALN + k];
+                    }
+                    ls.flag[c] |= TF_SUB;
+                }
+            }
+        }
+    }
+    const uint8_t need = masked ? TF_SUB : 0;
+    for (uint32_t s = 0; s < N && !err; ++s) {
+        uint8_t fs = ls.flag[s];
+        if ((fs & need) != need) continue;
+        if ((fs & TF_MARK) != 0) continue;
+        uint32_t sp = 0;
+        ls.stack[sp++] = (uint16_t)s;
+        while (sp) {
+            uint32_t c = ls.stack[sp - 1];
+            uint8_t fc = ls.flag[c];
+            bool valid = true;
+            if ((fc & TF_MARK) != 2) {
+                for (uint32_t e = ls.in_first[c]; e != VC_NONE16; ) {
+                    uint32_t tn = ls.etn[e];
+                    uint32_t t = tn & 0xFFFF;
+                    e = tn >> 16;
+                    uint8_t ft = ls.flag[t];
+                    if ((ft & need) != need) continue;
+                    if ((ft & TF_MARK) != 2) {
+                        if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
+                        ls.stack[sp++] = (uint16_t)t;
+                        valid = false;
+                    }
+                }
+                if (err) break;
+                uint32_t cnt = fc >> TF_CNTSH;
+                if (!(fc & TF_IGN)) {
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        uint32_t a = ls.al[c * VC_MAXALN + k];
+                        uint8_t fa = ls.flag[a];
+                        if ((fa & need) != need) continue;
+                        if ((fa & TF_MARK) != 2) {
+                            if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
+                            ls.stack[sp++] = (uint16_t)a;
+                            ls.flag[a] = fa | TF_IGN;
+                            valid = false;
+                        }
+                    }
+                    if (err) break;
+                }
+                fc = ls.flag[c];
+                if (valid) {
+                    ls.flag[c] = (fc & ~TF_MARK) | 2;
+                    if (!(fc & TF_IGN)) {
+                        ls.rank[nr++] = (uint16_t)c;
+                        for (uint32_t k = 0; k < cnt; ++k) {
+                            uint32_t a = ls.al[c * VC_MAXALN + k];
+                            if ((ls.flag[a] & need) != need) continue;
+                            ls.rank[nr++] = (uint16_t)a;
+                        }
+                    }
+                } else {
+                    if ((fc & TF_MARK) == 1) { err = VC_WIN_INVALID; break; }   // not a DAG
+                    ls.flag[c] = (fc & ~TF_MARK) | 1;
+                }
+            }
+            if (valid) sp--;
+        }
+    }
+    *nrows_out = nr;
+    return err;
+}
+
 __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                             uint32_t NC, uint32_t EC, uint32_t STK, int next_layer) {
+                                             uint32_t NC, uint32_t EC, uint32_t STK, int next_layer, int only_masked) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t slot = blockIdx.x;
     if (slot >= nslots) return;
@@ -158,120 +281,23 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         uint32_t L = (uint32_t)(b.seq_off[s0 + 1] - b.seq_off[s0]);
         mb = b.seq_begin[s0 + next_layer]; me = b.seq_end[s0 + next_layer];
         masked = !vc_full_span(mb, me, L);
+        if (only_masked && !masked) return;      // full-span layers take the incremental order (k_rows)
     }
     const uint32_t N = g.n_nodes[slot], E = g.n_edges[slot];
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
 
-    uint16_t* s_in_first = (uint16_t*)smem;
-    uint32_t* s_etn = (uint32_t*)(smem + ((2 * NC + 15) & ~15u));
-    uint16_t* s_al = (uint16_t*)((uint8_t*)s_etn + 4 * EC);
-    uint8_t*  s_flag = (uint8_t*)s_al + 8 * NC;
-    uint16_t* s_stack = (uint16_t*)(s_flag + ((NC + 15) & ~15u));
-    uint16_t* s_rank = s_stack + STK;
-
-    for (uint32_t i = lane; i < N; i += 64) {
-        s_in_first[i] = g.in_first[nb + i];
-        s_flag[i] = (uint8_t)(g.al_cnt[nb + i] << TF_CNTSH);
-    }
-    for (uint32_t i = lane; i < E; i += 64) s_etn[i] = g.e_tn[eb + i];
-    {
-        const uint2* src = (const uint2*)(g.al + nb * VC_MAXALN);
-        uint2* dst = (uint2*)s_al;
-        for (uint32_t i = lane; i < N; i += 64) dst[i] = src[i];
-    }
+    const VcTopoLds t = vc_topo_carve(smem, NC, EC, STK);
+    uint16_t* s_in_first = t.in_first; uint32_t* s_etn = t.etn; uint16_t* s_al = t.al;
+    uint8_t* s_flag = t.flag; uint16_t* s_rank = t.rank;
+    vc_topo_load(g, nb, eb, N, E, t, lane);
     __syncthreads();
 
     __shared__ uint32_t s_nrows;
     __shared__ int s_err;
     if (lane == 0) {
-        int err = 0;
         uint32_t nr = 0;
-        if (masked) {
-            // ExtractSubgraph(nodes_[end], nodes_[begin]), graph.cpp:640-666
-            if (me >= N || mb >= N) { err = VC_WIN_INVALID; }
-            else {
-                uint32_t sp = 0;
-                s_stack[sp++] = (uint16_t)me;
-                while (sp && !err) {
-                    uint32_t c = s_stack[--sp];
-                    if (!(s_flag[c] & TF_SUB) && c >= mb) {
-                        for (uint32_t e = s_in_first[c]; e != VC_NONE16; ) {
-                            uint32_t tn = s_etn[e];
-                            if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
-                            s_stack[sp++] = (uint16_t)(tn & 0xFFFF);
-                            e = tn >> 16;
-                        }
-                        uint32_t cnt = s_flag[c] >> TF_CNTSH;
-                        for (uint32_t k = 0; k < cnt; ++k) {
-                            if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
-                            s_stack[sp++] = s_al[c * VC_MAXALN + k];
-                        }
-                        s_flag[c] |= TF_SUB;
-                    }
-                }
-            }
-        }
-        const uint8_t need = masked ? TF_SUB : 0;
-        for (uint32_t s = 0; s < N && !err; ++s) {
-            uint8_t fs = s_flag[s];
-            if ((fs & need) != need) continue;
-            if ((fs & TF_MARK) != 0) continue;
-            uint32_t sp = 0;
-            s_stack[sp++] = (uint16_t)s;
-            while (sp) {
-                uint32_t c = s_stack[sp - 1];
-                uint8_t fc = s_flag[c];
-                bool valid = true;
-                if ((fc & TF_MARK) != 2) {
-                    for (uint32_t e = s_in_first[c]; e != VC_NONE16; ) {
-                        uint32_t tn = s_etn[e];
-                        uint32_t t = tn & 0xFFFF;
-                        e = tn >> 16;
-                        uint8_t ft = s_flag[t];
-                        if ((ft & need) != need) continue;
-                        if ((ft & TF_MARK) != 2) {
-                            if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
-                            s_stack[sp++] = (uint16_t)t;
-                            valid = false;
-                        }
-                    }
-                    if (err) break;
-                    uint32_t cnt = fc >> TF_CNTSH;
-                    if (!(fc & TF_IGN)) {
-                        for (uint32_t k = 0; k < cnt; ++k) {
-                            uint32_t a = s_al[c * VC_MAXALN + k];
-                            uint8_t fa = s_flag[a];
-                            if ((fa & need) != need) continue;
-                            if ((fa & TF_MARK) != 2) {
-                                if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
-                                s_stack[sp++] = (uint16_t)a;
-                                s_flag[a] = fa | TF_IGN;
-                                valid = false;
-                            }
-                        }
-                        if (err) break;
-                    }
-                    fc = s_flag[c];
-                    if (valid) {
-                        s_flag[c] = (fc & ~TF_MARK) | 2;
-                        if (!(fc & TF_IGN)) {
-                            s_rank[nr++] = (uint16_t)c;
-                            for (uint32_t k = 0; k < cnt; ++k) {
-                                uint32_t a = s_al[c * VC_MAXALN + k];
-                                if ((s_flag[a] & need) != need) continue;
-                                s_rank[nr++] = (uint16_t)a;
-                            }
-                        }
-                    } else {
-                        if ((fc & TF_MARK) == 1) { err = VC_WIN_INVALID; break; }   // not a DAG
-                        s_flag[c] = (fc & ~TF_MARK) | 1;
-                    }
-                }
-                if (valid) sp--;
-            }
-        }
+        s_err = vc_topo_dfs(t, N, STK, masked, mb, me, &nr);
         s_nrows = nr;
-        s_err = err;
     }
     __syncthreads();
     if (s_err) { if (lane == 0) vc_fail(b, w, s_err, 2, s_nrows); return; }
@@ -375,6 +401,159 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_rows: row records for a FULL-SPAN next layer from the incrementally maintained order VcGraph::ord
+// (no DFS).  H and the backtrack do not depend on which topological order the rows are visited in
+// (sisd :315-360 only needs predecessors first; ties in the backtrack follow in-edge LIST order),
+// so any valid order gives the reference's matrix.  The one place the reference's rank matters --
+// "first sink in rank order" among equal end scores (sisd :353-355) -- is settled by k_resolve,
+// which runs the exact DFS only for the ~1-2 % of alignments that actually tie.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+                                             uint32_t NC, uint32_t EC, int next_layer) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* s_spill = smem;                                  // [NC] by row
+    const uint32_t slot = blockIdx.x;
+    if (slot >= nslots) return;
+    const uint32_t w = w0 + slot;
+    if (b.status[w] != VC_WIN_OK) return;
+    const int lane = vc_lane();
+    const uint32_t s0 = b.win_seq_off[w], ns = b.win_seq_off[w + 1] - s0;
+    if ((uint32_t)next_layer >= ns) return;
+    {
+        const uint32_t L = (uint32_t)(b.seq_off[s0 + 1] - b.seq_off[s0]);
+        if (!vc_full_span(b.seq_begin[s0 + next_layer], b.seq_end[s0 + next_layer], L)) return;   // k_topo's job
+    }
+    const uint32_t N = g.n_nodes[slot];
+    const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
+    for (uint32_t i = lane; i < N; i += 64) s_spill[i] = 0;
+    __syncthreads();
+    int bad = 0, broken = 0;
+    // pass 1: rows a far successor will need from HBM
+    for (uint32_t r = lane; r < N; r += 64) {
+        const uint32_t v = g.ord[nb + r];
+        for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
+            const uint32_t tn = g.e_tn[eb + e];
+            e = tn >> 16;
+            const uint32_t pt = g.pos[nb + (tn & 0xFFFF)];
+            if (pt >= r) broken = 1;
+            else if (r - pt > VC_RING) s_spill[pt] = 1;
+        }
+    }
+    __syncthreads();
+    // pass 2: records
+    uint32_t ovf_base = 0, spill_base = 0;
+    for (uint32_t r0 = 0; r0 < N; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        const bool act = r < N;
+        const uint32_t v = act ? g.ord[nb + r] : 0;
+        uint32_t np = 0;
+        uint16_t dl[VC_INLINE_PRED];
+#pragma unroll
+        for (int k = 0; k < VC_INLINE_PRED; ++k) dl[k] = 0;
+        if (act) {
+            for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
+                const uint32_t tn = g.e_tn[eb + e];
+                e = tn >> 16;
+                const uint32_t delta = r - g.pos[nb + (tn & 0xFFFF)];
+#pragma unroll
+                for (int k = 0; k < VC_INLINE_PRED; ++k) if (np == (uint32_t)k) dl[k] = (uint16_t)delta;
+                np++;
+            }
+        }
+        const bool is_ovf = np > VC_INLINE_PRED;
+        uint32_t tot_ovf;
+        const uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
+        const uint32_t sp_flag = act ? s_spill[r] : 0u;
+        uint32_t tot_sp;
+        const uint32_t my_sp = wave_excl_sum(sp_flag, tot_sp) + spill_base;
+        if (act) {
+            if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }
+            if (np > 255) bad = 1;
+            if (is_ovf) {
+                if (my_ovf + np > EC) bad = 1;
+                else {
+                    uint32_t k = 0;
+                    for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
+                        const uint32_t tn = g.e_tn[eb + e];
+                        e = tn >> 16;
+                        const uint32_t delta = r - g.pos[nb + (tn & 0xFFFF)];
+                        if (delta > VC_PAYLOAD_NEAR && k >= 16) bad = 1;
+                        dp.ovf[eb + my_ovf + k] = (uint16_t)delta;
+                        k++;
+                    }
+                }
+                dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
+            }
+            const uint32_t fl = (g.out_first[nb + v] == VC_NONE16 ? VC_RF_SINK : 0u) | (sp_flag ? VC_RF_SPILL : 0u) |
+                                (is_ovf ? VC_RF_OVF : 0u);
+            uint4 rec;
+            rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
+            rec.y = dl[0] | ((uint32_t)dl[1] << 16);
+            rec.z = dl[2] | ((uint32_t)dl[3] << 16);
+            rec.w = dl[4] | ((uint32_t)dl[5] << 16);
+            dp.rec[nb + r] = rec;
+            dp.spill_slot[nb + r] = sp_flag ? (uint16_t)my_sp : VC_NONE16;
+            dp.rank2node[nb + r] = (uint16_t)v;
+        }
+        ovf_base += tot_ovf;
+        spill_base += tot_sp;
+    }
+    if (spill_base > VC_SPILLCAP) bad = 1;
+    bad = __any(bad);
+    broken = __any(broken);
+    if (broken) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 12, 0); return; }   // order invariant violated
+    if (lane == 0) {
+        dp.nrows[slot] = N;
+        dp.flags[slot] = (bad ? 1u : 0u) | 2u;
+        if (bad) b.errinfo[w] = (13u << 16) | (spill_base & 0xFFFF);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_resolve: the reference picks, among sinks with the same best end score, the first in ITS rank
+// order (sisd :353-355 with `<`).  For alignments done on the incremental order and ending in such a
+// tie, run the exact TopologicalSort DFS now and choose the tied sink with the smallest rank.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+                                                uint32_t NC, uint32_t EC, uint32_t STK,
+                                                const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t slot = blockIdx.x;
+    if (slot >= nslots) return;
+    const uint32_t w = w0 + slot;
+    const uint32_t nt = tie_cnt[slot];
+    if (nt < 2) return;
+    if (b.status[w] != VC_WIN_OK) return;
+    const int lane = vc_lane();
+    const uint32_t N = g.n_nodes[slot], E = g.n_edges[slot];
+    const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
+    const VcTopoLds t = vc_topo_carve(smem, NC, EC, STK);
+    vc_topo_load(g, nb, eb, N, E, t, lane);
+    __syncthreads();
+    __shared__ uint32_t s_nrows;
+    __shared__ int s_err;
+    if (lane == 0) {
+        uint32_t nr = 0;
+        s_err = vc_topo_dfs(t, N, STK, false, 0, 0, &nr);
+        s_nrows = nr;
+    }
+    __syncthreads();
+    if (s_err) { if (lane == 0) vc_fail(b, w, s_err, 14, s_nrows); return; }
+    // exact rank of each tied row's node
+    uint32_t myrank = 0xFFFFFFFFu, myrow = 0;
+    if ((uint32_t)lane < nt) {
+        myrow = tie_rows[(uint64_t)slot * VC_MAXTIE + lane];
+        const uint32_t node = dp.rank2node[nb + myrow - 1];
+        for (uint32_t r = 0; r < s_nrows; ++r) if (t.rank[r] == node) { myrank = r; break; }
+    }
+    const uint32_t best = wave_min_u32(myrank);
+    const unsigned long long m = __ballot(myrank == best && (uint32_t)lane < nt);
+    const int src = __ffsll((long long)m) - 1;
+    const uint32_t row = (uint32_t)__shfl((int)myrow, src, 64);
+    if (lane == 0) job_end[slot] = (row << 16) | (job_end[slot] & 0xFFFF);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_fwd: linear-gap graph DP, one alignment per wavefront.
 //   columns: lane l owns columns l*CPL+1 .. l*CPL+CPL (contiguous), column 0 is a per-row scalar
 //   scores:  32-bit lanes hold H<<16; the low 16 bits of a candidate carry a tie-break tag
@@ -398,6 +577,8 @@ struct VcFwdArgs {
     uint2*    spill;               // [jobs * VC_SPILLCAP * (NP*64 + 64)]
     uint32_t* job_end;             // [jobs] (row << 16) | col ; 0 = empty alignment
     uint8_t*  job_type;            // [jobs] 0 SW, 1 NW, 255 skipped
+    uint16_t* tie_rows;            // [jobs * VC_MAXTIE] NW: sink rows sharing the best end score (incremental order only)
+    uint8_t*  tie_cnt;             // [jobs]
     unsigned long long* stat_cells;
     unsigned long long* stat_rows;
 };
@@ -415,7 +596,7 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     if (slot >= a.nslots) return;
     const uint32_t k = a.k0 + job % a.group;
     const uint32_t w = a.w0 + slot;
-    if (lane == 0) { a.job_type[job] = 255; a.job_end[job] = 0; }
+    if (lane == 0) { a.job_type[job] = 255; a.job_end[job] = 0; a.tie_cnt[job] = 0; }
     if (a.b.status[w] != VC_WIN_OK) return;
     const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
     if (k >= ns) return;
@@ -472,7 +653,7 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
 
     // end-cell tracking
     int best = nw ? VC_INT_MIN : 0;          // NW: uniform; SW: per lane, tagged with (CPL-1-c)
-    uint32_t best_row = 0;
+    uint32_t best_row = 0, ntie = 0;
     const uint32_t lane_e = (len - 1) / CPL, c_e = (len - 1) % CPL;
     uint32_t spill_cnt = 0;
     int bad = 0;
@@ -606,7 +787,13 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
 #pragma unroll
                 for (int c = 1; c < CPL; ++c) v = (c_e == (uint32_t)c) ? H[c] : v;
                 v = __builtin_amdgcn_readlane(v, lane_e);
-                if (v > best) { best = v; best_row = i; }
+                if (v > best) {
+                    best = v; best_row = i; ntie = 1;
+                    if (lane == 0) a.tie_rows[(uint64_t)job * VC_MAXTIE] = (uint16_t)i;
+                } else if (v == best) {
+                    if (ntie < VC_MAXTIE && lane == 0) a.tie_rows[(uint64_t)job * VC_MAXTIE + ntie] = (uint16_t)i;
+                    ntie++;
+                }
             }
         } else {                                             // sisd :350-352
             int rm = 0;
@@ -648,6 +835,10 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     uint32_t end = 0;
     if (nw) {
         end = (best_row << 16) | len;
+        if (ntie > 1 && (a.dp.flags[slot] & 2u)) {          // tie on a non-reference order: k_resolve decides
+            if (ntie > VC_MAXTIE) { if (lane == 0) vc_fail(a.b, w, VC_WIN_UNSUPPORTED, 15, ntie); }
+            else if (lane == 0) a.tie_cnt[job] = (uint8_t)ntie;
+        }
     } else {
         const int bval = (int)((uint32_t)best & 0xFFFF0000u);
         const int gmax = wave_max_i32(bval);
@@ -760,6 +951,12 @@ struct VcAddArgs {
 __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* s_curr = (uint16_t*)smem;                 // [PC] node chosen for each pair (forward order)
+    uint16_t* s_row = s_curr + a.PC;                    // [PC] DP row of the pair (0 = none)
+    uint16_t* s_bs = s_row + a.PC;                      // [PC] first / last position in VcGraph::ord of the
+    uint16_t* s_be = s_bs + a.PC;                       //      aligned group of the pair's node
+    uint16_t* s_pn = s_be + a.PC;                       // [PC] position of the pair's node itself
+    uint16_t* s_anchor = s_pn + a.PC;                   // [PC] new node t goes in front of old position anchor[t]
+    uint16_t* s_ord = s_anchor + a.PC;                  // [NC] old order
     const uint32_t slot = blockIdx.x;
     if (slot >= a.nslots) return;
     const uint32_t w = a.w0 + slot;
@@ -786,6 +983,20 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
         const bool valid = act && col != 0;
         uint32_t curr = VC_NONE16;
         bool isnew = false;
+        if (act) {
+            s_row[f] = (uint16_t)row;
+            if (row != 0) {
+                const uint32_t nd = a.dp.rank2node[nb + row - 1];
+                const uint32_t pn = a.g.pos[nb + nd];
+                uint32_t bs = pn, be = pn;
+                const uint32_t cnt = a.g.al_cnt[nb + nd];
+                for (uint32_t t = 0; t < cnt; ++t) {
+                    const uint32_t pa = a.g.pos[nb + a.g.al[(nb + nd) * VC_MAXALN + t]];
+                    bs = min(bs, pa); be = max(be, pa);
+                }
+                s_pn[f] = (uint16_t)pn; s_bs[f] = (uint16_t)bs; s_be[f] = (uint16_t)be;
+            }
+        }
         if (valid) {
             const uint8_t c = a.b.bases[so + col - 1];
             if (row == 0) isnew = true;                                    // graph.cpp:249-251
@@ -913,6 +1124,48 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
         }
     }
     if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 8, E0 + enew); return; }
+
+    // pass D: keep VcGraph::ord a valid DP order with aligned groups contiguous.
+    //   a node created for a mismatch joins its group right behind the node it was aligned to;
+    //   a run of inserted bases goes in front of the group of the next graph node on the path
+    //   (behind the previous one's group when the read ends with it).
+    // New ids grow along the path and the path follows ord, so anchors are non-decreasing and the new
+    // order is the merge: old position p moves right by #(anchors <= p), new node t lands at anchor[t] + t.
+    for (uint32_t f0 = 0; f0 < P; f0 += 64) {
+        const uint32_t f = f0 + lane;
+        if (f >= P) continue;
+        const uint32_t curr = s_curr[f];
+        if (curr == VC_NONE16 || curr < N0) continue;
+        uint32_t anchor;
+        if (s_row[f] != 0) anchor = (uint32_t)s_pn[f] + 1;
+        else {
+            uint32_t gidx = f + 1;
+            while (gidx < P && s_row[gidx] == 0) gidx++;
+            if (gidx < P) anchor = s_bs[gidx];
+            else {
+                int h = (int)f - 1;
+                while (h >= 0 && s_row[h] == 0) h--;
+                anchor = h >= 0 ? (uint32_t)s_be[h] + 1 : N0;
+            }
+        }
+        s_anchor[curr - N0] = (uint16_t)anchor;
+    }
+    for (uint32_t p = lane; p < N0; p += 64) s_ord[p] = a.g.ord[nb + p];
+    __syncthreads();
+    for (uint32_t t = lane; t + 1 < nnew; t += 64) if (s_anchor[t + 1] < s_anchor[t]) err = 1;
+    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 16, 0); return; }
+    for (uint32_t p = lane; p < N0; p += 64) {
+        uint32_t lo = 0, hi = nnew;                     // first t with anchor[t] > p
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_anchor[mid] <= p) lo = mid + 1; else hi = mid; }
+        const uint32_t v = s_ord[p], np_ = p + lo;
+        a.g.ord[nb + np_] = (uint16_t)v;
+        a.g.pos[nb + v] = (uint16_t)np_;
+    }
+    for (uint32_t t = lane; t < nnew; t += 64) {
+        const uint32_t np_ = (uint32_t)s_anchor[t] + t;
+        a.g.ord[nb + np_] = (uint16_t)(N0 + t);
+        a.g.pos[nb + N0 + t] = (uint16_t)np_;
+    }
     if (lane == 0) { a.g.n_nodes[slot] = N0 + nnew; a.g.n_edges[slot] = E0 + enew; }
 }
 
