@@ -58,13 +58,14 @@ struct vc_ctx {
     uint64_t dir_bytes = 0;
     VcGraph gr[2]{};
     VcDp dp{};
-    uint8_t* d_dir = nullptr; uint8_t* d_dir0 = nullptr; uint2* d_spill = nullptr;
+    uint8_t* d_dir = nullptr; uint8_t* d_dir0 = nullptr; uint32_t* d_spill = nullptr;
     uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
     uint16_t* d_tie_rows = nullptr; uint8_t* d_tie_cnt = nullptr;
     std::vector<uint8_t> h_layer_partial;   // [layer] does any window have a partial-span layer at this index?
     uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
     uint32_t* d_rpairs = nullptr; uint32_t* d_rnpairs = nullptr;     // realign: [CW*max_nseq*PC]
-    unsigned long long* d_stat = nullptr;                            // [2] cells, rows
+    unsigned long long* d_stat = nullptr;                            // [4] cells, rows, spilled rows, far-row reads
+    uint64_t stat_spill = 0, stat_far = 0;
     uint32_t* d_maxn = nullptr;                                      // [1]
 
     // stats
@@ -156,18 +157,23 @@ void flush_events(vc_ctx* c) {
     c->ev_next = 0;
 }
 
+constexpr int kRing = 12;    // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
+
 template <int CPL>
 void launch_fwd_t(vc_ctx* c, const VcFwdArgs& a, uint32_t jobs) {
-    hipLaunchKernelGGL(k_fwd<CPL>, dim3(jobs), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL((k_fwd<CPL, kRing>), dim3(jobs), dim3(64), 0, c->stream, a);
 }
 
 int launch_fwd(vc_ctx* c, const VcFwdArgs& a, uint32_t jobs) {
     Timer t(c, KC_FWD);
     switch (c->cpl) {
         case 4:  launch_fwd_t<4>(c, a, jobs); break;
+        case 6:  launch_fwd_t<6>(c, a, jobs); break;
         case 8:  launch_fwd_t<8>(c, a, jobs); break;
+        case 10: launch_fwd_t<10>(c, a, jobs); break;
         case 12: launch_fwd_t<12>(c, a, jobs); break;
         case 16: launch_fwd_t<16>(c, a, jobs); break;
+        case 20: launch_fwd_t<20>(c, a, jobs); break;
         case 24: launch_fwd_t<24>(c, a, jobs); break;
         case 32: launch_fwd_t<32>(c, a, jobs); break;
         default: return fail(c, VC_ERR_ARG, "unsupported cells-per-lane %u", c->cpl);
@@ -176,7 +182,7 @@ int launch_fwd(vc_ctx* c, const VcFwdArgs& a, uint32_t jobs) {
 }
 
 uint32_t pick_cpl(uint32_t max_len) {
-    const uint32_t opts[] = {4, 8, 12, 16, 24, 32};
+    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
     for (uint32_t o : opts) if (64 * o >= max_len) return o;
     return 0;
 }
@@ -215,7 +221,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     vc_weight_lut(lw);
     for (int ch = 0; ch < 256; ++ch) ld[ch] = 1 - pow(10, (33 - (int)(signed char)ch) / 10.0);
     if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) ||
-        dalloc(c, c->allocs, &c->d_stat, 2) || dalloc(c, c->allocs, &c->d_maxn, 1)) {
+        dalloc(c, c->allocs, &c->d_stat, 4) || dalloc(c, c->allocs, &c->d_maxn, 1)) {
         g_create_error = c->err; vc_destroy(c); return VC_ERR_HIP;
     }
     (void)hipMemcpy(c->d_lut_w, lw, sizeof(lw), hipMemcpyHostToDevice);
@@ -335,11 +341,11 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     uint64_t budget = c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6);
-    const uint64_t rowb = 64ull * cpl;
-    const uint64_t np_ = cpl / 4;
+    const uint64_t rowb = 256ull * ((cpl + 3) / 4);
+    const uint64_t nd_ = cpl / 2;
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN + 4) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4);
-    const uint64_t per_job = NC * rowb + NC + (uint64_t)VC_SPILLCAP * (np_ * 64 + 1) * 8 + 8;
+    const uint64_t per_job = NC * rowb + NC + (uint64_t)VC_SPILLCAP * (nd_ * 64 + 1) * 4 + 8 + 2 * VC_MAXTIE + 8;
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, nw);
     while (CW > 64 && (per_slot_fixed + per_job) * CW > budget) CW /= 2;
@@ -365,7 +371,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         c->dir_bytes = (uint64_t)c->jobs_cap * NC * rowb;
         if ((rc = dalloc(c, c->chunk_allocs, &c->d_dir, c->dir_bytes)) ||
             (rc = dalloc(c, c->chunk_allocs, &c->d_dir0, (size_t)c->jobs_cap * NC)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_spill, (size_t)c->jobs_cap * VC_SPILLCAP * (np_ * 64 + 1))) ||
+            (rc = dalloc(c, c->chunk_allocs, &c->d_spill, (size_t)c->jobs_cap * VC_SPILLCAP * (nd_ * 64 + 1))) ||
             (rc = dalloc(c, c->chunk_allocs, &c->d_job_end, c->jobs_cap)) ||
             (rc = dalloc(c, c->chunk_allocs, &c->d_job_type, c->jobs_cap)) ||
             (rc = dalloc(c, c->chunk_allocs, &c->d_tie_rows, (size_t)c->jobs_cap * VC_MAXTIE)) ||
@@ -400,12 +406,12 @@ int vc_run(vc_ctx* c) {
     HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)add_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)topo_lds));
-    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 32, c->stream));
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
     HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, (size_t)b.n_windows * 4, c->stream));
     for (int i = 0; i < KC_N; ++i) { c->stats.ms[i] = 0; c->stats.launches[i] = 0; }
-    const uint64_t rowb = 64ull * cpl;
+    const uint64_t rowb = 256ull * ((cpl + 3) / 4);
 
     for (uint32_t w0 = 0; w0 < b.n_windows; w0 += CW) {
         const uint32_t ns = std::min(CW, b.n_windows - w0);
@@ -425,7 +431,7 @@ int vc_run(vc_ctx* c) {
         fa.sm = c->prm.sw_match; fa.sn = c->prm.sw_mismatch; fa.sg = c->prm.sw_gap;
         fa.dir = c->d_dir; fa.dir0 = c->d_dir0; fa.spill = c->d_spill;
         fa.job_end = c->d_job_end; fa.job_type = c->d_job_type; fa.tie_rows = c->d_tie_rows; fa.tie_cnt = c->d_tie_cnt;
-        fa.stat_cells = c->d_stat; fa.stat_rows = c->d_stat + 1;
+        fa.stat = c->d_stat;
         VcTraceArgs ta{};
         ta.b = b; ta.dp = c->dp; ta.w0 = w0; ta.nslots = ns; ta.NC = NC; ta.EC = EC; ta.cpl = cpl;
         ta.dir = c->d_dir; ta.dir0 = c->d_dir0; ta.job_end = c->d_job_end; ta.job_type = c->d_job_type; ta.PC = PC;
@@ -435,10 +441,10 @@ int vc_run(vc_ctx* c) {
         for (uint32_t j = 1; j <= layers; ++j) {
             // full-span layers: rows from the incrementally kept order; partial-span layers: exact DFS on the Subgraph
             { Timer t(c, KC_ROWS);
-              hipLaunchKernelGGL(k_rows, dim3(ns), dim3(64), rows_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, (int)j); }
+              hipLaunchKernelGGL(k_rows, dim3(ns), dim3(64), rows_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, (int)j, (uint32_t)kRing); }
             if (c->h_layer_partial[j]) {
                 Timer t(c, KC_TOPO);
-                hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, (int)j, 1);
+                hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, (int)j, 1, (uint32_t)kRing);
             }
             fa.group = 1; fa.k0 = j; fa.mode = 0; fa.dir_stride = (uint64_t)NC * rowb;
             int rc = launch_fwd(c, fa, ns);
@@ -463,7 +469,7 @@ int vc_run(vc_ctx* c) {
             { Timer t(c, KC_PRUNE); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), prune_lds, c->stream, pa); }
             cur ^= 1;
             { Timer t(c, KC_TOPO);
-              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, -1, 0); }
+              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing); }
             if (r + 1 == c->prm.num_prune) break;
             // how many rows do the pruned graphs have?  sizes the per-job direction matrices
             HIPCHK(c, hipMemsetAsync(c->d_maxn, 0, 4, c->stream));
@@ -597,10 +603,12 @@ int vc_debug_errinfo(vc_ctx* c, uint32_t* out) {
 int vc_get_stats(vc_ctx* c, vc_stats* s) {
     if (!c || !s) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    unsigned long long st[2] = {0, 0};
-    HIPCHK(c, hipMemcpy(st, c->d_stat, 16, hipMemcpyDeviceToHost));
+    unsigned long long st[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpy(st, c->d_stat, 32, hipMemcpyDeviceToHost));
+    c->stat_spill = st[2]; c->stat_far = st[3];
     c->stats.cells = st[0]; c->stats.dp_rows = st[1];
     c->stats.alignments = c->stats.launches[KC_FWD];
+    c->stats.spilled_rows = st[2]; c->stats.far_row_reads = st[3];
     *s = c->stats;
     return VC_OK;
 }

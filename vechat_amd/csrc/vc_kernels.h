@@ -266,7 +266,7 @@ __device__ int vc_topo_dfs(const VcTopoLds& ls, uint32_t N, uint32_t STK, bool m
 }
 
 __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                             uint32_t NC, uint32_t EC, uint32_t STK, int next_layer, int only_masked) {
+                                             uint32_t NC, uint32_t EC, uint32_t STK, int next_layer, int only_masked, uint32_t ring) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t slot = blockIdx.x;
     if (slot >= nslots) return;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
             if ((s_flag[t] & need) != need) continue;
             s_hasout[t] = 1;
             uint32_t delta = r - s_noderank[t];
-            if (delta > VC_RING) s_spill[s_noderank[t]] = 1;
+            if (delta > ring) s_spill[s_noderank[t]] = 1;
         }
     }
     __syncthreads();
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         uint32_t my_sp = wave_excl_sum(sp_flag, tot_sp) + spill_base;
         if (act) {
             if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }   // virtual row 0 is `row` rows above
-            if (np > 255) bad = 1;
+            if (np > 64) bad = 1;
             if (is_ovf) {
                 if (my_ovf + np > EC) bad = 1;
                 else {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
 // which runs the exact DFS only for the ~1-2 % of alignments that actually tie.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                             uint32_t NC, uint32_t EC, int next_layer) {
+                                             uint32_t NC, uint32_t EC, int next_layer, uint32_t ring) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_spill = smem;                                  // [NC] by row
     const uint32_t slot = blockIdx.x;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
             e = tn >> 16;
             const uint32_t pt = g.pos[nb + (tn & 0xFFFF)];
             if (pt >= r) broken = 1;
-            else if (r - pt > VC_RING) s_spill[pt] = 1;
+            else if (r - pt > ring) s_spill[pt] = 1;
         }
     }
     __syncthreads();
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
         const uint32_t my_sp = wave_excl_sum(sp_flag, tot_sp) + spill_base;
         if (act) {
             if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }
-            if (np > 255) bad = 1;
+            if (np > 64) bad = 1;
             if (is_ovf) {
                 if (my_ovf + np > EC) bad = 1;
                 else {
@@ -554,12 +554,15 @@ __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_fwd: linear-gap graph DP, one alignment per wavefront.
-//   columns: lane l owns columns l*CPL+1 .. l*CPL+CPL (contiguous), column 0 is a per-row scalar
-//   scores:  32-bit lanes hold H<<16; the low 16 bits of a candidate carry a tie-break tag
-//            ((255 - p) << 8 | payload) so that one v_max picks "largest score, first predecessor in
-//            in-edge order" -- exactly the order sisd_alignment_engine.cpp:392-448 scans when it backtracks
-//   rows:    the last VC_RING rows live in LDS as packed int16; rows a far successor needs go to HBM
+// k_fwd: linear-gap graph DP, one alignment per wavefront (64-thread workgroup = 1 wave).
+//   columns: lane l owns columns l*CPL+1 .. l*CPL+CPL (contiguous); column 0 is a per-row scalar
+//   scores:  32-bit lanes hold H<<16.  The low 16 bits of every candidate carry a tag
+//                [15:14] kind (3 diagonal, 2 vertical)   [13:8] 63 - p   [5:0] payload
+//            so ONE running v_max over all candidates yields "largest score; diagonal before vertical;
+//            first predecessor in in-edge order" -- exactly the order sisd_alignment_engine.cpp:392-448
+//            scans when it backtracks -- and the direction byte falls out of the winner's tag.
+//   rows:    the previous row stays in registers; the last RING rows live in LDS as packed int16;
+//            rows that a successor more than RING rows away needs are also parked in HBM
 //   output:  one direction byte per cell (HBM, coalesced dwords) + the end cell
 // mode: 0 build (NW), 1 re-alignment (NW for backbone/full-span else SW), 2 final SW of the backbone
 // ------------------------------------------------------------------------------------------------
@@ -574,22 +577,22 @@ struct VcFwdArgs {
     uint8_t*  dir;                 // [jobs * dir_stride]
     uint64_t  dir_stride;          // bytes
     uint8_t*  dir0;                // [jobs * NC]
-    uint2*    spill;               // [jobs * VC_SPILLCAP * (NP*64 + 64)]
+    uint32_t* spill;               // [jobs * VC_SPILLCAP * (CPL/2*64 + 1)]
     uint32_t* job_end;             // [jobs] (row << 16) | col ; 0 = empty alignment
     uint8_t*  job_type;            // [jobs] 0 SW, 1 NW, 255 skipped
     uint16_t* tie_rows;            // [jobs * VC_MAXTIE] NW: sink rows sharing the best end score (incremental order only)
     uint8_t*  tie_cnt;             // [jobs]
-    unsigned long long* stat_cells;
-    unsigned long long* stat_rows;
+    unsigned long long* stat;      // [4] cells, rows, spilled rows, far-row reads
 };
 
 #define VC_DPP_SHR(v, old, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xF, false)
 
-template <int CPL>
+template <int CPL, int RING>
 __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
-    constexpr int NP = CPL / 4;
-    __shared__ uint2 ring[VC_RING][NP][64];
-    __shared__ int ring_c0[VC_RING];
+    constexpr int ND = CPL / 2;              // packed int16 dwords per lane per row
+    constexpr int NQ = (CPL + 3) / 4;        // direction dwords per lane per row
+    __shared__ uint32_t ring[RING][ND][64];
+    __shared__ int ring_c0[RING];
     const int lane = vc_lane();
     const uint32_t job = blockIdx.x;
     const uint32_t slot = job / a.group;
@@ -625,19 +628,19 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     }
     if (lane == 0) {
         a.job_type[job] = nw ? 1 : 0;
-        atomicAdd(a.stat_cells, (unsigned long long)nrows * len);
-        atomicAdd(a.stat_rows, (unsigned long long)nrows);
+        atomicAdd(a.stat + 0, (unsigned long long)nrows * len);
+        atomicAdd(a.stat + 1, (unsigned long long)nrows);
     }
 
     // sequence bytes of my columns (0xFF beyond the end: matches nothing)
-    uint32_t sb[NP];
+    uint32_t sb[NQ];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         uint32_t v = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             uint32_t idx = lane * CPL + q * 4 + t;
-            uint32_t c = idx < len ? a.b.bases[so + idx] : 0xFFu;
+            uint32_t c = (q * 4 + t < CPL && idx < len) ? a.b.bases[so + idx] : 0xFFu;
             v |= c << (8 * t);
         }
         sb[q] = v;
@@ -649,14 +652,19 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
 
     uint8_t* dirp = a.dir + (uint64_t)job * a.dir_stride;
     uint8_t* dir0p = a.dir0 + (uint64_t)job * a.NC;
-    uint2* spillp = a.spill + (uint64_t)job * VC_SPILLCAP * (NP * 64 + 1);
+    uint32_t* spillp = a.spill + (uint64_t)job * VC_SPILLCAP * (ND * 64 + 1);
 
     // end-cell tracking
     int best = nw ? VC_INT_MIN : 0;          // NW: uniform; SW: per lane, tagged with (CPL-1-c)
     uint32_t best_row = 0, ntie = 0;
     const uint32_t lane_e = (len - 1) / CPL, c_e = (len - 1) % CPL;
-    uint32_t spill_cnt = 0;
+    uint32_t spill_cnt = 0, far_reads = 0;
     int bad = 0;
+
+    int Hprev[CPL];                          // row i-1 (H<<16), column-0 value alongside
+    int c0prev = 0;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) Hprev[c] = 0;
 
     uint4 myrec = make_uint4(0, 0, 0, 0);
     for (uint32_t i = 1; i <= nrows; ++i) {
@@ -675,10 +683,10 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) prof[c] = (((sb[c / 4] >> (8 * (c % 4))) & 0xFF) == x) ? ms : nsc;
 
-        int bd[CPL], bv[CPL];
+        int bm[CPL];
         int b0 = VC_INT_MIN;
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) { bd[c] = VC_INT_MIN; bv[c] = VC_INT_MIN; }
+        for (int c = 0; c < CPL; ++c) bm[c] = VC_INT_MIN;
 
         for (uint32_t p = 0; p < np; ++p) {
             uint32_t delta;
@@ -690,43 +698,46 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
             }
             const uint32_t pr = i - delta;
             const uint32_t payload = delta <= VC_PAYLOAD_NEAR ? delta - 1 : (p < 16 ? VC_PAYLOAD_NEAR + p : 63u);
-            const int tag = (int)(((255u - p) << 8) | payload);
+            const int tagv = (int)((2u << 14) | ((63u - p) << 8) | payload);     // vertical
+            const int tagd = tagv | (1 << 14);                                   // diagonal (kind 3)
             int hp[CPL];
             int c0p;
-            if (pr == 0) {
+            if (delta == 1 && i > 1) {
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) hp[c] = nw ? jgs[c] : 0;     // H[0][j] = j*g (NW) / 0 (SW)
+                for (int c = 0; c < CPL; ++c) hp[c] = Hprev[c];
+                c0p = c0prev;
+            } else if (pr == 0) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) hp[c] = nw ? jgs[c] : 0;           // H[0][j] = j*g (NW) / 0 (SW)
                 c0p = 0;
             } else {
-                uint2 pc[NP];
-                if (delta <= VC_RING) {
-                    const uint32_t rs = pr % VC_RING;
+                uint32_t pc[ND];
+                if (delta <= (uint32_t)RING) {
+                    const uint32_t rs = pr % RING;
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) pc[q] = ring[rs][q][lane];
+                    for (int q = 0; q < ND; ++q) pc[q] = ring[rs][q][lane];
                     c0p = ring_c0[rs];
                 } else {
                     const uint32_t ss = a.dp.spill_slot[nb + pr - 1];
-                    const uint2* sp = spillp + (uint64_t)ss * (NP * 64 + 1);
+                    const uint32_t* sp = spillp + (uint64_t)ss * (ND * 64 + 1);
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) pc[q] = sp[q * 64 + lane];
-                    c0p = (int)sp[NP * 64].x;
+                    for (int q = 0; q < ND; ++q) pc[q] = sp[q * 64 + lane];
+                    c0p = (int)sp[ND * 64];
+                    far_reads++;
                 }
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    hp[4 * q + 0] = (int)(pc[q].x << 16);
-                    hp[4 * q + 1] = (int)(pc[q].x & 0xFFFF0000u);
-                    hp[4 * q + 2] = (int)(pc[q].y << 16);
-                    hp[4 * q + 3] = (int)(pc[q].y & 0xFFFF0000u);
+                for (int q = 0; q < ND; ++q) {
+                    hp[2 * q + 0] = (int)(pc[q] << 16);
+                    hp[2 * q + 1] = (int)(pc[q] & 0xFFFF0000u);
                 }
             }
             // left neighbour of my first column: lane-1's last cell, lane 0 takes the pred's column 0
             const int hl = VC_DPP_SHR(hp[CPL - 1], c0p, 0x138, 0xF);
-            const int gt = gs + tag;
+            const int gt = gs + tagv;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int dsrc = c == 0 ? hl : hp[c - 1];
-                bd[c] = max(bd[c], dsrc + prof[c] + tag);
-                bv[c] = max(bv[c], hp[c] + gt);
+                bm[c] = max(bm[c], max(dsrc + prof[c] + tagd, hp[c] + gt));
             }
             b0 = max(b0, c0p + gt);
         }
@@ -737,7 +748,7 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
         int P[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            int mx = (int)((uint32_t)max(bd[c], bv[c]) & 0xFFFF0000u);
+            int mx = (int)((uint32_t)bm[c] & 0xFFFF0000u);
             if (!nw) mx = max(mx, 0);
             P[c] = mx - jgs[c];
         }
@@ -756,28 +767,29 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) H[c] = max(P[c], carry) + jgs[c];
 
-        // direction codes
-        uint32_t dcode[NP];
+        // direction codes: the winner's tag, unless the horizontal pass (or the SW floor) beat it
+        uint32_t dcode[NQ];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             uint32_t dwv = 0;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int c = 4 * q + t;
-                const bool eqd = (uint32_t)(bd[c] - H[c]) < 0x10000u;
-                const bool eqv = (uint32_t)(bv[c] - H[c]) < 0x10000u;
-                uint32_t code = eqd ? ((uint32_t)bd[c] & 63u)
-                                    : (eqv ? (0x40u | ((uint32_t)bv[c] & 63u)) : 0x80u);
-                if (!nw) code = H[c] == 0 ? 0xC0u : code;
-                dwv |= code << (8 * t);
+                if (c < CPL) {
+                    const uint32_t tg = (uint32_t)bm[c];
+                    uint32_t code = ((tg >> 8) & 0xC0u) | (tg & 0x3Fu);
+                    code = ((uint32_t)H[c] != (tg & 0xFFFF0000u)) ? (VC_K_HORZ << 6) : code;
+                    if (!nw) code = H[c] == 0 ? (VC_K_STOP << 6) : code;
+                    dwv |= code << (8 * t);
+                }
             }
             dcode[q] = dwv;
         }
         {
-            uint32_t* drow = (uint32_t*)(dirp + (uint64_t)(i - 1) * (64 * CPL));
+            uint32_t* drow = (uint32_t*)(dirp + (uint64_t)(i - 1) * (256 * NQ));
 #pragma unroll
-            for (int q = 0; q < NP; ++q) drow[q * 64 + lane] = dcode[q];
-            if (lane == 0) dir0p[i - 1] = nw ? (uint8_t)(0x40u | ((uint32_t)b0 & 63u)) : (uint8_t)0xC0u;
+            for (int q = 0; q < NQ; ++q) drow[q * 64 + lane] = dcode[q];
+            if (lane == 0) dir0p[i - 1] = nw ? (uint8_t)((VC_K_VERT << 6) | ((uint32_t)b0 & 63u)) : (uint8_t)(VC_K_STOP << 6);
         }
 
         // end cell
@@ -806,29 +818,35 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
             if ((int)((uint32_t)rm & 0xFFFF0000u) > (int)((uint32_t)best & 0xFFFF0000u)) { best = rm; best_row = i; }
         }
 
-        // keep the row: LDS ring (+ HBM when a successor is more than VC_RING rows away)
-        uint2 pk[NP];
+        // keep the row: registers, LDS ring, and HBM when a successor is more than RING rows away
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            pk[q].x = __builtin_amdgcn_perm((uint32_t)H[4 * q + 1], (uint32_t)H[4 * q + 0], 0x07060302u);
-            pk[q].y = __builtin_amdgcn_perm((uint32_t)H[4 * q + 3], (uint32_t)H[4 * q + 2], 0x07060302u);
-        }
-        const uint32_t ws = i % VC_RING;
-        __syncthreads();
+        for (int c = 0; c < CPL; ++c) Hprev[c] = H[c];
+        c0prev = col0;
+        uint32_t pk[ND];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) ring[ws][q][lane] = pk[q];
+        for (int q = 0; q < ND; ++q) pk[q] = __builtin_amdgcn_perm((uint32_t)H[2 * q + 1], (uint32_t)H[2 * q + 0], 0x07060302u);
+        const uint32_t ws = i % RING;
+        // one wave per workgroup: LDS operations of a wave retire in order, so no s_barrier (and no
+        // vmcnt(0) drain of the direction stores) is needed -- only keep the compiler from reordering
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < ND; ++q) ring[ws][q][lane] = pk[q];
         if (lane == 0) ring_c0[ws] = col0;
         if (fl & VC_RF_SPILL) {
             if (spill_cnt < VC_SPILLCAP) {
-                uint2* sp = spillp + (uint64_t)spill_cnt * (NP * 64 + 1);
+                uint32_t* sp = spillp + (uint64_t)spill_cnt * (ND * 64 + 1);
 #pragma unroll
-                for (int q = 0; q < NP; ++q) sp[q * 64 + lane] = pk[q];
-                if (lane == 0) sp[NP * 64] = make_uint2((uint32_t)col0, 0u);
+                for (int q = 0; q < ND; ++q) sp[q * 64 + lane] = pk[q];
+                if (lane == 0) sp[ND * 64] = (uint32_t)col0;
             } else bad = 1;
             spill_cnt++;
             __threadfence_block();
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && (spill_cnt | far_reads)) {
+        atomicAdd(a.stat + 2, (unsigned long long)spill_cnt);
+        atomicAdd(a.stat + 3, (unsigned long long)far_reads);
     }
 
     // publish the end cell
@@ -902,7 +920,7 @@ __global__ void k_trace(VcTraceArgs a) {
     const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
     const uint8_t* dirp = a.dir + (uint64_t)job * a.dir_stride;
     const uint8_t* dir0p = a.dir0 + (uint64_t)job * a.NC;
-    const uint32_t rowb = 64 * a.cpl;
+    const uint32_t rowb = 256 * ((a.cpl + 3) / 4);
     uint32_t n = 0;
     bool ovf = false;
     if (end != 0) {
