@@ -33,13 +33,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_CELL = 4.0           # one int16 score store + one load by a successor row
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(batch, params, budget_s):
     """CHECKER/BASELINE leg (rank 0, N=1): the reference itself when oracle/_ref travelled with the
     repo ("reference"), else our C restatement ("port"), on a bounded sample of the same workload,
     one window per task on all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as oa
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     kind = "reference" if oa.have_ref("sse41") else "port"
     if kind == "reference":
         oa.load_ref("sse41")

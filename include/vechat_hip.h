@@ -57,6 +57,7 @@ typedef struct vc_params {
     uint32_t chunk_windows;                 /* windows resident per pass; 0 = derive from memory   */
     uint64_t scratch_bytes;                 /* device scratch budget; 0 = 1/4 of free memory       */
     int32_t  profile;                       /* 1 = bracket every kernel class with HIP events      */
+    uint32_t n_streams;                     /* chunks in flight on separate HIP streams; 0 = 2     */
 } vc_params;
 
 /* A batch of windows, the unit the reference's accelerated path fills with
@@ -95,7 +96,7 @@ typedef struct vc_stats {
     double   ms[16];         /* accumulated HIP-event time per kernel class (profile=1)         */
     uint64_t launches[16];
     char     names[16][24];
-    uint32_t max_nodes, max_edges, chunk_windows;   /* what the context actually used          */
+    uint32_t max_nodes, max_edges, chunk_windows, n_streams;   /* what the context actually used */
 } vc_stats;
 
 /* -- lifecycle: stands in for createCUDABatch / ~CUDABatchProcessor (cudabatch.hpp:26,33) ------ */

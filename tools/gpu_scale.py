@@ -8,16 +8,17 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 500
 chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+streams = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 t0 = time.time()
 b = capi.synth_batch(capi.synth_cfg(1002, L, D), 0, n)
 print(f"generated {n} windows in {time.time()-t0:.1f}s, {b.bases.size/1e6:.1f} MB bases", flush=True)
-ctx = HipContext(device=0, profile=1, chunk_windows=chunk)
+ctx = HipContext(device=0, profile=1, chunk_windows=chunk, n_streams=streams)
 ctx.submit(b)
 for rep in range(2):
     t0 = time.time(); ctx.run(); ctx.sync(); t1 = time.time()
     s = ctx.stats()
     km = {k: round(v['ms'], 1) for k, v in s['kernels'].items()}
-    print(f"rep {rep}: {n/(t1-t0):.1f} win/s ({t1-t0:.3f}s) cells={s['cells']:.3e} GCUPS={s['cells']/(t1-t0)/1e9:.1f} rows={s['dp_rows']:.3e} spilled={s['spilled_rows']} far={s['far_row_reads']} NC={s['max_nodes']} EC={s['max_edges']} CW={s['chunk_windows']} ms={km}", flush=True)
+    print(f"rep {rep}: {n/(t1-t0):.1f} win/s ({t1-t0:.3f}s) cells={s['cells']:.3e} GCUPS={s['cells']/(t1-t0)/1e9:.1f} rows={s['dp_rows']:.3e} spilled={s['spilled_rows']} far={s['far_row_reads']} NC={s['max_nodes']} EC={s['max_edges']} CW={s['chunk_windows']}x{s['n_streams']} ms={km}", flush=True)
 cons, status = ctx.collect()
 import collections
 print("status histogram", collections.Counter(int(x) for x in status), "errinfo sample", [e for e in ctx.errinfo() if e != (0, 0)][:5])

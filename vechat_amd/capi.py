@@ -26,6 +26,7 @@ class VcParams(C.Structure):
         ("max_nodes", C.c_uint32), ("max_edges", C.c_uint32), ("chunk_windows", C.c_uint32),
         ("scratch_bytes", C.c_uint64),
         ("profile", C.c_int32),
+        ("n_streams", C.c_uint32),
     ]
 
 
@@ -60,7 +61,7 @@ class VcStats(C.Structure):
         ("ms", C.c_double * 16),
         ("launches", C.c_uint64 * 16),
         ("names", (C.c_char * 24) * 16),
-        ("max_nodes", C.c_uint32), ("max_edges", C.c_uint32), ("chunk_windows", C.c_uint32),
+        ("max_nodes", C.c_uint32), ("max_edges", C.c_uint32), ("chunk_windows", C.c_uint32), ("n_streams", C.c_uint32),
     ]
 
 
@@ -81,7 +82,7 @@ def default_params(**kw):
     """Defaults the Python driver ends up with (scripts/vechat:70-72: -d 0.2 -s 0.2; main.cpp:46-61)."""
     p = VcParams(device=0, match=3, mismatch=-5, gap=-4, sw_match=3, sw_mismatch=-5, sw_gap=-4,
                  min_confidence=0.2, min_support=0.2, num_prune=3, mode=0, trim=1, window_type=1,
-                 max_nodes=0, max_edges=0, chunk_windows=0, scratch_bytes=0, profile=0)
+                 max_nodes=0, max_edges=0, chunk_windows=0, scratch_bytes=0, profile=0, n_streams=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p

@@ -4,6 +4,14 @@
 // hands windows to Window::generate_consensus, shaped like its accelerated precedent
 // CUDABatchProcessor (src/cuda/cudabatch.cpp:79-270): fill a batch, run it, read statuses back.
 // There is no CPU fallback anywhere in this file: without a gfx950 device vc_create fails.
+//
+// Execution plan.  The batch is cut into chunks of CW windows; a chunk owns one workspace (graphs,
+// row records, direction matrices, pair lists) and one HIP stream.  Inside a chunk the build loop of
+// window.cpp:239-298 runs in lockstep: layer j of every window per iteration
+//     k_rows / k_topo -> k_fwd -> k_resolve -> k_trace -> k_addaln
+// then the prune rounds (k_prune_lcc -> k_topo -> [k_fwd, k_trace]* -> k_addw) and the final local
+// alignment.  Several chunks are in flight on separate streams so that the latency-bound single-lane
+// kernels (k_resolve, k_topo, k_prune_lcc) of one chunk overlap the throughput-bound k_fwd of another.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -21,15 +29,32 @@ namespace {
 thread_local std::string g_create_error;
 
 enum KClass { KC_AVG = 0, KC_INIT, KC_TOPO, KC_FWD, KC_TRACE, KC_ADDALN, KC_PRUNE, KC_ADDW, KC_FINISH, KC_ROWS, KC_RESOLVE, KC_N };
-const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace", "k_addaln", "k_prune_lcc", "k_addw", "k_finish", "k_rows", "k_resolve"};
+const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace", "k_addaln", "k_prune_lcc",
+                                 "k_addw", "k_finish", "k_rows", "k_resolve"};
+
+constexpr int kRing = 12;     // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
+constexpr int kMaxStreams = 4;
 
 uint32_t topo_lds_bytes(uint32_t NC, uint32_t EC, uint32_t STK) {
     return ((2 * NC + 15) & ~15u) + 4 * EC + 8 * NC + ((NC + 15) & ~15u) + 2 * STK + 2 * NC + 64;
 }
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
+// one chunk's device workspace + stream
+struct Work {
+    hipStream_t stream = nullptr;
+    VcGraph gr[2]{};
+    VcDp dp{};
+    uint8_t* d_dir = nullptr; uint8_t* d_dir0 = nullptr; uint32_t* d_spill = nullptr;
+    uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
+    uint16_t* d_tie_rows = nullptr; uint8_t* d_tie_cnt = nullptr;
+    uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
+    uint32_t* d_rpairs = nullptr; uint32_t* d_rnpairs = nullptr;     // realign: [CW*max_nseq*PC]
+    uint32_t* d_maxn = nullptr;
+    uint32_t* h_maxn = nullptr;                                      // pinned
+    // state of the chunk currently in flight
+    uint32_t w0 = 0, ns = 0, layers = 0, nseq_max = 0;
+    int cur = 0;
+    bool active = false;
 };
 
 }  // namespace
@@ -37,38 +62,28 @@ struct DevBuf {
 struct vc_ctx {
     vc_params prm{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // stream 0: uploads, collects
     std::string err;
-    std::vector<void*> allocs;          // everything hipMalloc'ed (freed in vc_destroy)
-    std::vector<void*> batch_allocs;    // per-batch allocations (freed on resubmit)
-    std::vector<void*> chunk_allocs;    // workspace (re-created when capacities change)
+    std::vector<void*> allocs;          // lifetime of the context
+    std::vector<void*> batch_allocs;    // per batch
+    std::vector<void*> chunk_allocs;    // workspaces (re-created when capacities change)
 
-    // batch
     bool have_batch = false, ran = false;
     VcBatchDev b{};
     std::vector<uint32_t> h_win_seq_off;
+    std::vector<uint8_t> h_layer_partial;   // [layer] does any window have a partial-span layer at this index?
     uint32_t max_layers = 0, max_len = 0, max_nseq = 0;
     uint64_t total_cons = 0;
     std::vector<uint32_t> h_cons_len;
     std::vector<uint8_t> h_status;
-    uint32_t *d_lut_w = nullptr; double* d_lut_d = nullptr;
+    uint32_t* d_lut_w = nullptr; double* d_lut_d = nullptr;
+    unsigned long long* d_stat = nullptr;   // [4] cells, rows, spilled rows, far-row reads
 
-    // workspace
-    uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, jobs_cap = 0, group_max = 1;
+    uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t dir_bytes = 0;
-    VcGraph gr[2]{};
-    VcDp dp{};
-    uint8_t* d_dir = nullptr; uint8_t* d_dir0 = nullptr; uint32_t* d_spill = nullptr;
-    uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
-    uint16_t* d_tie_rows = nullptr; uint8_t* d_tie_cnt = nullptr;
-    std::vector<uint8_t> h_layer_partial;   // [layer] does any window have a partial-span layer at this index?
-    uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
-    uint32_t* d_rpairs = nullptr; uint32_t* d_rnpairs = nullptr;     // realign: [CW*max_nseq*PC]
-    unsigned long long* d_stat = nullptr;                            // [4] cells, rows, spilled rows, far-row reads
-    uint64_t stat_spill = 0, stat_far = 0;
-    uint32_t* d_maxn = nullptr;                                      // [1]
+    Work works[kMaxStreams];
+    hipStream_t streams[kMaxStreams]{};
 
-    // stats
     vc_stats stats{};
     std::vector<hipEvent_t> ev_pool;
     struct EvRec { int cls; hipEvent_t a, b; };
@@ -130,20 +145,46 @@ int alloc_graph(vc_ctx* c, VcGraph* g) {
     return VC_OK;
 }
 
+int alloc_work(vc_ctx* c, Work* wk) {
+    const size_t CW = c->CW, NC = c->NC, EC = c->EC, PC = c->PC;
+    const size_t nd = c->cpl / 2;
+    int rc;
+    if ((rc = alloc_graph(c, &wk->gr[0])) || (rc = alloc_graph(c, &wk->gr[1]))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &wk->dp.nrows, CW)) || (rc = dalloc(c, c->chunk_allocs, &wk->dp.flags, CW)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->dp.rec, CW * NC)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->dp.spill_slot, CW * NC)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_dir, c->dir_bytes)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_dir0, (size_t)c->jobs_cap * NC)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_spill, (size_t)c->jobs_cap * VC_SPILLCAP * (nd * 64 + 1))) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_job_end, c->jobs_cap)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_job_type, c->jobs_cap)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_tie_rows, (size_t)c->jobs_cap * VC_MAXTIE)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_tie_cnt, c->jobs_cap)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_pairs, CW * PC)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_npairs, CW)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_rpairs, CW * c->max_nseq * PC)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_rnpairs, CW * c->max_nseq)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_maxn, 1)))
+        return rc;
+    return VC_OK;
+}
+
 struct Timer {
-    vc_ctx* c; int cls; hipEvent_t a = nullptr, b = nullptr;
-    Timer(vc_ctx* c_, int cls_) : c(c_), cls(cls_) {
+    vc_ctx* c; int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    Timer(vc_ctx* c_, int cls_, hipStream_t st_) : c(c_), cls(cls_), st(st_) {
         c->stats.launches[cls]++;
         if (!c->prm.profile) return;
         if (c->ev_next + 2 > c->ev_pool.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
         }
         a = c->ev_pool[c->ev_next++]; b = c->ev_pool[c->ev_next++];
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, st);
     }
     ~Timer() {
         if (!c->prm.profile) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         c->ev_recs.push_back({cls, a, b});
     }
 };
@@ -157,25 +198,23 @@ void flush_events(vc_ctx* c) {
     c->ev_next = 0;
 }
 
-constexpr int kRing = 12;    // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
-
 template <int CPL>
-void launch_fwd_t(vc_ctx* c, const VcFwdArgs& a, uint32_t jobs) {
-    hipLaunchKernelGGL((k_fwd<CPL, kRing>), dim3(jobs), dim3(64), 0, c->stream, a);
+void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs) {
+    hipLaunchKernelGGL((k_fwd<CPL, kRing>), dim3(jobs), dim3(64), 0, st, a);
 }
 
-int launch_fwd(vc_ctx* c, const VcFwdArgs& a, uint32_t jobs) {
-    Timer t(c, KC_FWD);
+int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a, uint32_t jobs) {
+    Timer t(c, KC_FWD, st);
     switch (c->cpl) {
-        case 4:  launch_fwd_t<4>(c, a, jobs); break;
-        case 6:  launch_fwd_t<6>(c, a, jobs); break;
-        case 8:  launch_fwd_t<8>(c, a, jobs); break;
-        case 10: launch_fwd_t<10>(c, a, jobs); break;
-        case 12: launch_fwd_t<12>(c, a, jobs); break;
-        case 16: launch_fwd_t<16>(c, a, jobs); break;
-        case 20: launch_fwd_t<20>(c, a, jobs); break;
-        case 24: launch_fwd_t<24>(c, a, jobs); break;
-        case 32: launch_fwd_t<32>(c, a, jobs); break;
+        case 4:  launch_fwd_t<4>(st, a, jobs); break;
+        case 6:  launch_fwd_t<6>(st, a, jobs); break;
+        case 8:  launch_fwd_t<8>(st, a, jobs); break;
+        case 10: launch_fwd_t<10>(st, a, jobs); break;
+        case 12: launch_fwd_t<12>(st, a, jobs); break;
+        case 16: launch_fwd_t<16>(st, a, jobs); break;
+        case 20: launch_fwd_t<20>(st, a, jobs); break;
+        case 24: launch_fwd_t<24>(st, a, jobs); break;
+        case 32: launch_fwd_t<32>(st, a, jobs); break;
         default: return fail(c, VC_ERR_ARG, "unsupported cells-per-lane %u", c->cpl);
     }
     return VC_OK;
@@ -186,6 +225,135 @@ uint32_t pick_cpl(uint32_t max_len) {
     for (uint32_t o : opts) if (64 * o >= max_len) return o;
     return 0;
 }
+
+// ---------------------------------------------------------------- one chunk, phase by phase
+struct Plan {
+    vc_ctx* c;
+    uint32_t NC, EC, PC, cpl, topo_lds, prune_lds, add_lds, rows_lds;
+    uint64_t rowb;
+
+    VcFwdArgs fwd_args(const Work& wk) const {
+        VcFwdArgs fa{};
+        fa.b = c->b; fa.dp = wk.dp; fa.w0 = wk.w0; fa.nslots = wk.ns; fa.NC = NC; fa.EC = EC;
+        fa.m = c->prm.match; fa.n = c->prm.mismatch; fa.g = c->prm.gap;
+        fa.sm = c->prm.sw_match; fa.sn = c->prm.sw_mismatch; fa.sg = c->prm.sw_gap;
+        fa.dir = wk.d_dir; fa.dir0 = wk.d_dir0; fa.spill = wk.d_spill;
+        fa.job_end = wk.d_job_end; fa.job_type = wk.d_job_type; fa.tie_rows = wk.d_tie_rows; fa.tie_cnt = wk.d_tie_cnt;
+        fa.stat = c->d_stat;
+        return fa;
+    }
+    VcTraceArgs trace_args(const Work& wk) const {
+        VcTraceArgs ta{};
+        ta.b = c->b; ta.dp = wk.dp; ta.w0 = wk.w0; ta.nslots = wk.ns; ta.NC = NC; ta.EC = EC; ta.cpl = cpl;
+        ta.dir = wk.d_dir; ta.dir0 = wk.d_dir0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC;
+        return ta;
+    }
+
+    void begin(Work& wk, uint32_t w0, uint32_t ns) {
+        wk.w0 = w0; wk.ns = ns; wk.cur = 0; wk.layers = 0; wk.nseq_max = 0; wk.active = true;
+        for (uint32_t w = w0; w < w0 + ns; ++w) {
+            const uint32_t n = c->h_win_seq_off[w + 1] - c->h_win_seq_off[w];
+            wk.nseq_max = std::max(wk.nseq_max, n);
+            if (n >= 3) wk.layers = std::max(wk.layers, n - 1);
+        }
+        { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3((ns + 63) / 64), dim3(64), 0, wk.stream, c->b, w0, ns); }
+        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), 0, wk.stream, c->b, wk.gr[0], w0, ns, NC, EC); }
+    }
+
+    // one layer of the build loop (window.cpp:239-298) for every window of the chunk
+    int build_layer(Work& wk, uint32_t j) {
+        const uint32_t ns = wk.ns;
+        // full-span layers: rows from the incrementally kept order; partial-span layers: exact DFS on the Subgraph
+        { Timer t(c, KC_ROWS, wk.stream);
+          hipLaunchKernelGGL(k_rows, dim3(ns), dim3(64), rows_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing); }
+        if (c->h_layer_partial[j]) {
+            Timer t(c, KC_TOPO, wk.stream);
+            hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, (int)j, 1, (uint32_t)kRing);
+        }
+        VcFwdArgs fa = fwd_args(wk);
+        fa.group = 1; fa.k0 = j; fa.mode = 0; fa.dir_stride = (uint64_t)NC * rowb;
+        int rc = launch_fwd(c, wk.stream, fa, ns);
+        if (rc) return rc;
+        { Timer t(c, KC_RESOLVE, wk.stream);
+          hipLaunchKernelGGL(k_resolve, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
+                             (const uint16_t*)wk.d_tie_rows, (const uint8_t*)wk.d_tie_cnt, wk.d_job_end); }
+        VcTraceArgs ta = trace_args(wk);
+        ta.group = 1; ta.k0 = j; ta.dir_stride = fa.dir_stride;
+        ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
+        { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, wk.stream, ta); }
+        VcAddArgs aa{};
+        aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
+        aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC;
+        { Timer t(c, KC_ADDALN, wk.stream); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, wk.stream, aa); }
+        return VC_OK;
+    }
+
+    // PruneGraph + LargestSubgraph + its TopologicalSort (window.cpp:318-321,374-383); `more` = a
+    // re-alignment round follows, so ask the device how tall the pruned graphs are
+    int prune(Work& wk, bool more) {
+        const uint32_t ns = wk.ns;
+        VcPruneArgs pa{};
+        pa.b = c->b; pa.src = wk.gr[wk.cur]; pa.dst = wk.gr[wk.cur ^ 1]; pa.w0 = wk.w0; pa.nslots = ns; pa.NC = NC; pa.EC = EC;
+        pa.min_conf = c->prm.min_confidence; pa.min_supp = c->prm.min_support;
+        { Timer t(c, KC_PRUNE, wk.stream); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), prune_lds, wk.stream, pa); }
+        wk.cur ^= 1;
+        { Timer t(c, KC_TOPO, wk.stream);
+          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing); }
+        if (more) {
+            HIPCHK(c, hipMemsetAsync(wk.d_maxn, 0, 4, wk.stream));
+            hipLaunchKernelGGL(k_max_u32, dim3((ns + 255) / 256), dim3(256), 0, wk.stream, wk.dp.nrows, ns, wk.d_maxn);
+            HIPCHK(c, hipMemcpyAsync(wk.h_maxn, wk.d_maxn, 4, hipMemcpyDeviceToHost, wk.stream));
+        }
+        return VC_OK;
+    }
+
+    // re-align every sequence to the pruned graph and add its weights (window.cpp:329-372)
+    int realign(Work& wk) {
+        const uint32_t ns = wk.ns;
+        HIPCHK(c, hipStreamSynchronize(wk.stream));          // h_maxn
+        uint32_t maxn = *wk.h_maxn;
+        if (maxn == 0) maxn = 1;
+        const uint64_t stride = (uint64_t)maxn * rowb;
+        uint32_t group = (uint32_t)std::min<uint64_t>(c->dir_bytes / (stride * ns), c->group_max);
+        if (group == 0) group = 1;
+        group = std::min(group, wk.nseq_max);
+        VcFwdArgs fa = fwd_args(wk);
+        VcTraceArgs ta = trace_args(wk);
+        for (uint32_t k0 = 0; k0 < wk.nseq_max; k0 += group) {
+            const uint32_t gsz = std::min(group, wk.nseq_max - k0);
+            fa.group = gsz; fa.k0 = k0; fa.mode = 1; fa.dir_stride = stride;
+            int rc = launch_fwd(c, wk.stream, fa, ns * gsz);
+            if (rc) return rc;
+            ta.group = gsz; ta.k0 = k0; ta.dir_stride = stride;
+            ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
+            { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns * gsz + 63) / 64), dim3(64), 0, wk.stream, ta); }
+        }
+        VcAddwArgs wa{};
+        wa.b = c->b; wa.g = wk.gr[wk.cur]; wa.dp = wk.dp; wa.w0 = wk.w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
+        wa.pairs = wk.d_rpairs; wa.npairs = wk.d_rnpairs; wa.PC = PC; wa.pair_group = c->max_nseq;
+        { Timer t(c, KC_ADDW, wk.stream); hipLaunchKernelGGL(k_addw, dim3(ns), dim3(64), 0, wk.stream, wa); }
+        return VC_OK;
+    }
+
+    // final local alignment of the backbone + corrected sequence (window.cpp:391-394)
+    int finish(Work& wk) {
+        const uint32_t ns = wk.ns;
+        VcFwdArgs fa = fwd_args(wk);
+        fa.group = 1; fa.k0 = 0; fa.mode = 2; fa.dir_stride = (uint64_t)NC * rowb;
+        int rc = launch_fwd(c, wk.stream, fa, ns);
+        if (rc) return rc;
+        VcTraceArgs ta = trace_args(wk);
+        ta.group = 1; ta.k0 = 0; ta.dir_stride = fa.dir_stride;
+        ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
+        { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, wk.stream, ta); }
+        VcFinishArgs fn{};
+        fn.b = c->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;
+        fn.pairs = wk.d_pairs; fn.npairs = wk.d_npairs; fn.PC = PC;
+        { Timer t(c, KC_FINISH, wk.stream); hipLaunchKernelGGL(k_finish, dim3(ns), dim3(64), 0, wk.stream, fn); }
+        wk.active = false;
+        return VC_OK;
+    }
+};
 
 }  // namespace
 
@@ -212,16 +380,22 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     vc_ctx* c = new vc_ctx();
     c->prm = *p;
     c->device = p->device;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
-        delete c;
-        return fail(nullptr, VC_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
+    c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 2;
+    if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }
+    for (uint32_t s = 0; s < c->n_streams; ++s) {
+        if (hipStreamCreateWithFlags(&c->streams[s], hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return fail(nullptr, VC_ERR_HIP, "hipStreamCreate failed");
+        }
+        c->works[s].stream = c->streams[s];
+        if (hipHostMalloc((void**)&c->works[s].h_maxn, 64) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipHostMalloc failed"); }
     }
+    c->stream = c->streams[0];
     // lookup tables from this host's libm, like the reference computes them (graph.cpp:169, window.cpp:235)
     uint32_t lw[256]; double ld[256];
     vc_weight_lut(lw);
     for (int ch = 0; ch < 256; ++ch) ld[ch] = 1 - pow(10, (33 - (int)(signed char)ch) / 10.0);
-    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) ||
-        dalloc(c, c->allocs, &c->d_stat, 4) || dalloc(c, c->allocs, &c->d_maxn, 1)) {
+    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, 4)) {
         g_create_error = c->err; vc_destroy(c); return VC_ERR_HIP;
     }
     (void)hipMemcpy(c->d_lut_w, lw, sizeof(lw), hipMemcpyHostToDevice);
@@ -235,12 +409,15 @@ int vc_create(vc_ctx** out, const vc_params* p) {
 void vc_destroy(vc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     free_list(c->chunk_allocs);
     free_list(c->batch_allocs);
     free_list(c->allocs);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (uint32_t s = 0; s < kMaxStreams; ++s) {
+        if (c->works[s].h_maxn) (void)hipHostFree(c->works[s].h_maxn);
+        if (c->streams[s]) (void)hipStreamDestroy(c->streams[s]);
+    }
     delete c;
 }
 
@@ -289,6 +466,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         const double est = depth > 0 ? 0.36 * ((double)sum / depth) * std::pow(depth, 0.55) : 0.0;
         need_nodes = std::max<uint64_t>(need_nodes, L + (uint64_t)std::ceil(est) + 64);
     }
+    (void)hipDeviceSynchronize();
     free_list(c->batch_allocs);
     c->have_batch = false; c->ran = false;
     VcBatchDev& b = c->b;
@@ -315,9 +493,9 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     b.bases = d_ba; b.quals = d_qu; b.win_fasta = d_wf;
     b.lut_w = c->d_lut_w; b.lut_d = c->d_lut_d;
     c->h_win_seq_off.assign(hb->win_seq_off, hb->win_seq_off + nw + 1);
-    c->max_layers = max_layers; c->max_len = max_len; c->max_nseq = max_nseq;
     c->h_layer_partial = layer_partial;
     c->h_layer_partial.resize(max_nseq + 2, 0);
+    c->max_layers = max_layers; c->max_len = max_len;
 
     // capacities
     uint32_t NC = c->prm.max_nodes ? c->prm.max_nodes : (uint32_t)std::min<uint64_t>(need_nodes, 60000);
@@ -328,59 +506,40 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     if (NC > 60000) return fail(c, VC_ERR_ARG, "max_nodes %u exceeds the 16-bit id space", NC);
     const uint32_t cpl = pick_cpl(max_len);
     if (!cpl) return fail(c, VC_ERR_ARG, "sequence length %u exceeds the kernels' 2048-column envelope", max_len);
-    hipDeviceProp_t prop;
-    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-    const uint32_t lds_max = (uint32_t)prop.sharedMemPerBlock ? (uint32_t)std::max<size_t>(prop.sharedMemPerBlock, 65536) : 65536;
     const uint32_t lds_cap = 160 * 1024;
-    (void)lds_max;
     if (topo_lds_bytes(NC, EC, c->STK) > lds_cap || vc_prune_lds_bytes(NC, EC) > lds_cap)
         return fail(c, VC_ERR_ARG, "graph capacity %u nodes / %u edges does not fit the 160 KB LDS", NC, EC);
     const uint32_t PC = NC + max_len + 8;
 
-    // chunk size from the scratch budget
+    // chunk size from the scratch budget (split over the streams)
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6);
+    const uint32_t S = c->n_streams;
+    uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6)) / S;
     const uint64_t rowb = 256ull * ((cpl + 3) / 4);
     const uint64_t nd_ = cpl / 2;
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN + 4) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4);
     const uint64_t per_job = NC * rowb + NC + (uint64_t)VC_SPILLCAP * (nd_ * 64 + 1) * 4 + 8 + 2 * VC_MAXTIE + 8;
-    uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
-    CW = std::min(CW, nw);
+    uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 4096;
+    CW = std::min(CW, (nw + S - 1) / S);
+    if (CW == 0) CW = 1;
     while (CW > 64 && (per_slot_fixed + per_job) * CW > budget) CW /= 2;
     if ((per_slot_fixed + per_job) * CW > budget) return fail(c, VC_ERR_ARG, "scratch budget %llu too small", (unsigned long long)budget);
     // extra dir space lets re-alignment rounds run several sequences of a window per launch
     uint64_t spare = budget - (per_slot_fixed + per_job) * CW;
-    uint32_t group_max = 1 + (uint32_t)std::min<uint64_t>(spare / (per_job * CW), 15);
+    uint32_t group_max = 1 + (uint32_t)std::min<uint64_t>(spare / (per_job * CW), 7);
     if (group_max > max_nseq) group_max = max_nseq;
 
     const bool same = c->NC == NC && c->EC == EC && c->CW == CW && c->cpl == cpl && c->PC == PC &&
                       c->group_max == group_max && c->max_nseq == max_nseq && !c->chunk_allocs.empty();
     if (!same) {
         free_list(c->chunk_allocs);
-        c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max;
+        c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
         c->jobs_cap = CW * group_max;
-        if ((rc = alloc_graph(c, &c->gr[0])) || (rc = alloc_graph(c, &c->gr[1]))) return rc;
-        if ((rc = dalloc(c, c->chunk_allocs, &c->dp.nrows, CW)) || (rc = dalloc(c, c->chunk_allocs, &c->dp.flags, CW)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->dp.rec, (size_t)CW * NC)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->dp.rank2node, (size_t)CW * NC)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->dp.ovf, (size_t)CW * EC)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->dp.spill_slot, (size_t)CW * NC)))
-            return rc;
         c->dir_bytes = (uint64_t)c->jobs_cap * NC * rowb;
-        if ((rc = dalloc(c, c->chunk_allocs, &c->d_dir, c->dir_bytes)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_dir0, (size_t)c->jobs_cap * NC)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_spill, (size_t)c->jobs_cap * VC_SPILLCAP * (nd_ * 64 + 1))) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_job_end, c->jobs_cap)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_job_type, c->jobs_cap)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_tie_rows, (size_t)c->jobs_cap * VC_MAXTIE)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_tie_cnt, c->jobs_cap)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_pairs, (size_t)CW * PC)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_npairs, CW)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_rpairs, (size_t)CW * max_nseq * PC)) ||
-            (rc = dalloc(c, c->chunk_allocs, &c->d_rnpairs, (size_t)CW * max_nseq)))
-            return rc;
+        for (uint32_t s = 0; s < S; ++s)
+            if ((rc = alloc_work(c, &c->works[s]))) return rc;
     }
     b.cons_cap = NC;
     if ((rc = dalloc(c, c->batch_allocs, &b.cons, (size_t)nw * b.cons_cap))) return rc;
@@ -397,117 +556,52 @@ int vc_run(vc_ctx* c) {
     if (!c->have_batch) return fail(c, VC_ERR_STATE, "vc_run before vc_submit");
     HIPCHK(c, hipSetDevice(c->device));
     const VcBatchDev& b = c->b;
-    const uint32_t NC = c->NC, EC = c->EC, CW = c->CW, PC = c->PC, cpl = c->cpl;
-    const uint32_t topo_lds = topo_lds_bytes(NC, EC, c->STK);
-    const uint32_t prune_lds = vc_prune_lds_bytes(NC, EC);
-    const uint32_t add_lds = 12 * PC + 2 * NC + 64;
-    const uint32_t rows_lds = NC + 64;
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)topo_lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)add_lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)topo_lds));
+    Plan pl{};
+    pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
+    pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK);
+    pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
+    pl.add_lds = 12 * c->PC + 2 * c->NC + 64;
+    pl.rows_lds = c->NC + 64;
+    pl.rowb = 256ull * ((c->cpl + 3) / 4);
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.topo_lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prune_lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.topo_lds));
     HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 32, c->stream));
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
     HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, (size_t)b.n_windows * 4, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < KC_N; ++i) { c->stats.ms[i] = 0; c->stats.launches[i] = 0; }
-    const uint64_t rowb = 256ull * ((cpl + 3) / 4);
 
-    for (uint32_t w0 = 0; w0 < b.n_windows; w0 += CW) {
-        const uint32_t ns = std::min(CW, b.n_windows - w0);
-        uint32_t layers = 0, nseq_max = 0;
-        for (uint32_t w = w0; w < w0 + ns; ++w) {
-            const uint32_t n = c->h_win_seq_off[w + 1] - c->h_win_seq_off[w];
-            nseq_max = std::max(nseq_max, n);
-            if (n >= 3) layers = std::max(layers, n - 1);
+    const uint32_t S = c->n_streams, CW = c->CW;
+    for (uint32_t g0 = 0; g0 < b.n_windows; g0 += S * CW) {
+        // S chunks advance in lockstep, each on its own stream
+        uint32_t max_layers = 0;
+        for (uint32_t s = 0; s < S; ++s) {
+            const uint32_t w0 = g0 + s * CW;
+            c->works[s].active = false;
+            if (w0 >= b.n_windows) continue;
+            pl.begin(c->works[s], w0, std::min(CW, b.n_windows - w0));
+            max_layers = std::max(max_layers, c->works[s].layers);
         }
-        { Timer t(c, KC_AVG); hipLaunchKernelGGL(k_avg, dim3((ns + 63) / 64), dim3(64), 0, c->stream, b, w0, ns); }
-        { Timer t(c, KC_INIT); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), 0, c->stream, b, c->gr[0], w0, ns, NC, EC); }
-        if (layers == 0) continue;
-
-        VcFwdArgs fa{};
-        fa.b = b; fa.dp = c->dp; fa.w0 = w0; fa.nslots = ns; fa.NC = NC; fa.EC = EC;
-        fa.m = c->prm.match; fa.n = c->prm.mismatch; fa.g = c->prm.gap;
-        fa.sm = c->prm.sw_match; fa.sn = c->prm.sw_mismatch; fa.sg = c->prm.sw_gap;
-        fa.dir = c->d_dir; fa.dir0 = c->d_dir0; fa.spill = c->d_spill;
-        fa.job_end = c->d_job_end; fa.job_type = c->d_job_type; fa.tie_rows = c->d_tie_rows; fa.tie_cnt = c->d_tie_cnt;
-        fa.stat = c->d_stat;
-        VcTraceArgs ta{};
-        ta.b = b; ta.dp = c->dp; ta.w0 = w0; ta.nslots = ns; ta.NC = NC; ta.EC = EC; ta.cpl = cpl;
-        ta.dir = c->d_dir; ta.dir0 = c->d_dir0; ta.job_end = c->d_job_end; ta.job_type = c->d_job_type; ta.PC = PC;
-
-        // ---- build loop (window.cpp:239-298): one layer of every window per iteration
-        int cur = 0;
-        for (uint32_t j = 1; j <= layers; ++j) {
-            // full-span layers: rows from the incrementally kept order; partial-span layers: exact DFS on the Subgraph
-            { Timer t(c, KC_ROWS);
-              hipLaunchKernelGGL(k_rows, dim3(ns), dim3(64), rows_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, (int)j, (uint32_t)kRing); }
-            if (c->h_layer_partial[j]) {
-                Timer t(c, KC_TOPO);
-                hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, (int)j, 1, (uint32_t)kRing);
-            }
-            fa.group = 1; fa.k0 = j; fa.mode = 0; fa.dir_stride = (uint64_t)NC * rowb;
-            int rc = launch_fwd(c, fa, ns);
-            if (rc) return rc;
-            { Timer t(c, KC_RESOLVE);
-              hipLaunchKernelGGL(k_resolve, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK,
-                                 (const uint16_t*)c->d_tie_rows, (const uint8_t*)c->d_tie_cnt, c->d_job_end); }
-            ta.group = 1; ta.k0 = j; ta.dir_stride = fa.dir_stride;
-            ta.pairs = c->d_pairs; ta.npairs = c->d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
-            { Timer t(c, KC_TRACE); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, c->stream, ta); }
-            VcAddArgs aa{};
-            aa.b = b; aa.g = c->gr[cur]; aa.dp = c->dp; aa.w0 = w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
-            aa.pairs = c->d_pairs; aa.npairs = c->d_npairs; aa.PC = PC;
-            { Timer t(c, KC_ADDALN); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, c->stream, aa); }
-        }
-
-        // ---- prune rounds (window.cpp:318-386)
+        int rc;
+        for (uint32_t j = 1; j <= max_layers; ++j)
+            for (uint32_t s = 0; s < S; ++s)
+                if (c->works[s].active && j <= c->works[s].layers && (rc = pl.build_layer(c->works[s], j))) return rc;
         for (uint32_t r = 0; r < c->prm.num_prune; ++r) {
-            VcPruneArgs pa{};
-            pa.b = b; pa.src = c->gr[cur]; pa.dst = c->gr[cur ^ 1]; pa.w0 = w0; pa.nslots = ns; pa.NC = NC; pa.EC = EC;
-            pa.min_conf = c->prm.min_confidence; pa.min_supp = c->prm.min_support;
-            { Timer t(c, KC_PRUNE); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), prune_lds, c->stream, pa); }
-            cur ^= 1;
-            { Timer t(c, KC_TOPO);
-              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, c->stream, b, c->gr[cur], c->dp, w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing); }
-            if (r + 1 == c->prm.num_prune) break;
-            // how many rows do the pruned graphs have?  sizes the per-job direction matrices
-            HIPCHK(c, hipMemsetAsync(c->d_maxn, 0, 4, c->stream));
-            hipLaunchKernelGGL(k_max_u32, dim3((ns + 255) / 256), dim3(256), 0, c->stream, c->dp.nrows, ns, c->d_maxn);
-            uint32_t maxn = 0;
-            HIPCHK(c, hipMemcpyAsync(&maxn, c->d_maxn, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (maxn == 0) maxn = 1;
-            const uint64_t stride = (uint64_t)maxn * rowb;
-            uint32_t group = (uint32_t)std::min<uint64_t>(c->dir_bytes / (stride * ns), c->group_max);
-            if (group == 0) group = 1;
-            group = std::min(group, nseq_max);
-            for (uint32_t k0 = 0; k0 < nseq_max; k0 += group) {
-                const uint32_t gsz = std::min(group, nseq_max - k0);
-                fa.group = gsz; fa.k0 = k0; fa.mode = 1; fa.dir_stride = stride;
-                int rc = launch_fwd(c, fa, ns * gsz);
-                if (rc) return rc;
-                ta.group = gsz; ta.k0 = k0; ta.dir_stride = stride;
-                ta.pairs = c->d_rpairs; ta.npairs = c->d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
-                { Timer t(c, KC_TRACE); hipLaunchKernelGGL(k_trace, dim3((ns * gsz + 63) / 64), dim3(64), 0, c->stream, ta); }
-            }
-            VcAddwArgs wa{};
-            wa.b = b; wa.g = c->gr[cur]; wa.dp = c->dp; wa.w0 = w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
-            wa.pairs = c->d_rpairs; wa.npairs = c->d_rnpairs; wa.PC = PC; wa.pair_group = c->max_nseq;
-            { Timer t(c, KC_ADDW); hipLaunchKernelGGL(k_addw, dim3(ns), dim3(64), 0, c->stream, wa); }
+            const bool more = r + 1 < c->prm.num_prune;
+            for (uint32_t s = 0; s < S; ++s)
+                if (c->works[s].active && c->works[s].layers && (rc = pl.prune(c->works[s], more))) return rc;
+            if (!more) break;
+            for (uint32_t s = 0; s < S; ++s)
+                if (c->works[s].active && c->works[s].layers && (rc = pl.realign(c->works[s]))) return rc;
         }
-
-        // ---- final local alignment of the backbone + corrected sequence (window.cpp:391-394)
-        fa.group = 1; fa.k0 = 0; fa.mode = 2; fa.dir_stride = (uint64_t)NC * rowb;
-        int rc = launch_fwd(c, fa, ns);
-        if (rc) return rc;
-        ta.group = 1; ta.k0 = 0; ta.dir_stride = fa.dir_stride;
-        ta.pairs = c->d_pairs; ta.npairs = c->d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
-        { Timer t(c, KC_TRACE); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, c->stream, ta); }
-        VcFinishArgs fn{};
-        fn.b = b; fn.g = c->gr[cur]; fn.dp = c->dp; fn.w0 = w0; fn.nslots = ns; fn.NC = NC;
-        fn.pairs = c->d_pairs; fn.npairs = c->d_npairs; fn.PC = PC;
-        { Timer t(c, KC_FINISH); hipLaunchKernelGGL(k_finish, dim3(ns), dim3(64), 0, c->stream, fn); }
+        for (uint32_t s = 0; s < S; ++s) {
+            if (!c->works[s].active) continue;
+            if (c->works[s].layers) { if ((rc = pl.finish(c->works[s]))) return rc; }
+            else c->works[s].active = false;
+        }
     }
     HIPCHK(c, hipGetLastError());
     c->ran = true;
@@ -517,13 +611,14 @@ int vc_run(vc_ctx* c) {
 int vc_sync(vc_ctx* c) {
     if (!c) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s]));
     if (c->prm.profile) flush_events(c);
     return VC_OK;
 }
 
 static int fetch_lengths(vc_ctx* c) {
     if (!c->ran) return fail(c, VC_ERR_STATE, "no finished run");
+    for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s]));
     const uint32_t nw = c->b.n_windows;
     c->h_cons_len.resize(nw); c->h_status.resize(nw);
     HIPCHK(c, hipMemcpyAsync(c->h_cons_len.data(), c->b.cons_len, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
@@ -605,10 +700,10 @@ int vc_get_stats(vc_ctx* c, vc_stats* s) {
     HIPCHK(c, hipSetDevice(c->device));
     unsigned long long st[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpy(st, c->d_stat, 32, hipMemcpyDeviceToHost));
-    c->stat_spill = st[2]; c->stat_far = st[3];
     c->stats.cells = st[0]; c->stats.dp_rows = st[1];
-    c->stats.alignments = c->stats.launches[KC_FWD];
     c->stats.spilled_rows = st[2]; c->stats.far_row_reads = st[3];
+    c->stats.alignments = c->stats.launches[KC_FWD];
+    c->stats.n_streams = c->n_streams;
     *s = c->stats;
     return VC_OK;
 }
