@@ -44,7 +44,7 @@ struct Work {
     hipStream_t stream = nullptr;
     VcGraph gr[2]{};
     VcDp dp{};
-    uint8_t* d_dir = nullptr; uint8_t* d_dir0 = nullptr; uint32_t* d_spill = nullptr;
+    uint32_t* d_hmat = nullptr; int16_t* d_c0 = nullptr;
     uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
     uint16_t* d_tie_rows = nullptr; uint8_t* d_tie_cnt = nullptr;
     uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
@@ -80,7 +80,7 @@ struct vc_ctx {
     unsigned long long* d_stat = nullptr;   // [4] cells, rows, spilled rows, far-row reads
 
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
-    uint64_t dir_bytes = 0;
+    uint64_t hmat_dwords = 0;
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
 
@@ -147,7 +147,6 @@ int alloc_graph(vc_ctx* c, VcGraph* g) {
 
 int alloc_work(vc_ctx* c, Work* wk) {
     const size_t CW = c->CW, NC = c->NC, EC = c->EC, PC = c->PC;
-    const size_t nd = c->cpl / 2;
     int rc;
     if ((rc = alloc_graph(c, &wk->gr[0])) || (rc = alloc_graph(c, &wk->gr[1]))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &wk->dp.nrows, CW)) || (rc = dalloc(c, c->chunk_allocs, &wk->dp.flags, CW)) ||
@@ -155,9 +154,8 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.spill_slot, CW * NC)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_dir, c->dir_bytes)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_dir0, (size_t)c->jobs_cap * NC)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_spill, (size_t)c->jobs_cap * VC_SPILLCAP * (nd * 64 + 1))) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_c0, (size_t)c->jobs_cap * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_end, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_type, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_tie_rows, (size_t)c->jobs_cap * VC_MAXTIE)) ||
@@ -230,14 +228,14 @@ uint32_t pick_cpl(uint32_t max_len) {
 struct Plan {
     vc_ctx* c;
     uint32_t NC, EC, PC, cpl, topo_lds, prune_lds, add_lds, rows_lds;
-    uint64_t rowb;
+    uint64_t rowd;          // dwords per H row
 
     VcFwdArgs fwd_args(const Work& wk) const {
         VcFwdArgs fa{};
         fa.b = c->b; fa.dp = wk.dp; fa.w0 = wk.w0; fa.nslots = wk.ns; fa.NC = NC; fa.EC = EC;
         fa.m = c->prm.match; fa.n = c->prm.mismatch; fa.g = c->prm.gap;
         fa.sm = c->prm.sw_match; fa.sn = c->prm.sw_mismatch; fa.sg = c->prm.sw_gap;
-        fa.dir = wk.d_dir; fa.dir0 = wk.d_dir0; fa.spill = wk.d_spill;
+        fa.hmat = wk.d_hmat; fa.c0 = wk.d_c0;
         fa.job_end = wk.d_job_end; fa.job_type = wk.d_job_type; fa.tie_rows = wk.d_tie_rows; fa.tie_cnt = wk.d_tie_cnt;
         fa.stat = c->d_stat;
         return fa;
@@ -245,7 +243,9 @@ struct Plan {
     VcTraceArgs trace_args(const Work& wk) const {
         VcTraceArgs ta{};
         ta.b = c->b; ta.dp = wk.dp; ta.w0 = wk.w0; ta.nslots = wk.ns; ta.NC = NC; ta.EC = EC; ta.cpl = cpl;
-        ta.dir = wk.d_dir; ta.dir0 = wk.d_dir0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC;
+        ta.m = c->prm.match; ta.n = c->prm.mismatch; ta.g = c->prm.gap;
+        ta.sm = c->prm.sw_match; ta.sn = c->prm.sw_mismatch; ta.sg = c->prm.sw_gap;
+        ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC;
         return ta;
     }
 
@@ -271,14 +271,14 @@ struct Plan {
             hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, (int)j, 1, (uint32_t)kRing);
         }
         VcFwdArgs fa = fwd_args(wk);
-        fa.group = 1; fa.k0 = j; fa.mode = 0; fa.dir_stride = (uint64_t)NC * rowb;
+        fa.group = 1; fa.k0 = j; fa.mode = 0; fa.hstride = (uint64_t)NC * rowd;
         int rc = launch_fwd(c, wk.stream, fa, ns);
         if (rc) return rc;
         { Timer t(c, KC_RESOLVE, wk.stream);
           hipLaunchKernelGGL(k_resolve, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
                              (const uint16_t*)wk.d_tie_rows, (const uint8_t*)wk.d_tie_cnt, wk.d_job_end); }
         VcTraceArgs ta = trace_args(wk);
-        ta.group = 1; ta.k0 = j; ta.dir_stride = fa.dir_stride;
+        ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
         { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, wk.stream, ta); }
         VcAddArgs aa{};
@@ -313,18 +313,18 @@ struct Plan {
         HIPCHK(c, hipStreamSynchronize(wk.stream));          // h_maxn
         uint32_t maxn = *wk.h_maxn;
         if (maxn == 0) maxn = 1;
-        const uint64_t stride = (uint64_t)maxn * rowb;
-        uint32_t group = (uint32_t)std::min<uint64_t>(c->dir_bytes / (stride * ns), c->group_max);
+        const uint64_t stride = (uint64_t)maxn * rowd;
+        uint32_t group = (uint32_t)std::min<uint64_t>(c->hmat_dwords / (stride * ns), c->group_max);
         if (group == 0) group = 1;
         group = std::min(group, wk.nseq_max);
         VcFwdArgs fa = fwd_args(wk);
         VcTraceArgs ta = trace_args(wk);
         for (uint32_t k0 = 0; k0 < wk.nseq_max; k0 += group) {
             const uint32_t gsz = std::min(group, wk.nseq_max - k0);
-            fa.group = gsz; fa.k0 = k0; fa.mode = 1; fa.dir_stride = stride;
+            fa.group = gsz; fa.k0 = k0; fa.mode = 1; fa.hstride = stride;
             int rc = launch_fwd(c, wk.stream, fa, ns * gsz);
             if (rc) return rc;
-            ta.group = gsz; ta.k0 = k0; ta.dir_stride = stride;
+            ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
             { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns * gsz + 63) / 64), dim3(64), 0, wk.stream, ta); }
         }
@@ -339,11 +339,11 @@ struct Plan {
     int finish(Work& wk) {
         const uint32_t ns = wk.ns;
         VcFwdArgs fa = fwd_args(wk);
-        fa.group = 1; fa.k0 = 0; fa.mode = 2; fa.dir_stride = (uint64_t)NC * rowb;
+        fa.group = 1; fa.k0 = 0; fa.mode = 2; fa.hstride = (uint64_t)NC * rowd;
         int rc = launch_fwd(c, wk.stream, fa, ns);
         if (rc) return rc;
         VcTraceArgs ta = trace_args(wk);
-        ta.group = 1; ta.k0 = 0; ta.dir_stride = fa.dir_stride;
+        ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
         { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, wk.stream, ta); }
         VcFinishArgs fn{};
@@ -380,7 +380,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     vc_ctx* c = new vc_ctx();
     c->prm = *p;
     c->device = p->device;
-    c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 2;
+    c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 4;
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }
     for (uint32_t s = 0; s < c->n_streams; ++s) {
         if (hipStreamCreateWithFlags(&c->streams[s], hipStreamNonBlocking) != hipSuccess) {
@@ -516,11 +516,10 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     const uint32_t S = c->n_streams;
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6)) / S;
-    const uint64_t rowb = 256ull * ((cpl + 3) / 4);
-    const uint64_t nd_ = cpl / 2;
+    const uint64_t rowd = 64ull * (cpl / 2);
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN + 4) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4);
-    const uint64_t per_job = NC * rowb + NC + (uint64_t)VC_SPILLCAP * (nd_ * 64 + 1) * 4 + 8 + 2 * VC_MAXTIE + 8;
+    const uint64_t per_job = NC * rowd * 4 + NC * 2 + 8 + 2 * VC_MAXTIE + 8;
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 4096;
     CW = std::min(CW, (nw + S - 1) / S);
     if (CW == 0) CW = 1;
@@ -537,7 +536,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         free_list(c->chunk_allocs);
         c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
         c->jobs_cap = CW * group_max;
-        c->dir_bytes = (uint64_t)c->jobs_cap * NC * rowb;
+        c->hmat_dwords = (uint64_t)c->jobs_cap * NC * rowd;
         for (uint32_t s = 0; s < S; ++s)
             if ((rc = alloc_work(c, &c->works[s]))) return rc;
     }
@@ -562,7 +561,7 @@ int vc_run(vc_ctx* c) {
     pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
     pl.add_lds = 12 * c->PC + 2 * c->NC + 64;
     pl.rows_lds = c->NC + 64;
-    pl.rowb = 256ull * ((c->cpl + 3) / 4);
+    pl.rowd = 64ull * (c->cpl / 2);
     HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.topo_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prune_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));

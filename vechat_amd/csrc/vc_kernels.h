@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         uint32_t my_sp = wave_excl_sum(sp_flag, tot_sp) + spill_base;
         if (act) {
             if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }   // virtual row 0 is `row` rows above
-            if (np > 64) bad = 1;
+            if (np > 255) bad = 1;
             if (is_ovf) {
                 if (my_ovf + np > EC) bad = 1;
                 else {
@@ -372,7 +372,6 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
                         e = tn >> 16;
                         if ((s_flag[t] & need) != need) continue;
                         uint32_t delta = r - s_noderank[t];
-                        if (delta > VC_PAYLOAD_NEAR && k >= 16) bad = 1;
                         dp.ovf[eb + my_ovf + k] = (uint16_t)delta;
                         k++;
                     }
@@ -391,7 +390,6 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         ovf_base += tot_ovf;
         spill_base += tot_sp;
     }
-    if (spill_base > VC_SPILLCAP) bad = 1;
     bad = __any(bad);
     if (lane == 0) {
         dp.nrows[slot] = nrows;
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
         const uint32_t my_sp = wave_excl_sum(sp_flag, tot_sp) + spill_base;
         if (act) {
             if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }
-            if (np > 64) bad = 1;
+            if (np > 255) bad = 1;
             if (is_ovf) {
                 if (my_ovf + np > EC) bad = 1;
                 else {
@@ -477,7 +475,6 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
                         const uint32_t tn = g.e_tn[eb + e];
                         e = tn >> 16;
                         const uint32_t delta = r - g.pos[nb + (tn & 0xFFFF)];
-                        if (delta > VC_PAYLOAD_NEAR && k >= 16) bad = 1;
                         dp.ovf[eb + my_ovf + k] = (uint16_t)delta;
                         k++;
                     }
@@ -498,7 +495,6 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
         ovf_base += tot_ovf;
         spill_base += tot_sp;
     }
-    if (spill_base > VC_SPILLCAP) bad = 1;
     bad = __any(bad);
     broken = __any(broken);
     if (broken) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 12, 0); return; }   // order invariant violated
@@ -556,14 +552,13 @@ __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp
 // ------------------------------------------------------------------------------------------------
 // k_fwd: linear-gap graph DP, one alignment per wavefront (64-thread workgroup = 1 wave).
 //   columns: lane l owns columns l*CPL+1 .. l*CPL+CPL (contiguous); column 0 is a per-row scalar
-//   scores:  32-bit lanes hold H<<16.  The low 16 bits of every candidate carry a tag
-//                [15:14] kind (3 diagonal, 2 vertical)   [13:8] 63 - p   [5:0] payload
-//            so ONE running v_max over all candidates yields "largest score; diagonal before vertical;
-//            first predecessor in in-edge order" -- exactly the order sisd_alignment_engine.cpp:392-448
-//            scans when it backtracks -- and the direction byte falls out of the winner's tag.
-//   rows:    the previous row stays in registers; the last RING rows live in LDS as packed int16;
-//            rows that a successor more than RING rows away needs are also parked in HBM
-//   output:  one direction byte per cell (HBM, coalesced dwords) + the end cell
+//   scores:  int16, two cells per 32-bit lane register, packed math (v_pk_add / v_pk_max_i16) -- the
+//            same width the reference's SIMD engine picks (simd impl:699-754), no saturation needed
+//            inside the envelope checked below
+//   rows:    the previous row stays in registers; the last RING rows live in LDS; rows that a successor
+//            more than RING rows away needs are re-read from the H matrix in HBM
+//   output:  the H matrix (2 B/cell, coalesced 256-B stores), column 0 per row, the end cell; the
+//            backtrack (k_trace) re-derives every move from H exactly as sisd:362-459 does
 // mode: 0 build (NW), 1 re-alignment (NW for backbone/full-span else SW), 2 final SW of the backbone
 // ------------------------------------------------------------------------------------------------
 struct VcFwdArgs {
@@ -574,23 +569,47 @@ struct VcFwdArgs {
     int mode;
     int m, n, g;                   // NW scores
     int sm, sn, sg;                // SW scores
-    uint8_t*  dir;                 // [jobs * dir_stride]
-    uint64_t  dir_stride;          // bytes
-    uint8_t*  dir0;                // [jobs * NC]
-    uint32_t* spill;               // [jobs * VC_SPILLCAP * (CPL/2*64 + 1)]
+    uint32_t* hmat;                // [jobs * hstride] packed int16 H, row = [CPL/2][64 lanes] dwords
+    uint64_t  hstride;             // dwords per job
+    int16_t*  c0;                  // [jobs * NC] H[i][0]
     uint32_t* job_end;             // [jobs] (row << 16) | col ; 0 = empty alignment
     uint8_t*  job_type;            // [jobs] 0 SW, 1 NW, 255 skipped
     uint16_t* tie_rows;            // [jobs * VC_MAXTIE] NW: sink rows sharing the best end score (incremental order only)
     uint8_t*  tie_cnt;             // [jobs]
-    unsigned long long* stat;      // [4] cells, rows, spilled rows, far-row reads
+    unsigned long long* stat;      // [4] cells, rows, -, far-row reads
 };
 
 #define VC_DPP_SHR(v, old, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xF, false)
 
+typedef short vc_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(vc_s2, a), __builtin_bit_cast(vc_s2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (vc_s2)(__builtin_bit_cast(vc_s2, a) + __builtin_bit_cast(vc_s2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (vc_s2)(__builtin_bit_cast(vc_s2, a) - __builtin_bit_cast(vc_s2, b)));
+}
+// d.lo = a.lo ; d.hi = max(a.hi, a.lo)
+__device__ __forceinline__ uint32_t pk_max_hi_with_lo(uint32_t a) {
+    uint32_t d;
+    asm("v_pk_max_i16 %0, %1, %1 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a));
+    return d;
+}
+// d.lo = max(a.lo, b.hi) ; d.hi = max(a.hi, b.hi)
+__device__ __forceinline__ uint32_t pk_max_bcast_hi(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_max_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xFFFFu) * 0x10001u; }
+__device__ __forceinline__ int pk_lo(uint32_t a) { return (int)(short)(a & 0xFFFF); }
+__device__ __forceinline__ int pk_hi(uint32_t a) { return (int)a >> 16; }
+
 template <int CPL, int RING>
 __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     constexpr int ND = CPL / 2;              // packed int16 dwords per lane per row
-    constexpr int NQ = (CPL + 3) / 4;        // direction dwords per lane per row
     __shared__ uint32_t ring[RING][ND][64];
     __shared__ int ring_c0[RING];
     const int lane = vc_lane();
@@ -612,7 +631,8 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
     const uint32_t nrows = a.dp.nrows[slot];
     const uint64_t nb = (uint64_t)slot * a.NC;
-    // envelope: int16 scores like the reference's int16 lanes (simd impl:699-754), tag-able predecessors
+    // envelope: the reference's int16 condition (simd impl:699-706) on the real length, plus headroom
+    // for H - j*g and for the cells this kernel computes beyond the sequence end
     {
         long long li = (long long)len + 8, lj = nrows;
         long long d = li > lj ? li - lj : lj - li, mn = li < lj ? li : lj;
@@ -632,39 +652,45 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
         atomicAdd(a.stat + 1, (unsigned long long)nrows);
     }
 
-    // sequence bytes of my columns (0xFF beyond the end: matches nothing)
-    uint32_t sb[NQ];
+    // match/mismatch profile of my columns for the four usual bases (packed pairs); other row bytes are
+    // compared on the fly.  Columns beyond the sequence end never match.
+    uint32_t pfA[ND], pfC[ND], pfG[ND], pfT[ND], sbp[ND];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            uint32_t idx = lane * CPL + q * 4 + t;
-            uint32_t c = (q * 4 + t < CPL && idx < len) ? a.b.bases[so + idx] : 0xFFu;
-            v |= c << (8 * t);
-        }
-        sb[q] = v;
+    for (int q = 0; q < ND; ++q) {
+        const uint32_t i0 = lane * CPL + 2 * q, i1 = i0 + 1;
+        const uint32_t b0 = i0 < len ? a.b.bases[so + i0] : 0xFFu;
+        const uint32_t b1 = i1 < len ? a.b.bases[so + i1] : 0xFFu;
+        sbp[q] = b0 | (b1 << 16);
+        auto sc = [&](uint32_t x) { return ((uint32_t)((b0 == x) ? m : n) & 0xFFFFu) | ((uint32_t)((b1 == x) ? m : n) << 16); };
+        pfA[q] = sc('A'); pfC[q] = sc('C'); pfG[q] = sc('G'); pfT[q] = sc('T');
     }
-    const int gs = g * 65536, ms = m * 65536, nsc = n * 65536;
-    int jgs[CPL];
+    const uint32_t gg = pk_dup(g);
+    uint32_t jg[ND];                          // (j*g) of my columns
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) jgs[c] = (lane * CPL + c + 1) * g * 65536;
+    for (int q = 0; q < ND; ++q) {
+        const int j0 = lane * CPL + 2 * q + 1;
+        jg[q] = ((uint32_t)(j0 * g) & 0xFFFFu) | ((uint32_t)((j0 + 1) * g) << 16);
+    }
+    uint32_t vmask[ND];                       // 0xFFFF per half whose column exists
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+        const uint32_t i0 = lane * CPL + 2 * q;
+        vmask[q] = (i0 < len ? 0xFFFFu : 0u) | (i0 + 1 < len ? 0xFFFF0000u : 0u);
+    }
 
-    uint8_t* dirp = a.dir + (uint64_t)job * a.dir_stride;
-    uint8_t* dir0p = a.dir0 + (uint64_t)job * a.NC;
-    uint32_t* spillp = a.spill + (uint64_t)job * VC_SPILLCAP * (ND * 64 + 1);
+    uint32_t* hrow0 = a.hmat + (uint64_t)job * a.hstride;
+    int16_t* c0p_out = a.c0 + (uint64_t)job * a.NC;
 
     // end-cell tracking
-    int best = nw ? VC_INT_MIN : 0;          // NW: uniform; SW: per lane, tagged with (CPL-1-c)
+    int best = nw ? VC_INT_MIN : 0;          // NW: uniform; SW: per lane
     uint32_t best_row = 0, ntie = 0;
     const uint32_t lane_e = (len - 1) / CPL, c_e = (len - 1) % CPL;
-    uint32_t spill_cnt = 0, far_reads = 0;
-    int bad = 0;
+    uint32_t far_reads = 0;
 
-    int Hprev[CPL];                          // row i-1 (H<<16), column-0 value alongside
+    uint32_t Hprev[ND];
     int c0prev = 0;
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) Hprev[c] = 0;
+    for (int q = 0; q < ND; ++q) Hprev[q] = 0;
 
     uint4 myrec = make_uint4(0, 0, 0, 0);
     for (uint32_t i = 1; i <= nrows; ++i) {
@@ -679,15 +705,27 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
         const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
         const uint32_t x = r0 & 0xFF, fl = (r0 >> 8) & 0xFF, np = (r0 >> 16) & 0xFF;
 
-        int prof[CPL];
+        uint32_t prof[ND];
+        if (x == 'A') {
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) prof[c] = (((sb[c / 4] >> (8 * (c % 4))) & 0xFF) == x) ? ms : nsc;
+            for (int q = 0; q < ND; ++q) prof[q] = pfA[q];
+        } else if (x == 'C') {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) prof[q] = pfC[q];
+        } else if (x == 'G') {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) prof[q] = pfG[q];
+        } else if (x == 'T') {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) prof[q] = pfT[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < ND; ++q)
+                prof[q] = ((uint32_t)(((sbp[q] & 0xFFFFu) == x) ? m : n) & 0xFFFFu) | ((uint32_t)(((sbp[q] >> 16) == x) ? m : n) << 16);
+        }
 
-        int bm[CPL];
+        uint32_t bm[ND];
         int b0 = VC_INT_MIN;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) bm[c] = VC_INT_MIN;
-
         for (uint32_t p = 0; p < np; ++p) {
             uint32_t delta;
             if (fl & VC_RF_OVF) {
@@ -697,64 +735,53 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
                 delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
             }
             const uint32_t pr = i - delta;
-            const uint32_t payload = delta <= VC_PAYLOAD_NEAR ? delta - 1 : (p < 16 ? VC_PAYLOAD_NEAR + p : 63u);
-            const int tagv = (int)((2u << 14) | ((63u - p) << 8) | payload);     // vertical
-            const int tagd = tagv | (1 << 14);                                   // diagonal (kind 3)
-            int hp[CPL];
+            uint32_t hp[ND];
             int c0p;
             if (delta == 1 && i > 1) {
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) hp[c] = Hprev[c];
+                for (int q = 0; q < ND; ++q) hp[q] = Hprev[q];
                 c0p = c0prev;
             } else if (pr == 0) {
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) hp[c] = nw ? jgs[c] : 0;           // H[0][j] = j*g (NW) / 0 (SW)
+                for (int q = 0; q < ND; ++q) hp[q] = nw ? jg[q] : 0u;            // H[0][j] = j*g (NW) / 0 (SW)
                 c0p = 0;
+            } else if (delta <= (uint32_t)RING) {
+                const uint32_t rs = pr % RING;
+#pragma unroll
+                for (int q = 0; q < ND; ++q) hp[q] = ring[rs][q][lane];
+                c0p = ring_c0[rs];
             } else {
-                uint32_t pc[ND];
-                if (delta <= (uint32_t)RING) {
-                    const uint32_t rs = pr % RING;
+                const uint32_t* hr = hrow0 + (uint64_t)(pr - 1) * (ND * 64);      // my own earlier stores
 #pragma unroll
-                    for (int q = 0; q < ND; ++q) pc[q] = ring[rs][q][lane];
-                    c0p = ring_c0[rs];
-                } else {
-                    const uint32_t ss = a.dp.spill_slot[nb + pr - 1];
-                    const uint32_t* sp = spillp + (uint64_t)ss * (ND * 64 + 1);
-#pragma unroll
-                    for (int q = 0; q < ND; ++q) pc[q] = sp[q * 64 + lane];
-                    c0p = (int)sp[ND * 64];
-                    far_reads++;
-                }
-#pragma unroll
-                for (int q = 0; q < ND; ++q) {
-                    hp[2 * q + 0] = (int)(pc[q] << 16);
-                    hp[2 * q + 1] = (int)(pc[q] & 0xFFFF0000u);
-                }
+                for (int q = 0; q < ND; ++q) hp[q] = hr[q * 64 + lane];
+                c0p = (int)__builtin_amdgcn_readfirstlane((int)c0p_out[pr - 1]);
+                far_reads++;
             }
-            // left neighbour of my first column: lane-1's last cell, lane 0 takes the pred's column 0
-            const int hl = VC_DPP_SHR(hp[CPL - 1], c0p, 0x138, 0xF);
-            const int gt = gs + tagv;
+            // cell j-1 for each of my cells: shift the row right by one int16; the hole is filled by the
+            // left lane's last cell, lane 0 takes the predecessor's column 0
+            const uint32_t left = (uint32_t)VC_DPP_SHR((int)hp[ND - 1], (int)((uint32_t)c0p << 16), 0x138, 0xF);
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int dsrc = c == 0 ? hl : hp[c - 1];
-                bm[c] = max(bm[c], max(dsrc + prof[c] + tagd, hp[c] + gt));
+            for (int q = 0; q < ND; ++q) {
+                const uint32_t sh = __builtin_amdgcn_alignbit(hp[q], q == 0 ? left : hp[q - 1], 16);
+                const uint32_t cand = pk_max(pk_add(sh, prof[q]), pk_add(hp[q], gg));
+                bm[q] = p == 0 ? cand : pk_max(bm[q], cand);
             }
-            b0 = max(b0, c0p + gt);
+            b0 = max(b0, c0p + g);
         }
 
         // column 0: NW max over predecessors (Initialize, sisd :210-222); SW 0
-        const int col0 = nw ? (int)((uint32_t)b0 & 0xFFFF0000u) : 0;
+        const int col0 = nw ? b0 : 0;
         // horizontal pass H[j] = max(H[j], H[j-1]+g) as a prefix max of H[j] - j*g  (sisd :347-349)
-        int P[CPL];
+        uint32_t P[ND];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            int mx = (int)((uint32_t)bm[c] & 0xFFFF0000u);
-            if (!nw) mx = max(mx, 0);
-            P[c] = mx - jgs[c];
+        for (int q = 0; q < ND; ++q) {
+            uint32_t mx = bm[q];
+            if (!nw) mx = pk_max(mx, 0u);
+            P[q] = pk_max_hi_with_lo(pk_sub(mx, jg[q]));
         }
 #pragma unroll
-        for (int c = 1; c < CPL; ++c) P[c] = max(P[c], P[c - 1]);
-        int sc = P[CPL - 1];
+        for (int q = 1; q < ND; ++q) P[q] = pk_max_bcast_hi(P[q], P[q - 1]);
+        int sc = pk_hi(P[ND - 1]);
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x111, 0xF));
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x112, 0xF));
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x114, 0xF));
@@ -762,42 +789,19 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x142, 0xA));
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x143, 0xC));
         int carry = VC_DPP_SHR(sc, VC_INT_MIN, 0x138, 0xF);
-        carry = max(carry, col0);
-        int H[CPL];
+        carry = max(carry, col0);                     // column 0 enters as A[0] = H[i][0] - 0*g
+        const uint32_t cc = pk_dup(carry);
+        uint32_t H[ND];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) H[c] = max(P[c], carry) + jgs[c];
-
-        // direction codes: the winner's tag, unless the horizontal pass (or the SW floor) beat it
-        uint32_t dcode[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            uint32_t dwv = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int c = 4 * q + t;
-                if (c < CPL) {
-                    const uint32_t tg = (uint32_t)bm[c];
-                    uint32_t code = ((tg >> 8) & 0xC0u) | (tg & 0x3Fu);
-                    code = ((uint32_t)H[c] != (tg & 0xFFFF0000u)) ? (VC_K_HORZ << 6) : code;
-                    if (!nw) code = H[c] == 0 ? (VC_K_STOP << 6) : code;
-                    dwv |= code << (8 * t);
-                }
-            }
-            dcode[q] = dwv;
-        }
-        {
-            uint32_t* drow = (uint32_t*)(dirp + (uint64_t)(i - 1) * (256 * NQ));
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) drow[q * 64 + lane] = dcode[q];
-            if (lane == 0) dir0p[i - 1] = nw ? (uint8_t)((VC_K_VERT << 6) | ((uint32_t)b0 & 63u)) : (uint8_t)(VC_K_STOP << 6);
-        }
+        for (int q = 0; q < ND; ++q) H[q] = pk_add(pk_max(P[q], cc), jg[q]);
 
         // end cell
         if (nw) {
             if (fl & VC_RF_SINK) {                           // sisd :353-355
-                int v = H[0];
+                uint32_t hv = H[0];
 #pragma unroll
-                for (int c = 1; c < CPL; ++c) v = (c_e == (uint32_t)c) ? H[c] : v;
+                for (int q = 1; q < ND; ++q) hv = (c_e / 2 == (uint32_t)q) ? H[q] : hv;
+                int v = (c_e & 1) ? pk_hi(hv) : pk_lo(hv);
                 v = __builtin_amdgcn_readlane(v, lane_e);
                 if (v > best) {
                     best = v; best_row = i; ntie = 1;
@@ -807,47 +811,34 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
                     ntie++;
                 }
             }
-        } else {                                             // sisd :350-352
-            int rm = 0;
+        } else {                                             // sisd :350-352 (first row with the best score)
+            uint32_t rmx = H[0] & vmask[0];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const bool in = (uint32_t)(lane * CPL + c) < len;
-                const int t = in ? (H[c] | (CPL - 1 - c)) : 0;
-                rm = max(rm, t);
-            }
-            if ((int)((uint32_t)rm & 0xFFFF0000u) > (int)((uint32_t)best & 0xFFFF0000u)) { best = rm; best_row = i; }
+            for (int q = 1; q < ND; ++q) rmx = pk_max(rmx, H[q] & vmask[q]);
+            const int rm = max(pk_lo(rmx), pk_hi(rmx));
+            if (rm > best) { best = rm; best_row = i; }
         }
 
-        // keep the row: registers, LDS ring, and HBM when a successor is more than RING rows away
+        // keep the row: registers, LDS ring, HBM
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) Hprev[c] = H[c];
+        for (int q = 0; q < ND; ++q) Hprev[q] = H[q];
         c0prev = col0;
-        uint32_t pk[ND];
-#pragma unroll
-        for (int q = 0; q < ND; ++q) pk[q] = __builtin_amdgcn_perm((uint32_t)H[2 * q + 1], (uint32_t)H[2 * q + 0], 0x07060302u);
         const uint32_t ws = i % RING;
         // one wave per workgroup: LDS operations of a wave retire in order, so no s_barrier (and no
-        // vmcnt(0) drain of the direction stores) is needed -- only keep the compiler from reordering
+        // vmcnt(0) drain of the H stores) is needed -- only keep the compiler from reordering
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < ND; ++q) ring[ws][q][lane] = pk[q];
-        if (lane == 0) ring_c0[ws] = col0;
-        if (fl & VC_RF_SPILL) {
-            if (spill_cnt < VC_SPILLCAP) {
-                uint32_t* sp = spillp + (uint64_t)spill_cnt * (ND * 64 + 1);
+        for (int q = 0; q < ND; ++q) ring[ws][q][lane] = H[q];
+        if (lane == 0) { ring_c0[ws] = col0; c0p_out[i - 1] = (int16_t)col0; }
+        {
+            uint32_t* hr = hrow0 + (uint64_t)(i - 1) * (ND * 64);
 #pragma unroll
-                for (int q = 0; q < ND; ++q) sp[q * 64 + lane] = pk[q];
-                if (lane == 0) sp[ND * 64] = (uint32_t)col0;
-            } else bad = 1;
-            spill_cnt++;
-            __threadfence_block();
+            for (int q = 0; q < ND; ++q) hr[q * 64 + lane] = H[q];
         }
+        if (fl & VC_RF_SPILL) __threadfence_block();          // a far successor will load this row back
         __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0 && (spill_cnt | far_reads)) {
-        atomicAdd(a.stat + 2, (unsigned long long)spill_cnt);
-        atomicAdd(a.stat + 3, (unsigned long long)far_reads);
-    }
+    if (lane == 0 && far_reads) atomicAdd(a.stat + 3, (unsigned long long)far_reads);
 
     // publish the end cell
     uint32_t end = 0;
@@ -858,31 +849,41 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
             else if (lane == 0) a.tie_cnt[job] = (uint8_t)ntie;
         }
     } else {
-        const int bval = (int)((uint32_t)best & 0xFFFF0000u);
-        const int gmax = wave_max_i32(bval);
+        const int gmax = wave_max_i32(best);
         if (gmax > 0) {
-            const uint32_t rowc = (bval == gmax) ? best_row : 0xFFFFFFFFu;
+            const uint32_t rowc = (best == gmax) ? best_row : 0xFFFFFFFFu;
             const uint32_t rstar = wave_min_u32(rowc);
-            const unsigned long long msk = __ballot(bval == gmax && best_row == rstar);
-            const int lstar = __ffsll((long long)msk) - 1;
-            const uint32_t cstar = (CPL - 1) - ((uint32_t)__builtin_amdgcn_readlane(best, lstar) & 0xFFFFu);
-            end = (rstar << 16) | (uint32_t)(lstar * CPL + cstar + 1);
+            // first column of that row holding the best score: re-read my part of the row
+            __threadfence_block();
+            const uint32_t* hr = hrow0 + (uint64_t)(rstar - 1) * (ND * 64);
+            uint32_t firstc = 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = ND - 1; q >= 0; --q) {
+                const uint32_t hv = hr[q * 64 + lane];
+                const uint32_t c1 = lane * CPL + 2 * q + 1, c0i = c1 - 1;
+                if (c1 < len && pk_hi(hv) == gmax) firstc = c1;
+                if (c0i < len && pk_lo(hv) == gmax) firstc = c0i;
+            }
+            const uint32_t cstar = wave_min_u32(firstc);
+            end = (rstar << 16) | (cstar + 1);
         }
     }
-    if (bad) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 4, spill_cnt); }
     if (lane == 0) a.job_end[job] = end;
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_trace: backtrack (sisd_alignment_engine.cpp:362-459), one alignment per thread.  Pairs are
-// emitted tail-first as (row << 16) | column, 0 meaning "-1"; consumers read them back to front.
+// k_trace: backtrack, one alignment per thread, straight from H like sisd_alignment_engine.cpp:362-459:
+// diagonal over the in-edges in list order, then vertical over the in-edges in list order, then
+// horizontal.  Pairs are emitted tail-first as (row << 16) | column, 0 meaning "-1"; consumers read
+// them back to front.
 // ------------------------------------------------------------------------------------------------
 struct VcTraceArgs {
     VcBatchDev b;
     VcDp dp;
     uint32_t w0, nslots, NC, EC, group, cpl;
-    const uint8_t* dir; uint64_t dir_stride;
-    const uint8_t* dir0;
+    int m, n, g, sm, sn, sg;
+    const uint32_t* hmat; uint64_t hstride;
+    const int16_t* c0;
     const uint32_t* job_end;
     const uint8_t* job_type;
     uint32_t* pairs;          // [pair_jobs * PC]
@@ -892,19 +893,10 @@ struct VcTraceArgs {
     uint32_t k0;
 };
 
-__device__ __forceinline__ uint32_t vc_pred_row(const VcDp& dp, uint64_t nb, uint64_t eb, uint32_t i, uint32_t payload) {
-    if (payload < VC_PAYLOAD_NEAR) return i - (payload + 1);
-    const uint32_t p = payload - VC_PAYLOAD_NEAR;
-    const uint4 rec = dp.rec[nb + i - 1];
-    uint32_t delta;
-    if ((rec.x >> 8) & VC_RF_OVF) delta = dp.ovf[eb + rec.y + p];
-    else {
-        uint32_t wsel = p < 2 ? rec.y : (p < 4 ? rec.z : rec.w);
-        delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
-    }
-    return i - delta;
-}
-
+// One alignment per THREAD: the walk is a chain of dependent lookups, so the instruction cost is shared
+// by 64 alignments per wave and the kernel is a latency chain that overlaps the forward kernel of another
+// stream (wave-per-alignment and LDS-tiled variants were measured slower end to end: they take issue
+// slots and CUs away from k_fwd).  Loads stop at the first matching move, like the reference's scan.
 __global__ void k_trace(VcTraceArgs a) {
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     if (job >= a.nslots * a.group) return;
@@ -918,37 +910,63 @@ __global__ void k_trace(VcTraceArgs a) {
     const uint32_t end = a.job_end[job];
     uint32_t i = end >> 16, j = end & 0xFFFF;
     const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
-    const uint8_t* dirp = a.dir + (uint64_t)job * a.dir_stride;
-    const uint8_t* dir0p = a.dir0 + (uint64_t)job * a.NC;
-    const uint32_t rowb = 256 * ((a.cpl + 3) / 4);
-    uint32_t n = 0;
-    bool ovf = false;
+    const bool nw = type == 1;
+    const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
+    const uint64_t so = a.b.seq_off[a.b.win_seq_off[w] + k];
+    const uint16_t* hm = (const uint16_t*)(a.hmat + (uint64_t)job * a.hstride);
+    const int16_t* c0 = a.c0 + (uint64_t)job * a.NC;
+    const uint32_t nd = a.cpl / 2, cpl = a.cpl;
+    auto Hat = [&](uint32_t r, uint32_t col) -> int {     // H[r][col] incl. the virtual row 0 / column 0
+        if (r == 0) return nw ? (int)col * g : 0;
+        if (col == 0) return nw ? (int)c0[r - 1] : 0;
+        const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
+        return (int)(short)hm[((uint64_t)(r - 1) * nd * 64 + (cc >> 1) * 64 + lc) * 2 + (cc & 1)];
+    };
+    uint32_t nout = 0;
+    bool ovf = false, broken = false;
     if (end != 0) {
+        int Hij = Hat(i, j);
         for (;;) {
-            if (type == 1) { if (i == 0 && j == 0) break; }
-            else           { if (i == 0 || j == 0) break; }
-            uint32_t pi_, pj_;
-            if (i == 0) { pi_ = 0; pj_ = j - 1; }                        // row 0: only the horizontal move matches
-            else {
-                uint32_t code;
-                if (j == 0) code = dir0p[i - 1];
-                else {
-                    const uint32_t ci = j - 1, lc = ci / a.cpl, c = ci % a.cpl;
-                    code = dirp[(uint64_t)(i - 1) * rowb + ((c >> 2) * 64 + lc) * 4 + (c & 3)];
+            if (nw) { if (i == 0 && j == 0) break; }
+            else if (Hij == 0) break;
+            uint32_t pi_ = 0, pj_ = 0;
+            int hv = 0;
+            bool found = false;
+            if (i != 0) {
+                const uint4 rec = a.dp.rec[nb + i - 1];
+                const uint32_t np = (rec.x >> 16) & 0xFF;
+                const bool isovf = ((rec.x >> 8) & VC_RF_OVF) != 0;
+                auto delta_of = [&](uint32_t p) -> uint32_t {
+                    if (isovf) return a.dp.ovf[eb + rec.y + p];
+                    const uint32_t wsel = p < 2 ? rec.y : (p < 4 ? rec.z : rec.w);
+                    return (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
+                };
+                if (j != 0) {
+                    const int sc = (a.b.bases[so + j - 1] == (rec.x & 0xFF)) ? m : n;
+                    for (uint32_t p = 0; p < np; ++p) {
+                        const uint32_t pr = i - delta_of(p);
+                        const int v = Hat(pr, j - 1);
+                        if (Hij == v + sc) { pi_ = pr; pj_ = j - 1; hv = v; found = true; break; }
+                    }
                 }
-                const uint32_t kind = code >> 6, payload = code & 63;
-                if (kind == VC_K_STOP) break;
-                if (kind == VC_K_DIAG)      { pi_ = vc_pred_row(a.dp, nb, eb, i, payload); pj_ = j - 1; }
-                else if (kind == VC_K_VERT) { pi_ = vc_pred_row(a.dp, nb, eb, i, payload); pj_ = j; }
-                else                        { pi_ = i; pj_ = j - 1; }
+                if (!found) {
+                    for (uint32_t p = 0; p < np; ++p) {
+                        const uint32_t pr = i - delta_of(p);
+                        const int v = Hat(pr, j);
+                        if (Hij == v + g) { pi_ = pr; pj_ = j; hv = v; found = true; break; }
+                    }
+                }
             }
-            if (n >= a.PC) { ovf = true; break; }
-            out[n++] = ((i == pi_ ? 0u : i) << 16) | (j == pj_ ? 0u : j);
-            i = pi_; j = pj_;
+            if (!found && j != 0) { const int v = Hat(i, j - 1); if (Hij == v + g) { pi_ = i; pj_ = j - 1; hv = v; found = true; } }
+            if (!found) { broken = true; break; }
+            if (nout >= a.PC) { ovf = true; break; }
+            out[nout++] = ((i == pi_ ? 0u : i) << 16) | (j == pj_ ? 0u : j);
+            i = pi_; j = pj_; Hij = hv;
         }
     }
-    if (ovf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, n); n = 0; }
-    a.npairs[pj] = n;
+    if (broken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, i); nout = 0; }
+    if (ovf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, nout); nout = 0; }
+    a.npairs[pj] = nout;
 }
 
 // ------------------------------------------------------------------------------------------------
