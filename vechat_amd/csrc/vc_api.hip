@@ -280,7 +280,7 @@ struct Plan {
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
-        { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, wk.stream, ta); }
+        { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
         aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC;
@@ -326,7 +326,7 @@ struct Plan {
             if (rc) return rc;
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
-            { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns * gsz + 63) / 64), dim3(64), 0, wk.stream, ta); }
+            { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         }
         VcAddwArgs wa{};
         wa.b = c->b; wa.g = wk.gr[wk.cur]; wa.dp = wk.dp; wa.w0 = wk.w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
@@ -345,7 +345,7 @@ struct Plan {
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
-        { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + 63) / 64), dim3(64), 0, wk.stream, ta); }
+        { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcFinishArgs fn{};
         fn.b = c->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;
         fn.pairs = wk.d_pairs; fn.npairs = wk.d_npairs; fn.PC = PC;

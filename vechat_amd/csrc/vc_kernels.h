@@ -523,6 +523,95 @@ __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp
     const int lane = vc_lane();
     const uint32_t N = g.n_nodes[slot], E = g.n_edges[slot];
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
+
+    // ---- shortcut that settles most ties without the DFS.  The reference's DFS takes roots in id order
+    // and, from a root, reaches everything upstream of it through in-edges and aligned links; an aligned
+    // group is emitted as a block [leader, leader's aligned list] the first time any member is reached.
+    // Hence group A precedes group B if the smallest id that can reach A (forward closure of A over
+    // out-edges and aligned links, F(A)) is smaller than that of B; and when min F(A) is itself a member
+    // of A, that member is a root and therefore A's leader.  Anything else falls through to the DFS.
+    {
+        uint32_t* s_vis = (uint32_t*)smem;                        // bitmap [N]
+        uint16_t* s_stk = (uint16_t*)(smem + 4 * ((NC + 31) / 32 + 1));   // [256]
+        __shared__ uint32_t s_fast;                                // winning row, 0 = undecided
+        for (uint32_t i = lane; i < (N + 31) / 32; i += 64) s_vis[i] = 0;
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t row[VC_MAXTIE], node[VC_MAXTIE], gid[VC_MAXTIE], rmin[VC_MAXTIE];
+            bool lead[VC_MAXTIE];
+            bool ok = true;
+            for (uint32_t k = 0; k < nt; ++k) {
+                row[k] = tie_rows[(uint64_t)slot * VC_MAXTIE + k];
+                node[k] = dp.rank2node[nb + row[k] - 1];
+                uint32_t gm = node[k];
+                const uint32_t cnt = g.al_cnt[nb + node[k]];
+                for (uint32_t t2 = 0; t2 < cnt; ++t2) gm = min(gm, (uint32_t)g.al[(nb + node[k]) * VC_MAXALN + t2]);
+                gid[k] = gm; rmin[k] = 0xFFFFFFFFu; lead[k] = false;
+            }
+            for (uint32_t k = 0; k < nt && ok; ++k) {
+                bool seen = false;
+                for (uint32_t q = 0; q < k; ++q) if (gid[q] == gid[k]) { rmin[k] = rmin[q]; lead[k] = lead[q]; seen = true; break; }
+                if (seen) continue;
+                // forward closure of the group
+                uint32_t sp = 0, visited = 0, mn = 0xFFFFFFFFu;
+                auto push = [&](uint32_t v) {
+                    if (s_vis[v >> 5] & (1u << (v & 31))) return;
+                    s_vis[v >> 5] |= 1u << (v & 31);
+                    if (sp < 256) s_stk[sp++] = (uint16_t)v; else ok = false;
+                };
+                push(node[k]);
+                while (sp && ok) {
+                    const uint32_t v = s_stk[--sp];
+                    mn = min(mn, v);
+                    if (++visited > 512) { ok = false; break; }
+                    for (uint32_t e = g.out_first[nb + v]; e != VC_NONE16; ) {
+                        const uint32_t hn = g.e_hn[eb + e];
+                        push(hn & 0xFFFF);
+                        e = hn >> 16;
+                    }
+                    const uint32_t cnt = g.al_cnt[nb + v];
+                    for (uint32_t t2 = 0; t2 < cnt; ++t2) push(g.al[(nb + v) * VC_MAXALN + t2]);
+                }
+                rmin[k] = mn;
+                // is the smallest id a member of the group?
+                bool member = mn == node[k];
+                const uint32_t cnt = g.al_cnt[nb + node[k]];
+                for (uint32_t t2 = 0; t2 < cnt; ++t2) member = member || mn == g.al[(nb + node[k]) * VC_MAXALN + t2];
+                lead[k] = member;
+                // groups are disjoint and closures of different tied groups must not share the bitmap
+                for (uint32_t i2 = 0; i2 < (N + 31) / 32; ++i2) s_vis[i2] = 0;
+            }
+            uint32_t win = 0;
+            if (ok) {
+                uint32_t best = 0xFFFFFFFFu, bestg = 0xFFFFFFFFu;
+                bool amb = false;
+                for (uint32_t k = 0; k < nt; ++k) {
+                    if (rmin[k] < best) { best = rmin[k]; bestg = gid[k]; amb = false; }
+                    else if (rmin[k] == best && gid[k] != bestg) amb = true;
+                }
+                if (!amb) {
+                    uint32_t cnt_in = 0, only = 0;
+                    bool ld = false;
+                    for (uint32_t k = 0; k < nt; ++k) if (gid[k] == bestg) { cnt_in++; only = k; ld = lead[k]; }
+                    if (cnt_in == 1) win = row[only];
+                    else if (ld) {
+                        const uint32_t L = best;                     // the leader
+                        for (uint32_t k = 0; k < nt && !win; ++k) if (gid[k] == bestg && node[k] == L) win = row[k];
+                        const uint32_t cnt = g.al_cnt[nb + L];
+                        for (uint32_t t2 = 0; t2 < cnt && !win; ++t2) {
+                            const uint32_t mnode = g.al[(nb + L) * VC_MAXALN + t2];
+                            for (uint32_t k = 0; k < nt; ++k) if (gid[k] == bestg && node[k] == mnode) { win = row[k]; break; }
+                        }
+                    }
+                }
+            }
+            s_fast = win;
+            if (win) job_end[slot] = (win << 16) | (job_end[slot] & 0xFFFF);
+        }
+        __syncthreads();
+        if (s_fast) return;
+    }
+
     const VcTopoLds t = vc_topo_carve(smem, NC, EC, STK);
     vc_topo_load(g, nb, eb, N, E, t, lane);
     __syncthreads();
@@ -692,12 +781,15 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
 #pragma unroll
     for (int q = 0; q < ND; ++q) Hprev[q] = 0;
 
-    uint4 myrec = make_uint4(0, 0, 0, 0);
+    // row records: lane t holds the record of row (block*64 + t); the next block is fetched a block ahead
+    uint4 myrec = make_uint4(0, 0, 0, 0), nextrec = make_uint4(0, 0, 0, 0);
+    if ((uint32_t)lane < nrows) nextrec = a.dp.rec[nb + lane];
     for (uint32_t i = 1; i <= nrows; ++i) {
         const uint32_t ri = (i - 1) & 63;
         if (ri == 0) {
-            uint32_t r = i - 1 + lane;
-            if (r < nrows) myrec = a.dp.rec[nb + r];
+            myrec = nextrec;
+            const uint32_t r = i - 1 + 64 + lane;
+            if (r < nrows) nextrec = a.dp.rec[nb + r];
         }
         const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
         const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
@@ -726,7 +818,9 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
 
         uint32_t bm[ND];
         int b0 = VC_INT_MIN;
-        for (uint32_t p = 0; p < np; ++p) {
+        // fetch of predecessor p's row: previous row from registers, virtual row 0 analytically, a recent
+        // row from the LDS ring, an older one back from the H matrix in HBM
+        auto fetch = [&](uint32_t p, uint32_t (&hp)[ND], int& c0p) {
             uint32_t delta;
             if (fl & VC_RF_OVF) {
                 delta = a.dp.ovf[(uint64_t)slot * a.EC + r1 + p];
@@ -735,8 +829,6 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
                 delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
             }
             const uint32_t pr = i - delta;
-            uint32_t hp[ND];
-            int c0p;
             if (delta == 1 && i > 1) {
 #pragma unroll
                 for (int q = 0; q < ND; ++q) hp[q] = Hprev[q];
@@ -757,6 +849,8 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
                 c0p = (int)__builtin_amdgcn_readfirstlane((int)c0p_out[pr - 1]);
                 far_reads++;
             }
+        };
+        auto relax = [&](uint32_t p, const uint32_t (&hp)[ND], int c0p) {
             // cell j-1 for each of my cells: shift the row right by one int16; the hole is filled by the
             // left lane's last cell, lane 0 takes the predecessor's column 0
             const uint32_t left = (uint32_t)VC_DPP_SHR((int)hp[ND - 1], (int)((uint32_t)c0p << 16), 0x138, 0xF);
@@ -767,6 +861,20 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
                 bm[q] = p == 0 ? cand : pk_max(bm[q], cand);
             }
             b0 = max(b0, c0p + g);
+        };
+        {
+            // two buffers: the next predecessor's row is in flight while the current one is relaxed
+            uint32_t hA[ND], hB[ND];
+            int cA = 0, cB = 0;
+            fetch(0, hA, cA);
+            for (uint32_t p = 0;;) {
+                if (p + 1 < np) fetch(p + 1, hB, cB);
+                relax(p, hA, cA);
+                if (++p >= np) break;
+                if (p + 1 < np) fetch(p + 1, hA, cA);
+                relax(p, hB, cB);
+                if (++p >= np) break;
+            }
         }
 
         // column 0: NW max over predecessors (Initialize, sisd :210-222); SW 0
@@ -897,8 +1005,10 @@ struct VcTraceArgs {
 // by 64 alignments per wave and the kernel is a latency chain that overlaps the forward kernel of another
 // stream (wave-per-alignment and LDS-tiled variants were measured slower end to end: they take issue
 // slots and CUs away from k_fwd).  Loads stop at the first matching move, like the reference's scan.
+#define VC_TRACE_LANES 8     // alignments per wave: lanes walk in lockstep, so fewer per wave = less waiting on the slowest
 __global__ void k_trace(VcTraceArgs a) {
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x >= VC_TRACE_LANES) return;
+    const uint32_t job = blockIdx.x * VC_TRACE_LANES + threadIdx.x;
     if (job >= a.nslots * a.group) return;
     const uint32_t slot = job / a.group, k = a.k0 + job % a.group;
     const uint32_t w = a.w0 + slot;
@@ -924,16 +1034,18 @@ __global__ void k_trace(VcTraceArgs a) {
     };
     uint32_t nout = 0;
     bool ovf = false, broken = false;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
     if (end != 0) {
         int Hij = Hat(i, j);
+        uint4 rec = i ? a.dp.rec[nb + i - 1] : zero4;
         for (;;) {
             if (nw) { if (i == 0 && j == 0) break; }
             else if (Hij == 0) break;
             uint32_t pi_ = 0, pj_ = 0;
             int hv = 0;
-            bool found = false;
+            uint4 nrec = zero4;
+            bool found = false, have_nrec = false;
             if (i != 0) {
-                const uint4 rec = a.dp.rec[nb + i - 1];
                 const uint32_t np = (rec.x >> 16) & 0xFF;
                 const bool isovf = ((rec.x >> 8) & VC_RF_OVF) != 0;
                 auto delta_of = [&](uint32_t p) -> uint32_t {
@@ -942,11 +1054,22 @@ __global__ void k_trace(VcTraceArgs a) {
                     return (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
                 };
                 if (j != 0) {
-                    const int sc = (a.b.bases[so + j - 1] == (rec.x & 0xFF)) ? m : n;
-                    for (uint32_t p = 0; p < np; ++p) {
+                    // by far the most frequent move is the diagonal through the first in-edge: issue its
+                    // three loads (cell, base, next row's record) together -- one round trip per step
+                    const uint32_t pr0 = i - (isovf ? delta_of(0) : (rec.y & 0xFFFF));
+                    // unconditional, branch-free addresses so the three loads are in flight together
+                    const uint32_t rr = pr0 ? pr0 : 1, cc1 = j > 1 ? j - 2 : 0, lc = cc1 / cpl, cw = cc1 % cpl;
+                    const int v0raw = (int)(short)hm[((uint64_t)(rr - 1) * nd * 64 + (cw >> 1) * 64 + lc) * 2 + (cw & 1)];
+                    const uint32_t bs = a.b.bases[so + j - 1];
+                    const uint4 q0 = a.dp.rec[nb + rr - 1];
+                    int v0 = v0raw;
+                    if (pr0 == 0 || j == 1) v0 = Hat(pr0, j - 1);
+                    const int sc = (bs == (rec.x & 0xFF)) ? m : n;
+                    if (Hij == v0 + sc) { pi_ = pr0; pj_ = j - 1; hv = v0; nrec = pr0 ? q0 : zero4; have_nrec = true; found = true; }
+                    for (uint32_t p = 1; p < np && !found; ++p) {
                         const uint32_t pr = i - delta_of(p);
                         const int v = Hat(pr, j - 1);
-                        if (Hij == v + sc) { pi_ = pr; pj_ = j - 1; hv = v; found = true; break; }
+                        if (Hij == v + sc) { pi_ = pr; pj_ = j - 1; hv = v; found = true; }
                     }
                 }
                 if (!found) {
@@ -957,11 +1080,15 @@ __global__ void k_trace(VcTraceArgs a) {
                     }
                 }
             }
-            if (!found && j != 0) { const int v = Hat(i, j - 1); if (Hij == v + g) { pi_ = i; pj_ = j - 1; hv = v; found = true; } }
+            if (!found && j != 0) {
+                const int v = Hat(i, j - 1);
+                if (Hij == v + g) { pi_ = i; pj_ = j - 1; hv = v; nrec = rec; have_nrec = true; found = true; }
+            }
             if (!found) { broken = true; break; }
             if (nout >= a.PC) { ovf = true; break; }
             out[nout++] = ((i == pi_ ? 0u : i) << 16) | (j == pj_ ? 0u : j);
-            i = pi_; j = pj_; Hij = hv;
+            if (!have_nrec) nrec = pi_ ? a.dp.rec[nb + pi_ - 1] : zero4;
+            i = pi_; j = pj_; Hij = hv; rec = nrec;
         }
     }
     if (broken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, i); nout = 0; }
