@@ -79,8 +79,8 @@ def test_ragged_batch_and_edge_windows(ctx):
 
 def test_result_is_independent_of_chunking(built):
     batch = capi.synth_batch(capi.synth_cfg(61, 150, 10, frac_partial=0.2), 0, 150)
-    a = HipContext(device=0, chunk_windows=64)
-    b = HipContext(device=0, chunk_windows=150)
+    a = HipContext(device=0, chunk_windows=64, n_streams=1)
+    b = HipContext(device=0, chunk_windows=150, n_streams=3)
     ca, sa = a.consensus(batch)
     cb, sb = b.consensus(batch)
     assert ca == cb and (sa == sb).all()
@@ -133,7 +133,7 @@ def test_full_size_config_b_properties(built):
     cons2, _ = c1.collect()
     assert hashlib.sha256(b"".join(hashlib.sha256(x).digest() for x in cons2)).hexdigest() == h1
     c1.close()
-    c2 = HipContext(device=0, chunk_windows=3000)
+    c2 = HipContext(device=0, chunk_windows=3000, n_streams=2)
     cons3, _ = c2.consensus(batch)
     assert hashlib.sha256(b"".join(hashlib.sha256(x).digest() for x in cons3)).hexdigest() == h1
     c2.close()

@@ -256,6 +256,7 @@ struct Plan {
             wk.nseq_max = std::max(wk.nseq_max, n);
             if (n >= 3) wk.layers = std::max(wk.layers, n - 1);
         }
+        (void)hipMemsetAsync(wk.dp.nrows, 0, (size_t)ns * 4, wk.stream);      // skipped windows must not carry a stale height
         { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3((ns + 63) / 64), dim3(64), 0, wk.stream, c->b, w0, ns); }
         { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), 0, wk.stream, c->b, wk.gr[0], w0, ns, NC, EC); }
     }
@@ -313,6 +314,7 @@ struct Plan {
         HIPCHK(c, hipStreamSynchronize(wk.stream));          // h_maxn
         uint32_t maxn = *wk.h_maxn;
         if (maxn == 0) maxn = 1;
+        if (maxn > NC) maxn = NC;
         const uint64_t stride = (uint64_t)maxn * rowd;
         uint32_t group = (uint32_t)std::min<uint64_t>(c->hmat_dwords / (stride * ns), c->group_max);
         if (group == 0) group = 1;
