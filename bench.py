@@ -77,10 +77,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=16384, help="windows per GPU per step")
+    ap.add_argument("--windows", type=int, default=32768, help="windows per GPU per step")
     ap.add_argument("--layers", type=int, default=64)
     ap.add_argument("--length", type=int, default=500)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
@@ -98,7 +99,7 @@ def main():
 
     cfg = capi.synth_cfg(1002, a.length, a.layers, profile=capi.PACBIO)
     batch = capi.synth_batch(cfg, rank * a.windows, a.windows)
-    ctx = HipContext(device=local, profile=1, chunk_windows=a.chunk)
+    ctx = HipContext(device=local, profile=1, chunk_windows=a.chunk, n_streams=a.streams)
     ctx.submit(batch)                                   # H2D: inputs resident before the timed region
 
     n = batch.n_windows
@@ -156,7 +157,7 @@ def main():
                                    f"FASTQ weights, haplotype mode d=0.2 s=0.2 k=3; {a.windows} windows per GPU per step "
                                    f"(stream of BASELINE config C)",
                        "windows_per_gpu_per_step": a.windows, "backbone_len": a.length, "reads_per_window": a.layers,
-                       "chunk_windows": s["chunk_windows"], "max_nodes": s["max_nodes"], "max_edges": s["max_edges"]},
+                       "chunk_windows": s["chunk_windows"], "streams": s["n_streams"], "max_nodes": s["max_nodes"], "max_edges": s["max_edges"]},
             "corrected_bases_per_s": bases * world / dt if world == 1 else bases / dt,
             "gcups": cells * world / dt / 1e9,
             "windows_not_ok": int((status > 1).sum()),

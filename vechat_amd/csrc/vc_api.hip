@@ -32,7 +32,7 @@ enum KClass { KC_AVG = 0, KC_INIT, KC_TOPO, KC_FWD, KC_TRACE, KC_ADDALN, KC_PRUN
 const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace", "k_addaln", "k_prune_lcc",
                                  "k_addw", "k_finish", "k_rows", "k_resolve"};
 
-constexpr int kRing = 12;     // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
+constexpr int kRing = 8;      // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
 constexpr int kMaxStreams = 4;
 
 uint32_t topo_lds_bytes(uint32_t NC, uint32_t EC, uint32_t STK) {
