@@ -29,12 +29,15 @@ def _check(ctx, batch, label=""):
     return st
 
 
-def test_golden_windows_through_the_c_abi(ctx):
+@pytest.mark.parametrize("mode,key", [(0, "hap"), (1, "linear")])
+def test_golden_windows_through_the_c_abi(built, mode, key):
     gold = fixtures.load_windows()
     batch = fixtures.fixture_batch(gold["windows"])
-    cons, status = ctx.consensus(batch)
+    c = HipContext(device=0, mode=mode)
+    cons, status = c.consensus(batch)
+    c.close()
     for w, win in enumerate(gold["windows"]):
-        exp = win["expected"]["hap"]
+        exp = win["expected"][key]
         assert cons[w].decode() == exp["consensus"], win["name"]
         assert (int(status[w]) == capi.VC_WIN_OK) == exp["polished"], win["name"]
         assert int(status[w]) in (capi.VC_WIN_OK, capi.VC_WIN_UNPOLISHED)
@@ -54,6 +57,20 @@ def test_parity_with_oracle_on_seeded_windows(ctx, seed, L, D, n, kw):
     batch = capi.synth_batch(capi.synth_cfg(seed, L, D, **kw), 0, n)
     st = _check(ctx, batch, f"seed{seed}")
     assert ctx.stats()["cells"] == st.cells                   # same DP work counted on both sides
+
+
+@pytest.mark.parametrize("seed,L,D,n,kw", [
+    (1002, 500, 64, 4, {}),
+    (23, 300, 25, 8, dict(frac_partial=0.3, fastq=0, backbone_fastq=0)),
+    (24, 200, 12, 8, dict(n_haplotypes=2, snp_rate=0.03)),
+])
+def test_racon_linear_overload_parity(built, seed, L, D, n, kw):
+    """Round 2 of the driver: Window::generate_consensus(engine, trim) (window.cpp:74-174)."""
+    batch = capi.synth_batch(capi.synth_cfg(seed, L, D, **kw), 0, n)
+    for trim in (1, 0):
+        c = HipContext(device=0, mode=1, trim=trim)
+        _check(c, batch, f"linear seed{seed} trim{trim}")
+        c.close()
 
 
 def test_prune_parameters_and_rounds(built):

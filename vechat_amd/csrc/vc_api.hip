@@ -28,9 +28,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum KClass { KC_AVG = 0, KC_INIT, KC_TOPO, KC_FWD, KC_TRACE, KC_ADDALN, KC_PRUNE, KC_ADDW, KC_FINISH, KC_ROWS, KC_RESOLVE, KC_N };
+enum KClass { KC_AVG = 0, KC_INIT, KC_TOPO, KC_FWD, KC_TRACE, KC_ADDALN, KC_PRUNE, KC_ADDW, KC_FINISH, KC_ROWS, KC_RESOLVE, KC_CONS, KC_N };
 const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace", "k_addaln", "k_prune_lcc",
-                                 "k_addw", "k_finish", "k_rows", "k_resolve"};
+                                 "k_addw", "k_finish", "k_rows", "k_resolve", "k_consensus"};
 
 constexpr int kRing = 8;      // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
 constexpr int kMaxStreams = 4;
@@ -142,6 +142,7 @@ int alloc_graph(vc_ctx* c, VcGraph* g) {
     if ((rc = dalloc(c, c->chunk_allocs, &g->e_w, CW * EC))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &g->ord, CW * NC))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &g->pos, CW * NC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->visits, CW * NC))) return rc;
     return VC_OK;
 }
 
@@ -227,7 +228,7 @@ uint32_t pick_cpl(uint32_t max_len) {
 // ---------------------------------------------------------------- one chunk, phase by phase
 struct Plan {
     vc_ctx* c;
-    uint32_t NC, EC, PC, cpl, topo_lds, prune_lds, add_lds, rows_lds;
+    uint32_t NC, EC, PC, cpl, topo_lds, prune_lds, add_lds, rows_lds, cons_lds;
     uint64_t rowd;          // dwords per H row
 
     VcFwdArgs fwd_args(const Work& wk) const {
@@ -337,6 +338,19 @@ struct Plan {
         return VC_OK;
     }
 
+    // racon-linear overload: exact rank of the finished graph, heaviest bundle, coverage trim (window.cpp:138-171)
+    int linear_tail(Work& wk) {
+        const uint32_t ns = wk.ns;
+        { Timer t(c, KC_TOPO, wk.stream);
+          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing); }
+        VcConsArgs ca{};
+        ca.b = c->b; ca.g = wk.gr[wk.cur]; ca.dp = wk.dp; ca.w0 = wk.w0; ca.nslots = ns; ca.NC = NC; ca.EC = EC;
+        ca.trim = c->prm.trim; ca.window_type = c->prm.window_type;
+        { Timer t(c, KC_CONS, wk.stream); hipLaunchKernelGGL(k_consensus, dim3(ns), dim3(64), cons_lds, wk.stream, ca); }
+        wk.active = false;
+        return VC_OK;
+    }
+
     // final local alignment of the backbone + corrected sequence (window.cpp:391-394)
     int finish(Work& wk) {
         const uint32_t ns = wk.ns;
@@ -372,7 +386,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
         return fail(nullptr, VC_ERR_NO_DEVICE, "no HIP device visible (%s); libvechat_hip has no CPU fallback",
                     e == hipSuccess ? "count 0" : hipGetErrorString(e));
     if (p->device < 0 || p->device >= ndev) return fail(nullptr, VC_ERR_ARG, "device %d out of range (%d visible)", p->device, ndev);
-    if (p->mode != 0) return fail(nullptr, VC_ERR_ARG, "mode %d not implemented on the device yet (haplotype overload only)", p->mode);
+    if (p->mode != 0 && p->mode != 1) return fail(nullptr, VC_ERR_ARG, "mode %d unknown (0 haplotype overload, 1 racon-linear overload)", p->mode);
     if (p->num_prune == 0) return fail(nullptr, VC_ERR_ARG, "num_prune must be >= 1");
     if (p->gap >= 0 || p->sw_gap >= 0) return fail(nullptr, VC_ERR_ARG, "gap penalties must be negative");
     hipDeviceProp_t prop;
@@ -509,7 +523,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint32_t cpl = pick_cpl(max_len);
     if (!cpl) return fail(c, VC_ERR_ARG, "sequence length %u exceeds the kernels' 2048-column envelope", max_len);
     const uint32_t lds_cap = 160 * 1024;
-    if (topo_lds_bytes(NC, EC, c->STK) > lds_cap || vc_prune_lds_bytes(NC, EC) > lds_cap)
+    if (topo_lds_bytes(NC, EC, c->STK) > lds_cap || vc_prune_lds_bytes(NC, EC) > lds_cap ||
+        (c->prm.mode == 1 && vc_cons_lds_bytes(NC, EC) > lds_cap))
         return fail(c, VC_ERR_ARG, "graph capacity %u nodes / %u edges does not fit the 160 KB LDS", NC, EC);
     const uint32_t PC = NC + max_len + 8;
 
@@ -519,7 +534,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint32_t S = c->n_streams;
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6)) / S;
     const uint64_t rowd = 64ull * (cpl / 2);
-    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN + 4) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
+    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN + 6) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4);
     const uint64_t per_job = NC * rowd * 4 + NC * 2 + 8 + 2 * VC_MAXTIE + 8;
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 4096;
@@ -563,11 +578,14 @@ int vc_run(vc_ctx* c) {
     pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
     pl.add_lds = 12 * c->PC + 2 * c->NC + 64;
     pl.rows_lds = c->NC + 64;
+    pl.cons_lds = vc_cons_lds_bytes(c->NC, c->EC);
     pl.rowd = 64ull * (c->cpl / 2);
     HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.topo_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prune_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.topo_lds));
+    if (c->prm.mode == 1)
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.cons_lds));
     HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 32, c->stream));
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
     HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
@@ -590,6 +608,14 @@ int vc_run(vc_ctx* c) {
         for (uint32_t j = 1; j <= max_layers; ++j)
             for (uint32_t s = 0; s < S; ++s)
                 if (c->works[s].active && j <= c->works[s].layers && (rc = pl.build_layer(c->works[s], j))) return rc;
+        if (c->prm.mode == 1) {
+            for (uint32_t s = 0; s < S; ++s) {
+                if (!c->works[s].active) continue;
+                if (c->works[s].layers) { if ((rc = pl.linear_tail(c->works[s]))) return rc; }
+                else c->works[s].active = false;
+            }
+            continue;
+        }
         for (uint32_t r = 0; r < c->prm.num_prune; ++r) {
             const bool more = r + 1 < c->prm.num_prune;
             for (uint32_t s = 0; s < S; ++s)

@@ -48,6 +48,7 @@ struct VcGraph {
     uint32_t* e_w;        // [CW*EC]
     uint16_t* ord;        // [CW*NC] a valid DP order of the nodes (aligned groups contiguous), kept incrementally
     uint16_t* pos;        // [CW*NC] inverse of ord
+    uint16_t* visits;     // [CW*NC] sequences (len >= 2) whose path contains the node == Node::Coverage() (graph.cpp:38-56)
 };
 
 // Input of the alignment kernel for one graph, produced by k_topo in rank order.

@@ -12,6 +12,7 @@
 //   k_prune_lcc     wave / window         graph.cpp:811-982 PruneGraph, :984-1102 DfsUtil/LargestSubgraph
 //   k_addw          wave / window         graph.cpp:1104-1165 AddWeights (+ window.cpp:351-372 weights)
 //   k_finish        wave / window         graph.cpp:1167-1179 GenerateCorrectedSequence
+//   k_consensus     wave / window         graph.cpp:450-638 GenerateConsensus (+ window.cpp:141-171 trim), racon-linear overload
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vc_device.h"
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, uint32_t w
         g.out_first[nb + i] = eout; g.out_last[nb + i] = eout;
         g.al_cnt[nb + i] = 0;
         g.ord[nb + i] = (uint16_t)i; g.pos[nb + i] = (uint16_t)i;
+        g.visits[nb + i] = L >= 2 ? 1 : 0;
         if (i + 1 < L) {
             uint32_t wgt = b.lut_w[b.quals[o0 + i]] + b.lut_w[b.quals[o0 + i + 1]];
             g.e_tn[eb + i] = i | ((uint32_t)VC_NONE16 << 16);
@@ -1223,9 +1225,18 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
             }
         }
         a.g.al_cnt[nb + curr] = (uint8_t)mycnt;
+        a.g.visits[nb + curr] = 0;
     }
     if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_UNSUPPORTED, 7, 0); return; }
     __syncthreads();      // pass B's stores are complete before pass C touches the same nodes
+
+    // every node on the path gains this sequence's label on an adjacent edge (Node::Coverage, graph.cpp:38-56)
+    if (len >= 2) {
+        for (uint32_t f = lane; f < P; f += 64) {
+            const uint32_t curr = s_curr[f];
+            if (curr != VC_NONE16) a.g.visits[nb + curr] = (uint16_t)((curr < N0 ? a.g.visits[nb + curr] : 0) + 1);
+        }
+    }
 
     // pass C: edges between consecutive aligned bases (graph.cpp:282-290 -> AddEdge :94-107)
     uint32_t enew = 0;
@@ -1603,6 +1614,132 @@ __global__ __launch_bounds__(64) void k_finish(VcFinishArgs a) {
         outn += tot;
     }
     if (__any(err)) { if (lane == 0) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 10, outn); a.b.cons_len[w] = 0; } return; }
+    if (lane == 0) a.b.cons_len[w] = outn;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_consensus: the racon-linear overload's tail (window.cpp:138-171): Graph::GenerateConsensus =
+// TraverseHeaviestBundle + BranchCompletion (graph.cpp:534-638), coverage summary (graph.cpp:476-484;
+// Node::Coverage == number of sequences through the node, kept in VcGraph::visits) and the TGS trim.
+// Serial by nature (scores propagate along the reference's rank order, ties decided by that order);
+// runs on lane 0 out of LDS, the graph is staged cooperatively.
+// LDS carve: rank 2N | noderank 2N | in_first 2N | out_first 2N | pred 2N | cons 2N | etn 4E | ehn 4E | w 4E | score 8N
+// ------------------------------------------------------------------------------------------------
+struct VcConsArgs {
+    VcBatchDev b;
+    VcGraph g;
+    VcDp dp;
+    uint32_t w0, nslots, NC, EC;
+    int trim, window_type;
+};
+
+__host__ __device__ inline uint32_t vc_cons_lds_bytes(uint32_t NC, uint32_t EC) { return 12 * NC + 12 * EC + 8 * NC + 128; }
+
+__global__ __launch_bounds__(64) void k_consensus(VcConsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t slot = blockIdx.x;
+    if (slot >= a.nslots) return;
+    const uint32_t w = a.w0 + slot;
+    if (a.b.status[w] != VC_WIN_OK) return;
+    const int lane = vc_lane();
+    const uint32_t NC = a.NC, EC = a.EC;
+    const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
+    const uint32_t N = a.g.n_nodes[slot], E = a.g.n_edges[slot];
+    const uint32_t nseq = a.b.win_seq_off[w + 1] - a.b.win_seq_off[w];
+    long long* s_score = (long long*)smem;                      // [NC]
+    uint32_t* s_etn = (uint32_t*)(s_score + NC);                // [EC]
+    uint32_t* s_ehn = s_etn + EC;
+    uint32_t* s_w = s_ehn + EC;
+    uint16_t* s_rank = (uint16_t*)(s_w + EC);                   // [NC] each
+    uint16_t* s_nrank = s_rank + NC;
+    uint16_t* s_inf = s_nrank + NC;
+    uint16_t* s_outf = s_inf + NC;
+    uint16_t* s_pred = s_outf + NC;
+    uint16_t* s_cons = s_pred + NC;
+    for (uint32_t i = lane; i < N; i += 64) {
+        const uint32_t v = a.dp.rank2node[nb + i];
+        s_rank[i] = (uint16_t)v; s_nrank[v] = (uint16_t)i;
+        s_inf[i] = a.g.in_first[nb + i]; s_outf[i] = a.g.out_first[nb + i];
+        s_pred[i] = VC_NONE16; s_score[i] = -1;
+    }
+    for (uint32_t e = lane; e < E; e += 64) { s_etn[e] = a.g.e_tn[eb + e]; s_ehn[e] = a.g.e_hn[eb + e]; s_w[e] = a.g.e_w[eb + e]; }
+    __syncthreads();
+    __shared__ uint32_t s_ncons;
+    if (lane == 0) {
+        // relax one node over its in-edges in list order (graph.cpp:549-559 / :615-632)
+        auto relax = [&](uint32_t it, bool skip_dead) {
+            for (uint32_t e = s_inf[it]; e != VC_NONE16; ) {
+                const uint32_t tn = s_etn[e];
+                const uint32_t tl = tn & 0xFFFF;
+                const long long wt = (long long)s_w[e];
+                e = tn >> 16;
+                if (skip_dead && s_score[tl] == -1) continue;
+                if (s_score[it] < wt || (s_score[it] == wt && s_score[s_pred[it]] <= s_score[tl])) { s_score[it] = wt; s_pred[it] = (uint16_t)tl; }
+            }
+            if (s_pred[it] != VC_NONE16) s_score[it] += s_score[s_pred[it]];
+        };
+        uint32_t mx = VC_NONE16;
+        for (uint32_t r = 0; r < N; ++r) {
+            const uint32_t it = s_rank[r];
+            relax(it, false);
+            if (mx == VC_NONE16 || s_score[mx] < s_score[it]) mx = it;
+        }
+        while (s_outf[mx] != VC_NONE16) {                         // BranchCompletion, graph.cpp:590-638
+            const uint32_t start = mx, rk = s_nrank[mx];
+            for (uint32_t e = s_outf[start]; e != VC_NONE16; ) {
+                const uint32_t hn = s_ehn[e];
+                for (uint32_t e2 = s_inf[hn & 0xFFFF]; e2 != VC_NONE16; ) {
+                    const uint32_t tn = s_etn[e2];
+                    if ((tn & 0xFFFF) != start) s_score[tn & 0xFFFF] = -1;
+                    e2 = tn >> 16;
+                }
+                e = hn >> 16;
+            }
+            uint32_t m2 = VC_NONE16;
+            for (uint32_t r = rk + 1; r < N; ++r) {
+                const uint32_t it = s_rank[r];
+                s_score[it] = -1; s_pred[it] = VC_NONE16;
+                relax(it, true);
+                if (m2 == VC_NONE16 || s_score[m2] < s_score[it]) m2 = it;
+            }
+            if (m2 == VC_NONE16) break;                           // cannot happen: a non-sink has a successor
+            mx = m2;
+        }
+        uint32_t n = 0;
+        while (s_pred[mx] != VC_NONE16) { s_cons[n++] = (uint16_t)mx; mx = s_pred[mx]; }
+        s_cons[n++] = (uint16_t)mx;
+        for (uint32_t x = 0, y = n - 1; x < y; ++x, --y) { const uint16_t t = s_cons[x]; s_cons[x] = s_cons[y]; s_cons[y] = t; }
+        s_ncons = n;
+    }
+    __syncthreads();
+    const uint32_t n = s_ncons;
+    // coverage of every consensus position (own + aligned nodes), then the TGS trim (window.cpp:141-171)
+    uint16_t* s_cov = s_pred;                                    // reuse
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t v = s_cons[i];
+        uint32_t cv = a.g.visits[nb + v];
+        const uint32_t cnt = a.g.al_cnt[nb + v];
+        for (uint32_t t = 0; t < cnt; ++t) cv += a.g.visits[nb + a.g.al[(nb + v) * VC_MAXALN + t]];
+        s_cov[i] = (uint16_t)(cv > 0xFFFF ? 0xFFFF : cv);
+    }
+    __syncthreads();
+    __shared__ int s_be[2];
+    if (lane == 0) {
+        int begin = 0, end = (int)n - 1;
+        if (a.window_type == 1 && a.trim) {
+            const uint32_t avgc = (nseq - 1) / 2;
+            for (; begin < (int)n; ++begin) if (s_cov[begin] >= avgc) break;
+            for (; end >= 0; --end) if (s_cov[end] >= avgc) break;
+            if (begin >= end) { begin = 0; end = (int)n - 1; }      // "might be chimeric": left untrimmed
+        }
+        s_be[0] = begin; s_be[1] = end;
+    }
+    __syncthreads();
+    const int begin = s_be[0], end = s_be[1];
+    const uint32_t outn = end >= begin ? (uint32_t)(end - begin + 1) : 0;
+    if (outn > a.b.cons_cap) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 18, outn); return; }
+    for (uint32_t i = lane; i < outn; i += 64) a.b.cons[(uint64_t)w * a.b.cons_cap + i] = a.g.code[nb + s_cons[begin + i]];
     if (lane == 0) a.b.cons_len[w] = outn;
 }
 
