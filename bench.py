@@ -148,6 +148,13 @@ def main():
         fwd_ms = kms.get("k_fwd", 0.0)
         fwd_launches = s["kernels"]["k_fwd"]["launches"] * a.steps
         achieved = BYTES_PER_CELL * cells / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
+        # measured HBM bytes per cell of k_fwd (rocprofv3 PMC passes, see profiles/r1_hbm_traffic.json)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
+            traffic = tj["bytes_per_cell"] * cells / max(fwd_launches, 1)
+        except Exception:
+            pass
         line = {
             "metric": "POA windows/sec (500 bp x 64-read)", "value": total_windows / dt, "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -162,7 +169,8 @@ def main():
             "gcups": cells * world / dt / 1e9,
             "windows_not_ok": int((status > 1).sum()),
             "roofline": {"bound": "hbm", "kernel": "k_fwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells / max(fwd_launches, 1),
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL, "cells_per_step": cells / a.steps,
                          "avg_launch_ms": fwd_ms / max(fwd_launches, 1), "launches_per_step": fwd_launches / a.steps},
             "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
