@@ -57,7 +57,7 @@ typedef struct vc_params {
     uint32_t chunk_windows;                 /* windows resident per pass; 0 = derive from memory   */
     uint64_t scratch_bytes;                 /* device scratch budget; 0 = 1/4 of free memory       */
     int32_t  profile;                       /* 1 = bracket every kernel class with HIP events      */
-    uint32_t n_streams;                     /* chunks in flight on separate HIP streams; 0 = 4     */
+    uint32_t n_streams;                     /* chunks in flight on separate HIP streams; 0 = 2     */
 } vc_params;
 
 /* A batch of windows, the unit the reference's accelerated path fills with

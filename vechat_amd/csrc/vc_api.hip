@@ -396,7 +396,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     vc_ctx* c = new vc_ctx();
     c->prm = *p;
     c->device = p->device;
-    c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 4;
+    c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 2;
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }
     for (uint32_t s = 0; s < c->n_streams; ++s) {
         if (hipStreamCreateWithFlags(&c->streams[s], hipStreamNonBlocking) != hipSuccess) {
@@ -537,7 +537,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN + 6) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4);
     const uint64_t per_job = NC * rowd * 4 + NC * 2 + 8 + 2 * VC_MAXTIE + 8;
-    uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 4096;
+    uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);
     if (CW == 0) CW = 1;
     while (CW > 64 && (per_slot_fixed + per_job) * CW > budget) CW /= 2;
