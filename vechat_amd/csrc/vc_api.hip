@@ -79,7 +79,7 @@ struct vc_ctx {
     uint32_t* d_lut_w = nullptr; double* d_lut_d = nullptr;
     unsigned long long* d_stat = nullptr;   // [4] cells, rows, spilled rows, far-row reads
 
-    uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
+    uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
@@ -197,24 +197,48 @@ void flush_events(vc_ctx* c) {
     c->ev_next = 0;
 }
 
-template <int CPL>
+template <int CA, int CB>
 void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs) {
-    hipLaunchKernelGGL((k_fwd<CPL, kRing>), dim3(jobs), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_fwd<CA, CB, kRing>), dim3(jobs), dim3(64), 0, st, a);
 }
 
-int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a, uint32_t jobs) {
-    Timer t(c, KC_FWD, st);
-    switch (c->cpl) {
-        case 4:  launch_fwd_t<4>(st, a, jobs); break;
-        case 6:  launch_fwd_t<6>(st, a, jobs); break;
-        case 8:  launch_fwd_t<8>(st, a, jobs); break;
-        case 10: launch_fwd_t<10>(st, a, jobs); break;
-        case 12: launch_fwd_t<12>(st, a, jobs); break;
-        case 16: launch_fwd_t<16>(st, a, jobs); break;
-        case 20: launch_fwd_t<20>(st, a, jobs); break;
-        case 24: launch_fwd_t<24>(st, a, jobs); break;
-        case 32: launch_fwd_t<32>(st, a, jobs); break;
-        default: return fail(c, VC_ERR_ARG, "unsupported cells-per-lane %u", c->cpl);
+// One launch when the batch's sequences fall into one width class or two adjacent ones (the usual case:
+// read pieces of a window differ by a few percent in length); otherwise one launch per class.
+int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs) {
+    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
+    VcFwdArgs a = a0;
+    a.do_init = 1;
+    int lo = -1, hi = -1;
+    for (int i = 0; i < 9; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
+    if (lo < 0 || hi < 0) return fail(c, VC_ERR_ARG, "unsupported cells-per-lane %u..%u", c->cpl_min, c->cpl);
+    if (hi - lo == 1) {
+        Timer t(c, KC_FWD, st);
+        switch (hi) {
+            case 1: launch_fwd_t<4, 6>(st, a, jobs); break;
+            case 2: launch_fwd_t<6, 8>(st, a, jobs); break;
+            case 3: launch_fwd_t<8, 10>(st, a, jobs); break;
+            case 4: launch_fwd_t<10, 12>(st, a, jobs); break;
+            case 5: launch_fwd_t<12, 16>(st, a, jobs); break;
+            case 6: launch_fwd_t<16, 20>(st, a, jobs); break;
+            case 7: launch_fwd_t<20, 24>(st, a, jobs); break;
+            case 8: launch_fwd_t<24, 32>(st, a, jobs); break;
+        }
+        return VC_OK;
+    }
+    for (int i = lo; i <= hi; ++i) {
+        Timer t(c, KC_FWD, st);
+        switch (opts[i]) {
+            case 4:  launch_fwd_t<4, 4>(st, a, jobs); break;
+            case 6:  launch_fwd_t<6, 6>(st, a, jobs); break;
+            case 8:  launch_fwd_t<8, 8>(st, a, jobs); break;
+            case 10: launch_fwd_t<10, 10>(st, a, jobs); break;
+            case 12: launch_fwd_t<12, 12>(st, a, jobs); break;
+            case 16: launch_fwd_t<16, 16>(st, a, jobs); break;
+            case 20: launch_fwd_t<20, 20>(st, a, jobs); break;
+            case 24: launch_fwd_t<24, 24>(st, a, jobs); break;
+            case 32: launch_fwd_t<32, 32>(st, a, jobs); break;
+        }
+        a.do_init = 0;
     }
     return VC_OK;
 }
@@ -449,7 +473,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint64_t nseq = hb->win_seq_off[nw];
     const uint64_t nbytes = hb->seq_off[nseq];
     // validation (what createWindow / add_layer enforce, window.cpp:22-27,56-67)
-    uint32_t max_layers = 0, max_len = 0, max_nseq = 0;
+    uint32_t max_layers = 0, max_len = 0, max_nseq = 0, min_len = 0xFFFFFFFFu;
     uint64_t need_nodes = 0;
     std::vector<uint8_t> layer_partial;
     for (uint32_t w = 0; w < nw; ++w) {
@@ -473,6 +497,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
                 if (!full) layer_partial[j] = 1;
             }
             max_len = std::max<uint32_t>(max_len, (uint32_t)len);
+            min_len = std::min<uint32_t>(min_len, (uint32_t)len);
         }
         max_layers = std::max(max_layers, s1 - s0 - 1);
         max_nseq = std::max(max_nseq, s1 - s0);
@@ -521,6 +546,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     if (EC > 32000) EC = 32000;
     if (NC > 60000) return fail(c, VC_ERR_ARG, "max_nodes %u exceeds the 16-bit id space", NC);
     const uint32_t cpl = pick_cpl(max_len);
+    c->cpl_min = pick_cpl(min_len);
     if (!cpl) return fail(c, VC_ERR_ARG, "sequence length %u exceeds the kernels' 2048-column envelope", max_len);
     const uint32_t lds_cap = 160 * 1024;
     if (topo_lds_bytes(NC, EC, c->STK) > lds_cap || vc_prune_lds_bytes(NC, EC) > lds_cap ||

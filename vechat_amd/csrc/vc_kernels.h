@@ -56,6 +56,13 @@ __device__ __forceinline__ uint32_t vc_weight(const VcBatchDev& b, uint64_t off,
     return has_qual ? b.lut_w[b.quals[off + q]] : 1u;
 }
 
+// columns-per-lane class of a sequence: the smallest instantiated k_fwd width that holds it
+__host__ __device__ inline uint32_t vc_cpl_for(uint32_t len) {
+    const uint32_t opts[9] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
+    for (int i = 0; i < 9; ++i) if (64 * opts[i] >= len) return opts[i];
+    return 0;
+}
+
 __device__ __forceinline__ bool vc_full_span(uint32_t begin, uint32_t end, uint32_t L) {
     uint32_t offset = (uint32_t)(0.01 * (double)L);          // window.cpp:212
     return begin < offset && end > L - offset;              // window.cpp:253-254
@@ -658,6 +665,7 @@ struct VcFwdArgs {
     uint32_t w0, nslots, NC, EC;
     uint32_t group, k0;            // jobs per slot in this launch, first sequence index
     int mode;
+    int do_init;                   // first width class of a launch group resets the per-job outputs
     int m, n, g;                   // NW scores
     int sm, sn, sg;                // SW scores
     uint32_t* hmat;                // [jobs * hstride] packed int16 H, row = [CPL/2][64 lanes] dwords
@@ -699,22 +707,22 @@ __device__ __forceinline__ int pk_lo(uint32_t a) { return (int)(short)(a & 0xFFF
 __device__ __forceinline__ int pk_hi(uint32_t a) { return (int)a >> 16; }
 
 template <int CPL, int RING>
-__global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
+__device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_raw, int* ring_c0) {
     constexpr int ND = CPL / 2;              // packed int16 dwords per lane per row
-    __shared__ uint32_t ring[RING][ND][64];
-    __shared__ int ring_c0[RING];
+    uint32_t (*ring)[ND][64] = reinterpret_cast<uint32_t (*)[ND][64]>(ring_raw);
     const int lane = vc_lane();
     const uint32_t job = blockIdx.x;
     const uint32_t slot = job / a.group;
     if (slot >= a.nslots) return;
     const uint32_t k = a.k0 + job % a.group;
     const uint32_t w = a.w0 + slot;
-    if (lane == 0) { a.job_type[job] = 255; a.job_end[job] = 0; a.tie_cnt[job] = 0; }
+    if (a.do_init && lane == 0) { a.job_type[job] = 255; a.job_end[job] = 0; a.tie_cnt[job] = 0; }
     if (a.b.status[w] != VC_WIN_OK) return;
     const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
     if (k >= ns) return;
     const uint64_t so = a.b.seq_off[s0 + k];
     const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k + 1] - so);
+    if (vc_cpl_for(len) != (uint32_t)CPL) return;             // another width class handles this sequence
     const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
     bool nw = true;
     if (a.mode == 2) nw = false;
@@ -981,6 +989,25 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     if (lane == 0) a.job_end[job] = end;
 }
 
+// CA <= CB: the two adjacent width classes of a batch share one launch (register and LDS budget of the
+// wider one); each alignment takes the narrowest body that holds its sequence.  CA == CB: single class.
+template <int CA, int CB, int RING>
+__global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
+    __shared__ uint32_t ring_raw[RING * (CB / 2) * 64];
+    __shared__ int ring_c0[RING];
+    if (CA != CB) {
+        // sequence length of this job decides the body (uniform per wave)
+        const uint32_t job = blockIdx.x, slot = job / a.group;
+        if (slot >= a.nslots) return;
+        const uint32_t w = a.w0 + slot, k = a.k0 + job % a.group;
+        const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
+        uint32_t cls = CB;
+        if (k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + k + 1] - a.b.seq_off[s0 + k]));
+        if (cls == (uint32_t)CA) { vc_fwd_body<CA, RING>(a, ring_raw, ring_c0); return; }
+    }
+    vc_fwd_body<CB, RING>(a, ring_raw, ring_c0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_trace: backtrack, one alignment per thread, straight from H like sisd_alignment_engine.cpp:362-459:
 // diagonal over the in-edges in list order, then vertical over the in-edges in list order, then
@@ -1027,7 +1054,7 @@ __global__ void k_trace(VcTraceArgs a) {
     const uint64_t so = a.b.seq_off[a.b.win_seq_off[w] + k];
     const uint16_t* hm = (const uint16_t*)(a.hmat + (uint64_t)job * a.hstride);
     const int16_t* c0 = a.c0 + (uint64_t)job * a.NC;
-    const uint32_t nd = a.cpl / 2, cpl = a.cpl;
+    const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[a.b.win_seq_off[w] + k + 1] - so)), nd = cpl / 2;
     auto Hat = [&](uint32_t r, uint32_t col) -> int {     // H[r][col] incl. the virtual row 0 / column 0
         if (r == 0) return nw ? (int)col * g : 0;
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
