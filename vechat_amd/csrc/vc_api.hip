@@ -504,7 +504,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         // graph growth saturates with depth: nodes ~ L + c * mean_layer_len * depth^0.55 (measured on
         // 8..128-read PacBio/ONT-profile windows; windows that still outgrow it report VC_WIN_OVERFLOW)
         const double depth = (double)(s1 - s0 - 1);
-        const double est = depth > 0 ? 0.36 * ((double)sum / depth) * std::pow(depth, 0.55) : 0.0;
+        const double est = depth > 0 ? 0.33 * ((double)sum / depth) * std::pow(depth, 0.55) : 0.0;
         need_nodes = std::max<uint64_t>(need_nodes, L + (uint64_t)std::ceil(est) + 64);
     }
     (void)hipDeviceSynchronize();

@@ -85,11 +85,32 @@ class HipContext:
             d["kernels"][s.names[i].value.decode()] = dict(ms=float(s.ms[i]), launches=int(s.launches[i]))
         return d
 
-    def consensus(self, batch: capi.Batch):
+    def consensus(self, batch: capi.Batch, retry_overflow=True):
+        """submit + run + collect.  Windows whose graph outgrew the capacity estimate come back as
+        VC_WIN_OVERFLOW with no bytes; with retry_overflow they are resubmitted (on the device, never on
+        the CPU) in a context with doubled capacities, as INTEGRATION.md section 4 describes."""
         self.submit(batch)
         self.run()
         self.sync()
-        return self.collect()
+        cons, status = self.collect()
+        over = [w for w in range(batch.n_windows) if int(status[w]) == capi.VC_WIN_OVERFLOW]
+        if retry_overflow and over:
+            st = self.stats()
+            p = capi.VcParams.from_buffer_copy(self.params)
+            p.max_nodes = min(2 * st["max_nodes"], 60000)
+            p.max_edges = min(2 * st["max_edges"], 32000)
+            if p.max_nodes > st["max_nodes"]:
+                try:
+                    sub = HipContext(params=p)
+                except VcError:
+                    return cons, status
+                try:
+                    c2, s2 = sub.consensus(batch.select(over), retry_overflow=True)
+                finally:
+                    sub.close()
+                for k, w in enumerate(over):
+                    cons[w], status[w] = c2[k], s2[k]
+        return cons, status
 
 
 class Window:
