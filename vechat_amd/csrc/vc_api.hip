@@ -50,6 +50,7 @@ struct Work {
     uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
     uint32_t* d_rpairs = nullptr; uint32_t* d_rnpairs = nullptr;     // realign: [CW*max_nseq*PC]
     uint32_t* d_maxn = nullptr;
+    uint16_t* d_scratch16 = nullptr;                                 // k_addaln per-pair notes
     uint32_t* h_maxn = nullptr;                                      // pinned
     // state of the chunk currently in flight
     uint32_t w0 = 0, ns = 0, layers = 0, nseq_max = 0;
@@ -165,6 +166,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->d_npairs, CW)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_rpairs, CW * c->max_nseq * PC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_rnpairs, CW * c->max_nseq)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_scratch16, CW * (4 * PC + NC))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_maxn, 1)))
         return rc;
     return VC_OK;
@@ -309,7 +311,7 @@ struct Plan {
         { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
-        aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC;
+        aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16;
         { Timer t(c, KC_ADDALN, wk.stream); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, wk.stream, aa); }
         return VC_OK;
     }
@@ -602,7 +604,7 @@ int vc_run(vc_ctx* c) {
     pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
     pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK);
     pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
-    pl.add_lds = 12 * c->PC + 2 * c->NC + 64;
+    pl.add_lds = 2 * c->PC + 2 * (c->PC - c->NC) + 64;
     pl.rows_lds = c->NC + 64;
     pl.cons_lds = vc_cons_lds_bytes(c->NC, c->EC);
     pl.rowd = 64ull * (c->cpl / 2);

@@ -1140,17 +1140,20 @@ struct VcAddArgs {
     VcDp dp;
     uint32_t w0, nslots, NC, EC, layer;
     const uint32_t* pairs; const uint32_t* npairs; uint32_t PC;
+    uint16_t* scratch;            // [CW * (4*PC + NC)]
 };
 
 __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* s_curr = (uint16_t*)smem;                 // [PC] node chosen for each pair (forward order)
-    uint16_t* s_row = s_curr + a.PC;                    // [PC] DP row of the pair (0 = none)
+    uint16_t* s_anchor = s_curr + a.PC;                 // [max_len] new node t goes in front of old position anchor[t]
+    // bulky per-pair notes live in HBM scratch, not LDS: this kernel shares CUs with k_fwd of the other
+    // stream and must leave it the LDS (each note is written once and read a few times in pass D)
+    uint16_t* s_row = a.scratch + (uint64_t)blockIdx.x * (4 * a.PC + a.NC);   // [PC] DP row of the pair (0 = none)
     uint16_t* s_bs = s_row + a.PC;                      // [PC] first / last position in VcGraph::ord of the
     uint16_t* s_be = s_bs + a.PC;                       //      aligned group of the pair's node
     uint16_t* s_pn = s_be + a.PC;                       // [PC] position of the pair's node itself
-    uint16_t* s_anchor = s_pn + a.PC;                   // [PC] new node t goes in front of old position anchor[t]
-    uint16_t* s_ord = s_anchor + a.PC;                  // [NC] old order
+    uint16_t* s_ord = s_pn + a.PC;                      // [NC] old order
     const uint32_t slot = blockIdx.x;
     if (slot >= a.nslots) return;
     const uint32_t w = a.w0 + slot;
