@@ -46,7 +46,7 @@ struct Work {
     VcDp dp{};
     uint32_t* d_hmat = nullptr; int16_t* d_c0 = nullptr;
     uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
-    uint16_t* d_tie_rows = nullptr; uint8_t* d_tie_cnt = nullptr;
+    uint16_t* d_tie_rows = nullptr; uint8_t* d_tie_cnt = nullptr; uint32_t* d_tie_list = nullptr; uint32_t* d_tie_n = nullptr;
     uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
     uint32_t* d_rpairs = nullptr; uint32_t* d_rnpairs = nullptr;     // realign: [CW*max_nseq*PC]
     uint32_t* d_maxn = nullptr;
@@ -162,6 +162,8 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_type, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_tie_rows, (size_t)c->jobs_cap * VC_MAXTIE)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_tie_cnt, c->jobs_cap)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_tie_list, c->jobs_cap)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_tie_n, 4)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_pairs, CW * PC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_npairs, CW)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_rpairs, CW * c->max_nseq * PC)) ||
@@ -263,7 +265,7 @@ struct Plan {
         fa.m = c->prm.match; fa.n = c->prm.mismatch; fa.g = c->prm.gap;
         fa.sm = c->prm.sw_match; fa.sn = c->prm.sw_mismatch; fa.sg = c->prm.sw_gap;
         fa.hmat = wk.d_hmat; fa.c0 = wk.d_c0;
-        fa.job_end = wk.d_job_end; fa.job_type = wk.d_job_type; fa.tie_rows = wk.d_tie_rows; fa.tie_cnt = wk.d_tie_cnt;
+        fa.job_end = wk.d_job_end; fa.job_type = wk.d_job_type; fa.tie_rows = wk.d_tie_rows; fa.tie_cnt = wk.d_tie_cnt; fa.tie_list = wk.d_tie_list; fa.tie_n = wk.d_tie_n;
         fa.stat = c->d_stat;
         return fa;
     }
@@ -300,11 +302,13 @@ struct Plan {
         }
         VcFwdArgs fa = fwd_args(wk);
         fa.group = 1; fa.k0 = j; fa.mode = 0; fa.hstride = (uint64_t)NC * rowd;
+        HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
         int rc = launch_fwd(c, wk.stream, fa, ns);
         if (rc) return rc;
         { Timer t(c, KC_RESOLVE, wk.stream);
-          hipLaunchKernelGGL(k_resolve, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
-                             (const uint16_t*)wk.d_tie_rows, (const uint8_t*)wk.d_tie_cnt, wk.d_job_end); }
+          hipLaunchKernelGGL(k_resolve, dim3(128), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
+                             (const uint16_t*)wk.d_tie_rows, (const uint8_t*)wk.d_tie_cnt, wk.d_job_end,
+                             (const uint32_t*)wk.d_tie_list, (const uint32_t*)wk.d_tie_n); }
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;

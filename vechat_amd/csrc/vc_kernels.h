@@ -519,11 +519,9 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
 // order (sisd :353-355 with `<`).  For alignments done on the incremental order and ending in such a
 // tie, run the exact TopologicalSort DFS now and choose the tied sink with the smallest rank.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                                uint32_t NC, uint32_t EC, uint32_t STK,
-                                                const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t slot = blockIdx.x;
+__device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b, const VcGraph& g, const VcDp& dp,
+                               uint32_t w0, uint32_t nslots, uint32_t NC, uint32_t EC, uint32_t STK,
+                               const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end) {
     if (slot >= nslots) return;
     const uint32_t w = w0 + slot;
     const uint32_t nt = tie_cnt[slot];
@@ -647,6 +645,20 @@ __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp
     if (lane == 0) job_end[slot] = (row << 16) | (job_end[slot] & 0xFFFF);
 }
 
+// a few resident workgroups walk the list of windows whose alignment ended in a tie (appended by k_fwd),
+// so the thousands of untied windows cost nothing and nobody parks 60 KB of LDS per window
+__global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+                                                uint32_t NC, uint32_t EC, uint32_t STK,
+                                                const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end,
+                                                const uint32_t* tie_list, const uint32_t* tie_n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t n = *tie_n;
+    for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
+        __syncthreads();
+        vc_resolve_one(smem, tie_list[idx], b, g, dp, w0, nslots, NC, EC, STK, tie_rows, tie_cnt, job_end);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_fwd: linear-gap graph DP, one alignment per wavefront (64-thread workgroup = 1 wave).
 //   columns: lane l owns columns l*CPL+1 .. l*CPL+CPL (contiguous); column 0 is a per-row scalar
@@ -675,6 +687,8 @@ struct VcFwdArgs {
     uint8_t*  job_type;            // [jobs] 0 SW, 1 NW, 255 skipped
     uint16_t* tie_rows;            // [jobs * VC_MAXTIE] NW: sink rows sharing the best end score (incremental order only)
     uint8_t*  tie_cnt;             // [jobs]
+    uint32_t* tie_list;            // [jobs] windows whose alignment ended in a tie (build phase)
+    uint32_t* tie_n;               // [1]
     unsigned long long* stat;      // [4] cells, rows, -, far-row reads
 };
 
@@ -966,7 +980,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         end = (best_row << 16) | len;
         if (ntie > 1 && (a.dp.flags[slot] & 2u)) {          // tie on a non-reference order: k_resolve decides
             if (ntie > VC_MAXTIE) { if (lane == 0) vc_fail(a.b, w, VC_WIN_UNSUPPORTED, 15, ntie); }
-            else if (lane == 0) a.tie_cnt[job] = (uint8_t)ntie;
+            else if (lane == 0) { a.tie_cnt[job] = (uint8_t)ntie; a.tie_list[atomicAdd(a.tie_n, 1u)] = slot; }
         }
     } else {
         const int gmax = wave_max_i32(best);
