@@ -13,7 +13,8 @@ t0 = time.time()
 b = capi.synth_batch(capi.synth_cfg(1002, L, D), 0, n)
 print(f"generated {n} windows in {time.time()-t0:.1f}s, {b.bases.size/1e6:.1f} MB bases", flush=True)
 ctx = HipContext(device=0, profile=1, chunk_windows=chunk, n_streams=streams)
-ctx.submit(b)
+t0 = time.time(); ctx.submit(b); ts = time.time() - t0
+print(f"vc_submit (validation + H2D of {2*b.bases.size/1e6:.0f} MB): {ts:.3f}s = {n/ts:.0f} win/s", flush=True)
 for rep in range(2):
     t0 = time.time(); ctx.run(); ctx.sync(); t1 = time.time()
     s = ctx.stats()

@@ -85,6 +85,9 @@ struct vc_ctx {
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
 
+    void* h_stage[2] = {nullptr, nullptr};   // pinned staging for uploads from pageable caller memory
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+
     vc_stats stats{};
     std::vector<hipEvent_t> ev_pool;
     struct EvRec { int cls; hipEvent_t a, b; };
@@ -171,6 +174,29 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->d_scratch16, CW * (4 * PC + NC))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_maxn, 1)))
         return rc;
+    return VC_OK;
+}
+
+
+constexpr size_t kStageBytes = 64u << 20;
+
+// H2D from pageable caller memory through two pinned staging buffers (copy-in of chunk k+1 overlaps
+// the DMA of chunk k); small arrays go straight through hipMemcpyAsync
+int h2d(vc_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (bytes < (4u << 20)) { HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return VC_OK; }
+    for (int i = 0; i < 2; ++i) {
+        if (!c->h_stage[i]) { HIPCHK(c, hipHostMalloc(&c->h_stage[i], kStageBytes)); HIPCHK(c, hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming)); }
+    }
+    size_t off = 0;
+    int k = 0;
+    while (off < bytes) {
+        const size_t n = std::min(kStageBytes, bytes - off);
+        HIPCHK(c, hipEventSynchronize(c->stage_ev[k]));                 // buffer k free again
+        std::memcpy(c->h_stage[k], (const char*)src + off, n);
+        HIPCHK(c, hipMemcpyAsync((char*)dst + off, c->h_stage[k], n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->stage_ev[k], c->stream));
+        off += n; k ^= 1;
+    }
     return VC_OK;
 }
 
@@ -460,6 +486,7 @@ void vc_destroy(vc_ctx* c) {
     free_list(c->batch_allocs);
     free_list(c->allocs);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) { if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); }
     for (uint32_t s = 0; s < kMaxStreams; ++s) {
         if (c->works[s].h_maxn) (void)hipHostFree(c->works[s].h_maxn);
         if (c->streams[s]) (void)hipStreamDestroy(c->streams[s]);
@@ -533,8 +560,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     HIPCHK(c, hipMemcpyAsync(d_sb, hb->seq_begin, nseq * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_se, hb->seq_end, nseq * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_hq, hb->seq_has_qual, nseq, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_ba, hb->bases, nbytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_qu, hb->quals, nbytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = h2d(c, d_ba, hb->bases, nbytes)) || (rc = h2d(c, d_qu, hb->quals, nbytes))) return rc;
     HIPCHK(c, hipMemcpyAsync(d_wf, hb->win_fasta, nw, hipMemcpyHostToDevice, c->stream));
     b.win_seq_off = d_wso; b.seq_off = d_so; b.seq_begin = d_sb; b.seq_end = d_se; b.seq_has_qual = d_hq;
     b.bases = d_ba; b.quals = d_qu; b.win_fasta = d_wf;
