@@ -89,9 +89,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("VC_FORCE_DIST") == "1"      # exercise the RCCL path on a single GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -115,10 +117,10 @@ def main():
             raise RuntimeError(ctx.lib.vc_last_error(ctx.h).decode())
         lens = d_off[1:] - d_off[:-1]
         total = int(d_off[-1].item())
-        return gather_consensus(d_cons[:total], lens, dst=0)
+        return gather_consensus(d_cons[:total], lens, dst=0, force=force_dist)
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -140,6 +142,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    out_line = None
     if rank == 0:
         total_windows = a.windows * world * a.steps
         bases = int(lens_all.sum().item()) * a.steps
@@ -184,10 +187,13 @@ def main():
             cb["parity_mismatches"] = bad
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"] if cb["value"] else None
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        out_line = json.dumps(line)
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if out_line is not None:
+        sys.stderr.flush()
+        print(out_line, flush=True)          # the one JSON line, last thing on stdout
 
 
 if __name__ == "__main__":

@@ -14,12 +14,12 @@ def shard_range(n_windows: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_consensus(cons: torch.Tensor, lens: torch.Tensor, dst: int = 0):
+def gather_consensus(cons: torch.Tensor, lens: torch.Tensor, dst: int = 0, force: bool = False):
     """cons: uint8 [sum(lens)] consensus bytes of this rank's windows, lens: int64 [n_local].
     Returns (cons_all, lens_all) on rank `dst` (window order), (None, None) elsewhere.
     Two collectives: all_gather of (n_windows, n_bytes), then an all_gather of payloads padded to
     the largest shard (one large message per peer link; no ring dependency on payload size)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return cons, lens
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = cons.device
