@@ -9,8 +9,9 @@ D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 500
 chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 streams = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+fp = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
 t0 = time.time()
-b = capi.synth_batch(capi.synth_cfg(1002, L, D), 0, n)
+b = capi.synth_batch(capi.synth_cfg(1002, L, D, frac_partial=fp), 0, n)
 print(f"generated {n} windows in {time.time()-t0:.1f}s, {b.bases.size/1e6:.1f} MB bases", flush=True)
 ctx = HipContext(device=0, profile=1, chunk_windows=chunk, n_streams=streams)
 t0 = time.time(); ctx.submit(b); ts = time.time() - t0

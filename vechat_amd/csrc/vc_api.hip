@@ -51,6 +51,7 @@ struct Work {
     uint32_t* d_rpairs = nullptr; uint32_t* d_rnpairs = nullptr;     // realign: [CW*max_nseq*PC]
     uint32_t* d_maxn = nullptr;
     uint16_t* d_scratch16 = nullptr;                                 // k_addaln per-pair notes
+    uint32_t* d_submask = nullptr;                                   // [CW*(NC/32+1)] Subgraph membership by node id
     uint32_t* h_maxn = nullptr;                                      // pinned
     // state of the chunk currently in flight
     uint32_t w0 = 0, ns = 0, layers = 0, nseq_max = 0;
@@ -172,6 +173,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->d_rpairs, CW * c->max_nseq * PC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_rnpairs, CW * c->max_nseq)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_scratch16, CW * (4 * PC + NC))) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_submask, CW * (NC / 32 + 1))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_maxn, 1)))
         return rc;
     return VC_OK;
@@ -323,8 +325,9 @@ struct Plan {
         { Timer t(c, KC_ROWS, wk.stream);
           hipLaunchKernelGGL(k_rows, dim3(ns), dim3(64), rows_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing); }
         if (c->h_layer_partial[j]) {
-            Timer t(c, KC_TOPO, wk.stream);
-            hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, (int)j, 1, (uint32_t)kRing);
+            Timer t(c, KC_ROWS, wk.stream);
+            const uint32_t sub_lds = 8 * ((NC + 63) / 64) + 2 * NC + ((NC + 15) & ~15u) + 4 * (NC / 32 + 1) + 64;
+            hipLaunchKernelGGL(k_rows_sub, dim3(ns), dim3(64), sub_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing, wk.d_submask);
         }
         VcFwdArgs fa = fwd_args(wk);
         fa.group = 1; fa.k0 = j; fa.mode = 0; fa.hstride = (uint64_t)NC * rowd;
@@ -334,7 +337,7 @@ struct Plan {
         { Timer t(c, KC_RESOLVE, wk.stream);
           hipLaunchKernelGGL(k_resolve, dim3(128), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
                              (const uint16_t*)wk.d_tie_rows, (const uint8_t*)wk.d_tie_cnt, wk.d_job_end,
-                             (const uint32_t*)wk.d_tie_list, (const uint32_t*)wk.d_tie_n); }
+                             (const uint32_t*)wk.d_tie_list, (const uint32_t*)wk.d_tie_n, (const uint32_t*)wk.d_submask, (int)j); }
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;

@@ -515,13 +515,198 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_rows_sub: row records for a PARTIAL-SPAN next layer without the DFS.  The reference aligns such a
+// layer to Graph::Subgraph(begin, end) (graph.cpp:640-732): everything that reaches nodes_[end]
+// backwards over in-edges and aligned links without passing a node id < begin.  VcGraph::ord restricted
+// to that set is a valid DP order of the subgraph (a restriction of a topological order, aligned groups
+// still contiguous), so only the membership is needed: a reverse sweep over ord in 64-position blocks,
+// every lane pulling from its out-neighbours / aligned mates, each block iterated to its fixed point
+// with ballots; repeated until nothing changes (groups straddling a block boundary).
+// LDS carve: member bits 8*nW | rowidx 2*NC | spill NC | node-id bitmap 4*(NC/32+1)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+                                                 uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t slot = blockIdx.x;
+    if (slot >= nslots) return;
+    const uint32_t w = w0 + slot;
+    if (b.status[w] != VC_WIN_OK) return;
+    const int lane = vc_lane();
+    const uint32_t s0 = b.win_seq_off[w], ns = b.win_seq_off[w + 1] - s0;
+    if ((uint32_t)next_layer >= ns) return;
+    const uint32_t L = (uint32_t)(b.seq_off[s0 + 1] - b.seq_off[s0]);
+    const uint32_t mb = b.seq_begin[s0 + next_layer], me = b.seq_end[s0 + next_layer];
+    if (vc_full_span(mb, me, L)) return;                       // k_rows' job
+    const uint32_t N = g.n_nodes[slot];
+    const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
+    if (me >= N || mb >= N) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 19, me); return; }
+    const uint32_t nW = (NC + 63) / 64;
+    unsigned long long* s_mem = (unsigned long long*)smem;                 // [nW] member bit per POSITION
+    uint16_t* s_rowidx = (uint16_t*)(s_mem + nW);                          // [NC] row of a member position
+    uint8_t* s_spill = (uint8_t*)(s_rowidx + NC);                          // [NC] by row
+    uint32_t* s_sub = (uint32_t*)(s_spill + ((NC + 15) & ~15u));           // [NC/32+1] member bit per NODE id
+    for (uint32_t i = lane; i < nW; i += 64) s_mem[i] = 0;
+    for (uint32_t i = lane; i < NC; i += 64) s_spill[i] = 0;
+    for (uint32_t i = lane; i < NC / 32 + 1; i += 64) s_sub[i] = 0;
+    __syncthreads();
+    auto is_mem = [&](uint32_t p) -> bool { return (s_mem[p >> 6] >> (p & 63)) & 1ull; };
+    // the sweep starts at the block holding the last position of end's aligned group
+    uint32_t ptop = g.pos[nb + me];
+    {
+        const uint32_t cnt = g.al_cnt[nb + me];
+        for (uint32_t t = 0; t < cnt; ++t) ptop = max(ptop, (uint32_t)g.pos[nb + g.al[(nb + me) * VC_MAXALN + t]]);
+    }
+    int guard = 0;
+    for (;;) {
+        int changed = 0;
+        for (int B = (int)(ptop >> 6); B >= 0; --B) {
+            const uint32_t p = (uint32_t)B * 64 + lane;
+            const bool act = p < N && p <= ptop;
+            const uint32_t v = act ? g.ord[nb + p] : 0;
+            const bool elig = act && v >= mb;
+            unsigned long long pull = 0;
+            bool ext = act && v == me;
+            if (elig) {
+                for (uint32_t e = g.out_first[nb + v]; e != VC_NONE16; ) {
+                    const uint32_t hn = g.e_hn[eb + e];
+                    e = hn >> 16;
+                    const uint32_t ph = g.pos[nb + (hn & 0xFFFF)];
+                    if ((ph >> 6) == (uint32_t)B) pull |= 1ull << (ph & 63);
+                    else if (ph <= ptop && is_mem(ph)) ext = true;
+                }
+                const uint32_t cnt = g.al_cnt[nb + v];
+                for (uint32_t t = 0; t < cnt; ++t) {
+                    const uint32_t pa = g.pos[nb + g.al[(nb + v) * VC_MAXALN + t]];
+                    if ((pa >> 6) == (uint32_t)B) pull |= 1ull << (pa & 63);
+                    else if (pa <= ptop && is_mem(pa)) ext = true;
+                }
+            }
+            const unsigned long long cur = s_mem[B];
+            unsigned long long M = cur;
+            for (;;) {
+                const unsigned long long M2 = __ballot(elig && (ext || (pull & M) != 0ull)) | M;
+                if (M2 == M) break;
+                M = M2;
+            }
+            if (M != cur) { if (lane == 0) s_mem[B] = M; changed = 1; }
+            __syncthreads();
+        }
+        if (!changed) break;
+        if (++guard > 64) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 20, 0); return; }
+    }
+    // compact: row index of every member position
+    uint32_t nrows = 0;
+    for (uint32_t B = 0; B <= (ptop >> 6); ++B) {
+        const unsigned long long M = s_mem[B];
+        const uint32_t p = B * 64 + lane;
+        if ((M >> lane) & 1ull) {
+            s_rowidx[p] = (uint16_t)(nrows + __popcll(M & ((1ull << lane) - 1ull)));
+            const uint32_t v = g.ord[nb + p];
+            atomicOr(&s_sub[v >> 5], 1u << (v & 31));
+        }
+        nrows += __popcll(M);
+    }
+    __syncthreads();
+    if (nrows == 0) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 21, 0); return; }
+    int bad = 0, broken = 0;
+    // pass 1: rows a far successor will need from HBM
+    for (uint32_t p = lane; p <= ptop && p < N; p += 64) {
+        if (!is_mem(p)) continue;
+        const uint32_t r = s_rowidx[p], v = g.ord[nb + p];
+        for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
+            const uint32_t tn = g.e_tn[eb + e];
+            e = tn >> 16;
+            const uint32_t pt = g.pos[nb + (tn & 0xFFFF)];
+            if (pt > ptop || !is_mem(pt)) continue;
+            const uint32_t rt = s_rowidx[pt];
+            if (rt >= r) broken = 1;
+            else if (r - rt > ring) s_spill[rt] = 1;
+        }
+    }
+    __syncthreads();
+    // pass 2: records, block by block in position order
+    uint32_t ovf_base = 0;
+    for (uint32_t B = 0; B <= (ptop >> 6); ++B) {
+        const uint32_t p = B * 64 + lane;
+        const bool act = p < N && p <= ptop && is_mem(p);
+        const uint32_t v = act ? g.ord[nb + p] : 0, r = act ? s_rowidx[p] : 0;
+        uint32_t np = 0;
+        uint16_t dl[VC_INLINE_PRED];
+#pragma unroll
+        for (int k = 0; k < VC_INLINE_PRED; ++k) dl[k] = 0;
+        if (act) {
+            for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
+                const uint32_t tn = g.e_tn[eb + e];
+                e = tn >> 16;
+                const uint32_t pt = g.pos[nb + (tn & 0xFFFF)];
+                if (pt > ptop || !is_mem(pt)) continue;
+                const uint32_t delta = r - s_rowidx[pt];
+#pragma unroll
+                for (int k = 0; k < VC_INLINE_PRED; ++k) if (np == (uint32_t)k) dl[k] = (uint16_t)delta;
+                np++;
+            }
+        }
+        const bool is_ovf = np > VC_INLINE_PRED;
+        uint32_t tot_ovf;
+        const uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
+        if (act) {
+            if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }
+            if (np > 255) bad = 1;
+            if (is_ovf) {
+                if (my_ovf + np > EC) bad = 1;
+                else {
+                    uint32_t k = 0;
+                    for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
+                        const uint32_t tn = g.e_tn[eb + e];
+                        e = tn >> 16;
+                        const uint32_t pt = g.pos[nb + (tn & 0xFFFF)];
+                        if (pt > ptop || !is_mem(pt)) continue;
+                        dp.ovf[eb + my_ovf + k] = (uint16_t)(r - s_rowidx[pt]);
+                        k++;
+                    }
+                }
+                dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
+            }
+            bool hasout = false;                                // a sink of the subgraph has no member successor
+            for (uint32_t e = g.out_first[nb + v]; e != VC_NONE16 && !hasout; ) {
+                const uint32_t hn = g.e_hn[eb + e];
+                e = hn >> 16;
+                const uint32_t ph = g.pos[nb + (hn & 0xFFFF)];
+                hasout = ph <= ptop && is_mem(ph);
+            }
+            const uint32_t sp_flag = s_spill[r];
+            const uint32_t fl = (hasout ? 0u : VC_RF_SINK) | (sp_flag ? VC_RF_SPILL : 0u) | (is_ovf ? VC_RF_OVF : 0u);
+            uint4 rec;
+            rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
+            rec.y = dl[0] | ((uint32_t)dl[1] << 16);
+            rec.z = dl[2] | ((uint32_t)dl[3] << 16);
+            rec.w = dl[4] | ((uint32_t)dl[5] << 16);
+            dp.rec[nb + r] = rec;
+            dp.spill_slot[nb + r] = VC_NONE16;
+            dp.rank2node[nb + r] = (uint16_t)v;
+        }
+        ovf_base += tot_ovf;
+    }
+    for (uint32_t i = lane; i < NC / 32 + 1; i += 64) submask[(uint64_t)slot * (NC / 32 + 1) + i] = s_sub[i];
+    bad = __any(bad);
+    broken = __any(broken);
+    if (broken) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 22, 0); return; }
+    if (lane == 0) {
+        dp.nrows[slot] = nrows;
+        dp.flags[slot] = (bad ? 1u : 0u) | 2u | 4u;            // incremental order, masked
+        if (bad) b.errinfo[w] = (23u << 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_resolve: the reference picks, among sinks with the same best end score, the first in ITS rank
 // order (sisd :353-355 with `<`).  For alignments done on the incremental order and ending in such a
 // tie, run the exact TopologicalSort DFS now and choose the tied sink with the smallest rank.
 // ------------------------------------------------------------------------------------------------
 __device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b, const VcGraph& g, const VcDp& dp,
                                uint32_t w0, uint32_t nslots, uint32_t NC, uint32_t EC, uint32_t STK,
-                               const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end) {
+                               const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end,
+                               const uint32_t* submask, int layer) {
     if (slot >= nslots) return;
     const uint32_t w = w0 + slot;
     const uint32_t nt = tie_cnt[slot];
@@ -530,6 +715,10 @@ __device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b
     const int lane = vc_lane();
     const uint32_t N = g.n_nodes[slot], E = g.n_edges[slot];
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
+    // alignment to a Subgraph: every rule below applies to the induced subgraph (its own DFS, roots in id order)
+    const bool masked = (dp.flags[slot] & 4u) != 0;
+    const uint32_t* sub = submask + (uint64_t)slot * (NC / 32 + 1);
+    auto in_sub = [&](uint32_t v) -> bool { return !masked || ((sub[v >> 5] >> (v & 31)) & 1u); };
 
     // ---- shortcut that settles most ties without the DFS.  The reference's DFS takes roots in id order
     // and, from a root, reaches everything upstream of it through in-edges and aligned links; an aligned
@@ -552,7 +741,10 @@ __device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b
                 node[k] = dp.rank2node[nb + row[k] - 1];
                 uint32_t gm = node[k];
                 const uint32_t cnt = g.al_cnt[nb + node[k]];
-                for (uint32_t t2 = 0; t2 < cnt; ++t2) gm = min(gm, (uint32_t)g.al[(nb + node[k]) * VC_MAXALN + t2]);
+                for (uint32_t t2 = 0; t2 < cnt; ++t2) {
+                    const uint32_t mnode = g.al[(nb + node[k]) * VC_MAXALN + t2];
+                    if (in_sub(mnode)) gm = min(gm, mnode);
+                }
                 gid[k] = gm; rmin[k] = 0xFFFFFFFFu; lead[k] = false;
             }
             for (uint32_t k = 0; k < nt && ok; ++k) {
@@ -562,6 +754,7 @@ __device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b
                 // forward closure of the group
                 uint32_t sp = 0, visited = 0, mn = 0xFFFFFFFFu;
                 auto push = [&](uint32_t v) {
+                    if (!in_sub(v)) return;
                     if (s_vis[v >> 5] & (1u << (v & 31))) return;
                     s_vis[v >> 5] |= 1u << (v & 31);
                     if (sp < 256) s_stk[sp++] = (uint16_t)v; else ok = false;
@@ -583,7 +776,7 @@ __device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b
                 // is the smallest id a member of the group?
                 bool member = mn == node[k];
                 const uint32_t cnt = g.al_cnt[nb + node[k]];
-                for (uint32_t t2 = 0; t2 < cnt; ++t2) member = member || mn == g.al[(nb + node[k]) * VC_MAXALN + t2];
+                for (uint32_t t2 = 0; t2 < cnt; ++t2) member = member || mn == g.al[(nb + node[k]) * VC_MAXALN + t2];   // mn is in the subgraph
                 lead[k] = member;
                 // groups are disjoint and closures of different tied groups must not share the bitmap
                 for (uint32_t i2 = 0; i2 < (N + 31) / 32; ++i2) s_vis[i2] = 0;
@@ -626,7 +819,9 @@ __device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b
     __shared__ int s_err;
     if (lane == 0) {
         uint32_t nr = 0;
-        s_err = vc_topo_dfs(t, N, STK, false, 0, 0, &nr);
+        uint32_t mb = 0, me = 0;
+        if (masked) { const uint32_t s0 = b.win_seq_off[w]; mb = b.seq_begin[s0 + layer]; me = b.seq_end[s0 + layer]; }
+        s_err = vc_topo_dfs(t, N, STK, masked, mb, me, &nr);
         s_nrows = nr;
     }
     __syncthreads();
@@ -650,12 +845,13 @@ __device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b
 __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                                 uint32_t NC, uint32_t EC, uint32_t STK,
                                                 const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end,
-                                                const uint32_t* tie_list, const uint32_t* tie_n) {
+                                                const uint32_t* tie_list, const uint32_t* tie_n,
+                                                const uint32_t* submask, int layer) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t n = *tie_n;
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
         __syncthreads();
-        vc_resolve_one(smem, tie_list[idx], b, g, dp, w0, nslots, NC, EC, STK, tie_rows, tie_cnt, job_end);
+        vc_resolve_one(smem, tie_list[idx], b, g, dp, w0, nslots, NC, EC, STK, tie_rows, tie_cnt, job_end, submask, layer);
     }
 }
 
