@@ -90,8 +90,7 @@ typedef struct vc_stats {
     uint64_t cells;          /* sum over Align calls of graph_nodes * sequence_len  */
     uint64_t alignments;
     uint64_t dp_rows;
-    uint64_t spilled_rows;   /* DP rows parked in HBM for successors beyond the LDS ring             */
-    uint64_t far_row_reads;  /* predecessor rows fetched back from HBM                                */
+    uint64_t far_row_reads;  /* predecessor rows older than the LDS ring, read back from the H matrix */
     uint32_t n_classes;      /* kernel classes below                                            */
     double   ms[16];         /* accumulated HIP-event time per kernel class (profile=1)         */
     uint64_t launches[16];

@@ -79,7 +79,7 @@ struct vc_ctx {
     std::vector<uint32_t> h_cons_len;
     std::vector<uint8_t> h_status;
     uint32_t* d_lut_w = nullptr; double* d_lut_d = nullptr;
-    unsigned long long* d_stat = nullptr;   // [4] cells, rows, spilled rows, far-row reads
+    unsigned long long* d_stat = nullptr;   // [4] cells, rows, -, far-row reads
 
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
@@ -159,7 +159,6 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rec, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->dp.spill_slot, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_c0, (size_t)c->jobs_cap * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_end, c->jobs_cap)) ||
@@ -789,7 +788,7 @@ int vc_get_stats(vc_ctx* c, vc_stats* s) {
     unsigned long long st[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpy(st, c->d_stat, 32, hipMemcpyDeviceToHost));
     c->stats.cells = st[0]; c->stats.dp_rows = st[1];
-    c->stats.spilled_rows = st[2]; c->stats.far_row_reads = st[3];
+    c->stats.far_row_reads = st[3];
     c->stats.alignments = c->stats.launches[KC_FWD];
     c->stats.n_streams = c->n_streams;
     *s = c->stats;

@@ -14,23 +14,12 @@
 
 #define VC_NONE16   0xFFFFu
 #define VC_MAXALN   4          // aligned group <= 5 members (A,C,G,T,N)
-#define VC_SPILLCAP 256        // rows per alignment that may be parked in HBM for far successors
 #define VC_INLINE_PRED 6       // predecessors stored inline in a row record
 #define VC_MAXTIE   16         // NW end-cell ties remembered for the exact-rank resolver
 
-// dir-code byte written by the forward DP, read by the traceback
-//   bits 7:6 kind (3 diagonal, 2 vertical, 1 horizontal, 0 stop): a larger kind wins a score tie,
-//            which is the order the reference's backtrack tries the moves in
-//   bits 5:0 payload: < 48 -> predecessor row = row - (payload+1); >= 48 -> predecessor list index payload-48
-#define VC_K_DIAG 3u
-#define VC_K_VERT 2u
-#define VC_K_HORZ 1u
-#define VC_K_STOP 0u
-#define VC_PAYLOAD_NEAR 48u
-
 // row record flags
 #define VC_RF_SINK  1u
-#define VC_RF_SPILL 2u
+#define VC_RF_SPILL 2u     // a successor lies beyond the LDS ring and will read this row back from the H matrix
 #define VC_RF_OVF   4u
 
 struct VcGraph {
@@ -61,7 +50,6 @@ struct VcDp {
     uint4*    rec;        // [CW*NC]
     uint16_t* rank2node;  // [CW*NC]
     uint16_t* ovf;        // [CW*EC]
-    uint16_t* spill_slot; // [CW*NC]
 };
 
 struct VcBatchDev {

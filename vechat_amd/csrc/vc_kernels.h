@@ -339,8 +339,8 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         }
     }
     __syncthreads();
-    // pass 2: records, overflow lists, spill slots
-    uint32_t ovf_base = 0, spill_base = 0;
+    // pass 2: records, overflow lists
+    uint32_t ovf_base = 0;
     int bad = 0;
     for (uint32_t r0 = 0; r0 < nrows; r0 += 64) {
         uint32_t r = r0 + lane;
@@ -366,8 +366,6 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         uint32_t tot_ovf;
         uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
         uint32_t sp_flag = act ? s_spill[r] : 0u;
-        uint32_t tot_sp;
-        uint32_t my_sp = wave_excl_sum(sp_flag, tot_sp) + spill_base;
         if (act) {
             if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }   // virtual row 0 is `row` rows above
             if (np > 255) bad = 1;
@@ -394,16 +392,14 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             dp.rec[nb + r] = rec;
-            dp.spill_slot[nb + r] = sp_flag ? (uint16_t)my_sp : VC_NONE16;
         }
         ovf_base += tot_ovf;
-        spill_base += tot_sp;
     }
     bad = __any(bad);
     if (lane == 0) {
         dp.nrows[slot] = nrows;
         dp.flags[slot] = bad ? 1u : 0u;
-        if (bad) b.errinfo[w] = (11u << 16) | (spill_base & 0xFFFF);
+        if (bad) b.errinfo[w] = (11u << 16) | (ovf_base & 0xFFFF);
     }
 }
 
@@ -448,7 +444,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
     }
     __syncthreads();
     // pass 2: records
-    uint32_t ovf_base = 0, spill_base = 0;
+    uint32_t ovf_base = 0;
     for (uint32_t r0 = 0; r0 < N; r0 += 64) {
         const uint32_t r = r0 + lane;
         const bool act = r < N;
@@ -471,8 +467,6 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
         uint32_t tot_ovf;
         const uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
         const uint32_t sp_flag = act ? s_spill[r] : 0u;
-        uint32_t tot_sp;
-        const uint32_t my_sp = wave_excl_sum(sp_flag, tot_sp) + spill_base;
         if (act) {
             if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }
             if (np > 255) bad = 1;
@@ -498,11 +492,9 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             dp.rec[nb + r] = rec;
-            dp.spill_slot[nb + r] = sp_flag ? (uint16_t)my_sp : VC_NONE16;
             dp.rank2node[nb + r] = (uint16_t)v;
         }
         ovf_base += tot_ovf;
-        spill_base += tot_sp;
     }
     bad = __any(bad);
     broken = __any(broken);
@@ -510,7 +502,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
     if (lane == 0) {
         dp.nrows[slot] = N;
         dp.flags[slot] = (bad ? 1u : 0u) | 2u;
-        if (bad) b.errinfo[w] = (13u << 16) | (spill_base & 0xFFFF);
+        if (bad) b.errinfo[w] = (13u << 16) | (ovf_base & 0xFFFF);
     }
 }
 
@@ -682,7 +674,6 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             dp.rec[nb + r] = rec;
-            dp.spill_slot[nb + r] = VC_NONE16;
             dp.rank2node[nb + r] = (uint16_t)v;
         }
         ovf_base += tot_ovf;
