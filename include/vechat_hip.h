@@ -91,6 +91,9 @@ typedef struct vc_stats {
     uint64_t alignments;
     uint64_t dp_rows;
     uint64_t far_row_reads;  /* predecessor rows older than the LDS ring, read back from the H matrix */
+    uint64_t trace_steps;    /* backtrack moves emitted                                               */
+    uint64_t trace_spec;     /* ... of which confirmed in bulk by the first-in-edge speculation       */
+    uint64_t trace_rounds;   /* speculation rounds (each: one batch of loads)                         */
     uint32_t n_classes;      /* kernel classes below                                            */
     double   ms[16];         /* accumulated HIP-event time per kernel class (profile=1)         */
     uint64_t launches[16];

@@ -56,7 +56,7 @@ class VcResult(C.Structure):
 class VcStats(C.Structure):
     _fields_ = [
         ("cells", C.c_uint64), ("alignments", C.c_uint64), ("dp_rows", C.c_uint64),
-        ("far_row_reads", C.c_uint64),
+        ("far_row_reads", C.c_uint64), ("trace_steps", C.c_uint64), ("trace_spec", C.c_uint64), ("trace_rounds", C.c_uint64),
         ("n_classes", C.c_uint32),
         ("ms", C.c_double * 16),
         ("launches", C.c_uint64 * 16),

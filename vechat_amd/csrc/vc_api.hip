@@ -79,10 +79,11 @@ struct vc_ctx {
     std::vector<uint32_t> h_cons_len;
     std::vector<uint8_t> h_status;
     uint32_t* d_lut_w = nullptr; double* d_lut_d = nullptr;
-    unsigned long long* d_stat = nullptr;   // [4] cells, rows, -, far-row reads
+    unsigned long long* d_stat = nullptr;   // [8] cells, rows, -, far-row reads, trace steps, speculated steps, rounds, -
 
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
+    bool trace_wave = true;
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
 
@@ -157,6 +158,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
     if ((rc = alloc_graph(c, &wk->gr[0])) || (rc = alloc_graph(c, &wk->gr[1]))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &wk->dp.nrows, CW)) || (rc = dalloc(c, c->chunk_allocs, &wk->dp.flags, CW)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rec, CW * NC)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->dp.frec, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
@@ -301,7 +303,7 @@ struct Plan {
         ta.b = c->b; ta.dp = wk.dp; ta.w0 = wk.w0; ta.nslots = wk.ns; ta.NC = NC; ta.EC = EC; ta.cpl = cpl;
         ta.m = c->prm.match; ta.n = c->prm.mismatch; ta.g = c->prm.gap;
         ta.sm = c->prm.sw_match; ta.sn = c->prm.sw_mismatch; ta.sg = c->prm.sw_gap;
-        ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC;
+        ta.stat = c->d_stat; ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC;
         return ta;
     }
 
@@ -340,7 +342,9 @@ struct Plan {
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
-        { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
+        { Timer t(c, KC_TRACE, wk.stream);
+          if (c->trace_wave) hipLaunchKernelGGL(k_tracew, dim3(ns), dim3(64), vc_tracew_lds_bytes(NC), wk.stream, ta);
+          else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
         aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16;
@@ -387,7 +391,9 @@ struct Plan {
             if (rc) return rc;
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
-            { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
+            { Timer t(c, KC_TRACE, wk.stream);
+          if (c->trace_wave) hipLaunchKernelGGL(k_tracew, dim3(ns * gsz), dim3(64), vc_tracew_lds_bytes(NC), wk.stream, ta);
+          else hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         }
         VcAddwArgs wa{};
         wa.b = c->b; wa.g = wk.gr[wk.cur]; wa.dp = wk.dp; wa.w0 = wk.w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
@@ -419,7 +425,9 @@ struct Plan {
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
-        { Timer t(c, KC_TRACE, wk.stream); hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
+        { Timer t(c, KC_TRACE, wk.stream);
+          if (c->trace_wave) hipLaunchKernelGGL(k_tracew, dim3(ns), dim3(64), vc_tracew_lds_bytes(NC), wk.stream, ta);
+          else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcFinishArgs fn{};
         fn.b = c->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;
         fn.pairs = wk.d_pairs; fn.npairs = wk.d_npairs; fn.PC = PC;
@@ -455,6 +463,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->prm = *p;
     c->device = p->device;
     c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 2;
+    c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }
     for (uint32_t s = 0; s < c->n_streams; ++s) {
         if (hipStreamCreateWithFlags(&c->streams[s], hipStreamNonBlocking) != hipSuccess) {
@@ -469,7 +478,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     uint32_t lw[256]; double ld[256];
     vc_weight_lut(lw);
     for (int ch = 0; ch < 256; ++ch) ld[ch] = 1 - pow(10, (33 - (int)(signed char)ch) / 10.0);
-    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, 4)) {
+    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, 8)) {
         g_create_error = c->err; vc_destroy(c); return VC_ERR_HIP;
     }
     (void)hipMemcpy(c->d_lut_w, lw, sizeof(lw), hipMemcpyHostToDevice);
@@ -646,7 +655,7 @@ int vc_run(vc_ctx* c) {
     HIPCHK(c, hipFuncSetAttribute((const void*)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.topo_lds));
     if (c->prm.mode == 1)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.cons_lds));
-    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 32, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
     HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, (size_t)b.n_windows * 4, c->stream));
@@ -785,10 +794,11 @@ int vc_debug_errinfo(vc_ctx* c, uint32_t* out) {
 int vc_get_stats(vc_ctx* c, vc_stats* s) {
     if (!c || !s) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    unsigned long long st[4] = {0, 0, 0, 0};
-    HIPCHK(c, hipMemcpy(st, c->d_stat, 32, hipMemcpyDeviceToHost));
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(c, hipMemcpy(st, c->d_stat, 64, hipMemcpyDeviceToHost));
     c->stats.cells = st[0]; c->stats.dp_rows = st[1];
     c->stats.far_row_reads = st[3];
+    c->stats.trace_steps = st[4]; c->stats.trace_spec = st[5]; c->stats.trace_rounds = st[6];
     c->stats.alignments = c->stats.launches[KC_FWD];
     c->stats.n_streams = c->n_streams;
     *s = c->stats;

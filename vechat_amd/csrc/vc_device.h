@@ -21,6 +21,8 @@
 #define VC_RF_SINK  1u
 #define VC_RF_SPILL 2u     // a successor lies beyond the LDS ring and will read this row back from the H matrix
 #define VC_RF_OVF   4u
+#define VC_RF_PREV  8u     // one of the predecessors is the row directly above (still in registers)
+#define VC_RF_SLOW  16u    // frec only: a listed predecessor is the virtual row 0 or lies beyond the LDS ring, or the list overflowed
 
 struct VcGraph {
     uint32_t* n_nodes;    // [CW]
@@ -48,6 +50,7 @@ struct VcDp {
     uint32_t* nrows;      // [CW]
     uint32_t* flags;      // [CW] bit0: outside the kernel envelope; bit1: rows follow VcGraph::ord, not the reference's rank
     uint4*    rec;        // [CW*NC]
+    uint4*    frec;       // [CW*NC] the forward kernel's view of the same row (see vc_make_frec)
     uint16_t* rank2node;  // [CW*NC]
     uint16_t* ovf;        // [CW*EC]
 };

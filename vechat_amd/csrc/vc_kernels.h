@@ -19,6 +19,10 @@
 #include "vechat_hip.h"
 
 #define VC_INT_MIN (-2147483647 - 1)
+// The latency-bound single-lane kernels of one chunk run next to the throughput-bound k_fwd of another
+// chunk (separate streams).  The CU issues the oldest ready wave first, which starves them; raising the
+// wave priority lets their few instructions through at once and costs k_fwd almost nothing.
+#define VC_LATENCY_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
 
 __device__ __forceinline__ int vc_lane() { return (int)(threadIdx.x & 63); }
 
@@ -68,10 +72,50 @@ __device__ __forceinline__ bool vc_full_span(uint32_t begin, uint32_t end, uint3
     return begin < offset && end > L - offset;              // window.cpp:253-254
 }
 
+// The forward kernel's view of a row (16 B): byte0 code, byte1 flags, byte2 number of listed predecessors,
+// byte3 base index (0..3 = ACGT, 4 = other), then up to 6 x u16 row distances of the predecessors OTHER than
+// the row directly above (that one is flagged VC_RF_PREV and taken from registers).  The order of the
+// in-edges does not matter to the forward pass.  VC_RF_SLOW marks rows whose list needs the general path:
+// the virtual row 0, a row older than the LDS ring, or more predecessors than fit (list in VcDp::ovf).
+__device__ __forceinline__ uint4 vc_make_frec(uint32_t code, uint32_t fl, uint32_t np, const uint16_t (&dl)[VC_INLINE_PRED],
+                                              bool is_ovf, bool hasprev, uint32_t r, uint32_t ring) {
+    uint32_t f = fl & (VC_RF_SINK | VC_RF_SPILL | VC_RF_OVF);
+    uint16_t out[VC_INLINE_PRED];
+#pragma unroll
+    for (int k = 0; k < VC_INLINE_PRED; ++k) out[k] = 0;
+    uint32_t nq = 0;
+    bool slow = is_ovf;
+    if (hasprev) f |= VC_RF_PREV;
+    if (is_ovf) {
+        out[0] = dl[0]; out[1] = dl[1];                      // offset into VcDp::ovf
+        nq = np;
+    } else {
+#pragma unroll
+        for (int k = 0; k < VC_INLINE_PRED; ++k) {
+            if ((uint32_t)k < np && !(hasprev && dl[k] == 1)) {
+                const uint32_t d = dl[k];
+#pragma unroll
+                for (int t = 0; t < VC_INLINE_PRED; ++t) if (nq == (uint32_t)t) out[t] = (uint16_t)d;
+                nq++;
+                if (d > ring || d == r + 1) slow = true;
+            }
+        }
+    }
+    if (slow) f |= VC_RF_SLOW;
+    const uint32_t bi = code == 'A' ? 0u : code == 'C' ? 1u : code == 'G' ? 2u : code == 'T' ? 3u : 4u;
+    uint4 o;
+    o.x = code | (f << 8) | (nq << 16) | (bi << 24);
+    o.y = out[0] | ((uint32_t)out[1] << 16);
+    o.z = out[2] | ((uint32_t)out[3] << 16);
+    o.w = out[4] | ((uint32_t)out[5] << 16);
+    return o;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_avg: average_weight per window -- a strictly ordered fp64 sum (window.cpp:225-236,283,292-309)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_avg(VcBatchDev b, uint32_t w0, uint32_t nw) {
+    VC_LATENCY_KERNEL_PRIO();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nw) return;
     uint32_t w = w0 + t;
@@ -276,6 +320,7 @@ __device__ int vc_topo_dfs(const VcTopoLds& ls, uint32_t N, uint32_t STK, bool m
 
 __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                              uint32_t NC, uint32_t EC, uint32_t STK, int next_layer, int only_masked, uint32_t ring) {
+    VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t slot = blockIdx.x;
     if (slot >= nslots) return;
@@ -347,6 +392,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         bool act = r < nrows;
         uint32_t v = act ? s_rank[r] : 0;
         uint32_t np = 0;
+        bool hasprev = false;
         uint16_t dl[VC_INLINE_PRED];
 #pragma unroll
         for (int k = 0; k < VC_INLINE_PRED; ++k) dl[k] = 0;
@@ -360,6 +406,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
 #pragma unroll
                 for (int k = 0; k < VC_INLINE_PRED; ++k) if (np == (uint32_t)k) dl[k] = (uint16_t)delta;
                 np++;
+                hasprev |= delta == 1;
             }
         }
         bool is_ovf = np > VC_INLINE_PRED;
@@ -385,13 +432,14 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
                 }
                 dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
             }
-            uint32_t fl = (s_hasout[v] ? 0u : VC_RF_SINK) | (sp_flag ? VC_RF_SPILL : 0u) | (is_ovf ? VC_RF_OVF : 0u);
+            uint32_t fl = (s_hasout[v] ? 0u : VC_RF_SINK) | (sp_flag ? VC_RF_SPILL : 0u) | (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
             uint4 rec;
             rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
             rec.y = dl[0] | ((uint32_t)dl[1] << 16);
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             dp.rec[nb + r] = rec;
+            dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl, is_ovf, hasprev, r, ring);
         }
         ovf_base += tot_ovf;
     }
@@ -413,6 +461,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                              uint32_t NC, uint32_t EC, int next_layer, uint32_t ring) {
+    VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_spill = smem;                                  // [NC] by row
     const uint32_t slot = blockIdx.x;
@@ -450,6 +499,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
         const bool act = r < N;
         const uint32_t v = act ? g.ord[nb + r] : 0;
         uint32_t np = 0;
+        bool hasprev = false;
         uint16_t dl[VC_INLINE_PRED];
 #pragma unroll
         for (int k = 0; k < VC_INLINE_PRED; ++k) dl[k] = 0;
@@ -461,6 +511,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
 #pragma unroll
                 for (int k = 0; k < VC_INLINE_PRED; ++k) if (np == (uint32_t)k) dl[k] = (uint16_t)delta;
                 np++;
+                hasprev |= delta == 1;
             }
         }
         const bool is_ovf = np > VC_INLINE_PRED;
@@ -485,13 +536,14 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
                 dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
             }
             const uint32_t fl = (g.out_first[nb + v] == VC_NONE16 ? VC_RF_SINK : 0u) | (sp_flag ? VC_RF_SPILL : 0u) |
-                                (is_ovf ? VC_RF_OVF : 0u);
+                                (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
             uint4 rec;
             rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
             rec.y = dl[0] | ((uint32_t)dl[1] << 16);
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             dp.rec[nb + r] = rec;
+            dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl, is_ovf, hasprev, r, ring);
             dp.rank2node[nb + r] = (uint16_t)v;
         }
         ovf_base += tot_ovf;
@@ -518,6 +570,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                                  uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask) {
+    VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t slot = blockIdx.x;
     if (slot >= nslots) return;
@@ -623,6 +676,7 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
         const bool act = p < N && p <= ptop && is_mem(p);
         const uint32_t v = act ? g.ord[nb + p] : 0, r = act ? s_rowidx[p] : 0;
         uint32_t np = 0;
+        bool hasprev = false;
         uint16_t dl[VC_INLINE_PRED];
 #pragma unroll
         for (int k = 0; k < VC_INLINE_PRED; ++k) dl[k] = 0;
@@ -636,6 +690,7 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
 #pragma unroll
                 for (int k = 0; k < VC_INLINE_PRED; ++k) if (np == (uint32_t)k) dl[k] = (uint16_t)delta;
                 np++;
+                hasprev |= delta == 1;
             }
         }
         const bool is_ovf = np > VC_INLINE_PRED;
@@ -667,13 +722,14 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
                 hasout = ph <= ptop && is_mem(ph);
             }
             const uint32_t sp_flag = s_spill[r];
-            const uint32_t fl = (hasout ? 0u : VC_RF_SINK) | (sp_flag ? VC_RF_SPILL : 0u) | (is_ovf ? VC_RF_OVF : 0u);
+            const uint32_t fl = (hasout ? 0u : VC_RF_SINK) | (sp_flag ? VC_RF_SPILL : 0u) | (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
             uint4 rec;
             rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
             rec.y = dl[0] | ((uint32_t)dl[1] << 16);
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             dp.rec[nb + r] = rec;
+            dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl, is_ovf, hasprev, r, ring);
             dp.rank2node[nb + r] = (uint16_t)v;
         }
         ovf_base += tot_ovf;
@@ -838,6 +894,7 @@ __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp
                                                 const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end,
                                                 const uint32_t* tie_list, const uint32_t* tie_n,
                                                 const uint32_t* submask, int layer) {
+    VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t n = *tie_n;
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
@@ -907,9 +964,68 @@ __device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xFFFF
 __device__ __forceinline__ int pk_lo(uint32_t a) { return (int)(short)(a & 0xFFFF); }
 __device__ __forceinline__ int pk_hi(uint32_t a) { return (int)a >> 16; }
 
+// Stored form of a DP row.  Along a row the tilted scores never decrease and two neighbours differ by at
+// most max(m, n) - 2g (diagonal vs the vertical-then-horizontal detour), so when that bound fits a nibble
+// (it is 11 for the scores VeChat uses) a lane's CPL cells are kept as one absolute int16 (its first cell)
+// plus CPL-1 four-bit steps: word 0 = first cell | step_1 << 16; word 1+t holds the step pairs
+// q = 1+4t .. 4+4t (cells 2q, 2q+1) as (step_2q << 4u) | (step_2q+1 << (16 + 4u)), u = q-1-4t.
+// That is 8 bytes per lane per row for 6..12 cells per lane instead of 2 bytes per cell -- the kernel is
+// bound by HBM write bandwidth, not by VALU.  Other score sets keep raw packed int16 pairs.
+__host__ __device__ constexpr int vc_nds(int cpl) { return 1 + (cpl / 2 - 1 + 3) / 4; }
+__host__ __device__ inline bool vc_row_packed(int m, int n, int g) { return g < 0 && (m > n ? m : n) - 2 * g <= 15; }
+
+template <int ND, int NDS>
+__device__ __forceinline__ void vc_pack_row(const uint32_t (&T)[ND], uint32_t (&w)[NDS]) {
+    w[0] = pk_sub(T[0], T[0] << 16);
+#pragma unroll
+    for (int q = 1; q < ND; ++q) {
+        const uint32_t e = pk_sub(T[q], __builtin_amdgcn_alignbit(T[q], T[q - 1], 16));
+        const int t = (q - 1) / 4, u = (q - 1) & 3;
+        w[1 + t] = u == 0 ? e : ((e << (4 * u)) | w[1 + t]);
+    }
+}
+template <int ND, int NDS>
+__device__ __forceinline__ void vc_unpack_row(const uint32_t (&w)[NDS], uint32_t (&T)[ND]) {
+    uint32_t c = w[0] & 0xFFFFu;
+    uint32_t d = c + ((w[0] >> 16) & 15u);
+    T[0] = c | (d << 16);
+#pragma unroll
+    for (int q = 1; q < ND; ++q) {
+        const int t = (q - 1) / 4, u = (q - 1) & 3;
+        c = d + ((w[1 + t] >> (4 * u)) & 15u);
+        d = c + ((w[1 + t] >> (16 + 4 * u)) & 15u);
+        T[q] = (c & 0xFFFFu) | (d << 16);
+    }
+}
+// one cell of a packed row (k_trace): words of the lane that owns the cell, cell index cc inside the lane
+__device__ __forceinline__ int vc_packed_cell(const uint32_t* w, uint32_t cc) {
+    const uint32_t w0 = w[0], w1 = w[1];                      // both unconditional: one round trip
+    int v = (int)(short)(w0 & 0xFFFFu);
+    if (cc >= 1) v += (int)((w0 >> 16) & 15u);
+    if (cc >= 2) {
+        const uint32_t ne = cc >> 1, no = (cc - 1) >> 1;      // pairs whose even / odd cell is <= cc
+        for (uint32_t t = 0; 4 * t < ne; ++t) {
+            const uint32_t ae = min(ne - 4 * t, 4u), ao = no > 4 * t ? min(no - 4 * t, 4u) : 0u;
+            const uint32_t mask = ((1u << (4 * ae)) - 1u) | (((1u << (4 * ao)) - 1u) << 16);
+            const uint32_t x = (t == 0 ? w1 : w[1 + t]) & mask;
+            const uint32_t y = (x & 0x0F0F0F0Fu) + ((x >> 4) & 0x0F0F0F0Fu);
+            v += (int)((y * 0x01010101u) >> 24);
+        }
+    }
+    return v;
+}
+
+// The forward DP works on the TILTED matrix T[i][j] = H[i][j] - j*g.  In that domain the horizontal
+// pass of sisd :347-349 is a plain prefix maximum (T[i][j] = max(T[i][j], T[i][j-1])), the vertical move
+// adds g, and the diagonal move adds (P[c][j] - g) -- folded into the profile once.  Since the row's
+// profile and g do not depend on the predecessor,
+//     max_p (H[p][j-1] + P[j]) = (max_p H[p][j-1]) + P[j],   max_p (H[p][j] + g) = (max_p H[p][j]) + g,
+// so each additional in-edge costs one packed max per register instead of a full relaxation, and the
+// order of the in-edges is irrelevant here (it matters only to the backtrack, which follows it).
 template <int CPL, int RING>
-__device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_raw, int* ring_c0) {
+__device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_raw) {
     constexpr int ND = CPL / 2;              // packed int16 dwords per lane per row
+    constexpr int NDS = vc_nds(CPL);         // dwords per lane per row in the packed stored form
     uint32_t (*ring)[ND][64] = reinterpret_cast<uint32_t (*)[ND][64]>(ring_raw);
     const int lane = vc_lane();
     const uint32_t job = blockIdx.x;
@@ -932,7 +1048,9 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     const uint32_t nrows = a.dp.nrows[slot];
     const uint64_t nb = (uint64_t)slot * a.NC;
     // envelope: the reference's int16 condition (simd impl:699-706) on the real length, plus headroom
-    // for H - j*g and for the cells this kernel computes beyond the sequence end
+    // for H - j*g and for the cells this kernel computes beyond the sequence end.  The SW end-cell rule
+    // below also relies on negative mismatch / gap scores (cells past the sequence end can then never
+    // strictly exceed the best real cell).
     {
         long long li = (long long)len + 8, lj = nrows;
         long long d = li > lj ? li - lj : lj - li, mn = li < lj ? li : lj;
@@ -940,7 +1058,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         long long wc2 = (long long)g * li + (long long)g * lj;
         long long wc = wc1 < wc2 ? wc1 : wc2;
         bool ok = wc >= -31744 && ((long long)(m - g) * (64 * CPL + 1) < 32767) && len <= 64u * CPL && len > 0 &&
-                  nrows > 0 && !(a.dp.flags[slot] & 1u);
+                  nrows > 0 && !(a.dp.flags[slot] & 1u) && g < 0 && (nw || n < 0);
         if (!ok) {
             if (lane == 0) vc_fail(a.b, w, (len == 0 || nrows == 0) ? VC_WIN_INVALID : VC_WIN_UNSUPPORTED, 3, (a.dp.flags[slot] & 1u) ? 1 : 2);
             return;
@@ -952,154 +1070,181 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         atomicAdd(a.stat + 1, (unsigned long long)nrows);
     }
 
-    // match/mismatch profile of my columns for the four usual bases (packed pairs); other row bytes are
-    // compared on the fly.  Columns beyond the sequence end never match.
+    // tilted match/mismatch profile (score - g) of my columns for the four usual bases (packed pairs);
+    // other row bytes are compared on the fly.  Columns beyond the sequence end never match.
     uint32_t pfA[ND], pfC[ND], pfG[ND], pfT[ND], sbp[ND];
+    const int mt = m - g, nt = n - g;
 #pragma unroll
     for (int q = 0; q < ND; ++q) {
         const uint32_t i0 = lane * CPL + 2 * q, i1 = i0 + 1;
         const uint32_t b0 = i0 < len ? a.b.bases[so + i0] : 0xFFu;
         const uint32_t b1 = i1 < len ? a.b.bases[so + i1] : 0xFFu;
         sbp[q] = b0 | (b1 << 16);
-        auto sc = [&](uint32_t x) { return ((uint32_t)((b0 == x) ? m : n) & 0xFFFFu) | ((uint32_t)((b1 == x) ? m : n) << 16); };
+        auto sc = [&](uint32_t x) { return ((uint32_t)((b0 == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)((b1 == x) ? mt : nt) << 16); };
         pfA[q] = sc('A'); pfC[q] = sc('C'); pfG[q] = sc('G'); pfT[q] = sc('T');
     }
     const uint32_t gg = pk_dup(g);
-    uint32_t jg[ND];                          // (j*g) of my columns
+    uint32_t njg[ND];                         // -(j*g) of my columns: the tilted image of H == 0 (SW floor, SW row 0)
 #pragma unroll
     for (int q = 0; q < ND; ++q) {
         const int j0 = lane * CPL + 2 * q + 1;
-        jg[q] = ((uint32_t)(j0 * g) & 0xFFFFu) | ((uint32_t)((j0 + 1) * g) << 16);
-    }
-    uint32_t vmask[ND];                       // 0xFFFF per half whose column exists
-#pragma unroll
-    for (int q = 0; q < ND; ++q) {
-        const uint32_t i0 = lane * CPL + 2 * q;
-        vmask[q] = (i0 < len ? 0xFFFFu : 0u) | (i0 + 1 < len ? 0xFFFF0000u : 0u);
+        njg[q] = ((uint32_t)(-j0 * g) & 0xFFFFu) | ((uint32_t)(-(j0 + 1) * g) << 16);
     }
 
-    uint32_t* hrow0 = a.hmat + (uint64_t)job * a.hstride;
-    int16_t* c0p_out = a.c0 + (uint64_t)job * a.NC;
+    uint32_t* const hrow0 = a.hmat + (uint64_t)job * a.hstride;
+    const bool packed = vc_row_packed(m, n, g);
+    int16_t* const c0p_out = a.c0 + (uint64_t)job * a.NC;
+    const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
 
     // end-cell tracking
-    int best = nw ? VC_INT_MIN : 0;          // NW: uniform; SW: per lane
+    int best = nw ? VC_INT_MIN : 0;          // NW: uniform (tilted value of the last column); SW: per lane (real H)
     uint32_t best_row = 0, ntie = 0;
     const uint32_t lane_e = (len - 1) / CPL, c_e = (len - 1) % CPL;
     uint32_t far_reads = 0;
 
-    uint32_t Hprev[ND];
+    uint32_t acc[ND];                         // between iterations: T of the row just finished
     int c0prev = 0;
+    int c0vec = 0;                            // lane t: column 0 of the latest row r with (r - 1) % 64 == t
 #pragma unroll
-    for (int q = 0; q < ND; ++q) Hprev[q] = 0;
+    for (int q = 0; q < ND; ++q) acc[q] = 0;
 
-    // row records: lane t holds the record of row (block*64 + t); the next block is fetched a block ahead
+    // row records (the forward view, VcDp::frec): lane t holds the record of row (block*64 + t); the next
+    // block is fetched a block ahead
     uint4 myrec = make_uint4(0, 0, 0, 0), nextrec = make_uint4(0, 0, 0, 0);
-    if ((uint32_t)lane < nrows) nextrec = a.dp.rec[nb + lane];
+    if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
+    uint32_t* hrow = hrow0;                                   // stored form of the current row
+    const uint32_t rowdw = packed ? NDS * 64 : ND * 64;
     for (uint32_t i = 1; i <= nrows; ++i) {
         const uint32_t ri = (i - 1) & 63;
         if (ri == 0) {
             myrec = nextrec;
             const uint32_t r = i - 1 + 64 + lane;
-            if (r < nrows) nextrec = a.dp.rec[nb + r];
+            if (r < nrows) nextrec = a.dp.frec[nb + r];
         }
         const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
         const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
-        const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
-        const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
-        const uint32_t x = r0 & 0xFF, fl = (r0 >> 8) & 0xFF, np = (r0 >> 16) & 0xFF;
+        const uint32_t x = r0 & 0xFF, fl = (r0 >> 8) & 0xFF, nq = (r0 >> 16) & 0xFF, bi = r0 >> 24;
 
-        uint32_t prof[ND];
-        if (x == 'A') {
+        // ---- element-wise maximum over the predecessor rows (and over their column 0)
+        int c0m;
+        if (fl & VC_RF_PREV) {
+            c0m = c0prev;                     // acc already holds row i-1
+        } else {
+            c0m = VC_INT_MIN;
 #pragma unroll
-            for (int q = 0; q < ND; ++q) prof[q] = pfA[q];
-        } else if (x == 'C') {
+            for (int q = 0; q < ND; ++q) acc[q] = 0x80008000u;
+        }
+        if (nq) {
+            // a row of the LDS ring; column 0 of the last 64 rows lives in c0vec
+            auto ringrow = [&](uint32_t delta, uint32_t (&hp)[ND], int& c0p) __attribute__((always_inline)) {
+                const uint32_t pr = i - delta, rs = pr % RING;
 #pragma unroll
-            for (int q = 0; q < ND; ++q) prof[q] = pfC[q];
-        } else if (x == 'G') {
+                for (int q = 0; q < ND; ++q) hp[q] = ring[rs][q][lane];
+                c0p = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
+            };
+            auto merge = [&](const uint32_t (&hp)[ND], int c0p) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < ND; ++q) prof[q] = pfG[q];
-        } else if (x == 'T') {
+                for (int q = 0; q < ND; ++q) acc[q] = pk_max(acc[q], hp[q]);
+                c0m = max(c0m, c0p);
+            };
+            uint32_t hA[ND], hB[ND];
+            int cA = 0, cB = 0;
+            if (!(fl & VC_RF_SLOW)) {
+                // usual case: every listed predecessor sits in the LDS ring
+                ringrow(r1 & 0xFFFF, hA, cA);
+                if (nq > 1) ringrow(r1 >> 16, hB, cB);
+                merge(hA, cA);
+                if (nq > 1) {
+                    merge(hB, cB);
+                    if (nq > 2) {
+                        const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
+                        const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
+                        for (uint32_t p = 2; p < nq; ++p) {
+                            const uint32_t wsel = p < 4 ? r2 : r3;
+                            ringrow((p & 1) ? (wsel >> 16) : (wsel & 0xFFFF), hA, cA);
+                            merge(hA, cA);
+                        }
+                    }
+                }
+            } else {
+                // general path: the virtual row 0 analytically, a recent row from the LDS ring, an older one
+                // back from the stored matrix in HBM; long lists come from VcDp::ovf
+                const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
+                const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
+                for (uint32_t p = 0; p < nq; ++p) {
+                    uint32_t delta;
+                    if (fl & VC_RF_OVF) {
+                        delta = ovfp[r1 + p];
+                        if ((fl & VC_RF_PREV) && delta == 1) continue;
+                    } else {
+                        const uint32_t wsel = p < 2 ? r1 : (p < 4 ? r2 : r3);
+                        delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
+                    }
+                    const uint32_t pr = i - delta;
+                    if (pr == 0) {
 #pragma unroll
-            for (int q = 0; q < ND; ++q) prof[q] = pfT[q];
+                        for (int q = 0; q < ND; ++q) hA[q] = nw ? 0u : njg[q];       // H[0][j] = j*g (NW) / 0 (SW)
+                        cA = 0;
+                    } else if (delta <= (uint32_t)RING) {
+                        ringrow(delta, hA, cA);
+                    } else {
+                        if (packed) {                                                 // my own earlier stores
+                            const uint32_t* hr = hrow0 + (uint64_t)(pr - 1) * (NDS * 64) + lane * NDS;
+                            uint32_t wv[NDS];
+#pragma unroll
+                            for (int t = 0; t < NDS; ++t) wv[t] = hr[t];
+                            vc_unpack_row<ND, NDS>(wv, hA);
+                        } else {
+                            const uint32_t* hr = hrow0 + (uint64_t)(pr - 1) * (ND * 64);
+#pragma unroll
+                            for (int q = 0; q < ND; ++q) hA[q] = hr[q * 64 + lane];
+                        }
+                        far_reads++;
+                        if (delta <= 64) cA = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
+                        else cA = (int)__builtin_amdgcn_readfirstlane((int)c0p_out[pr - 1]);
+                    }
+                    merge(hA, cA);
+                }
+            }
+        }
+
+        // ---- this row: diagonal (cell j-1 of the maximum: shift right by one int16; the hole is filled by
+        // the left lane's last cell, lane 0 takes column 0) and vertical candidates
+        const uint32_t left = (uint32_t)VC_DPP_SHR((int)acc[ND - 1], (int)((uint32_t)c0m << 16), 0x138, 0xF);
+        uint32_t P[ND];
+#pragma unroll
+        for (int q = 0; q < ND; ++q) P[q] = __builtin_amdgcn_alignbit(acc[q], q == 0 ? left : acc[q - 1], 16);
+        if (bi < 2) {
+            if (bi == 0) {
+#pragma unroll
+                for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfA[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfC[q]);
+            }
+        } else if (bi == 2) {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfG[q]);
+        } else if (bi == 3) {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfT[q]);
         } else {
 #pragma unroll
             for (int q = 0; q < ND; ++q)
-                prof[q] = ((uint32_t)(((sbp[q] & 0xFFFFu) == x) ? m : n) & 0xFFFFu) | ((uint32_t)(((sbp[q] >> 16) == x) ? m : n) << 16);
-        }
-
-        uint32_t bm[ND];
-        int b0 = VC_INT_MIN;
-        // fetch of predecessor p's row: previous row from registers, virtual row 0 analytically, a recent
-        // row from the LDS ring, an older one back from the H matrix in HBM
-        auto fetch = [&](uint32_t p, uint32_t (&hp)[ND], int& c0p) {
-            uint32_t delta;
-            if (fl & VC_RF_OVF) {
-                delta = a.dp.ovf[(uint64_t)slot * a.EC + r1 + p];
-            } else {
-                uint32_t wsel = p < 2 ? r1 : (p < 4 ? r2 : r3);
-                delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
-            }
-            const uint32_t pr = i - delta;
-            if (delta == 1 && i > 1) {
-#pragma unroll
-                for (int q = 0; q < ND; ++q) hp[q] = Hprev[q];
-                c0p = c0prev;
-            } else if (pr == 0) {
-#pragma unroll
-                for (int q = 0; q < ND; ++q) hp[q] = nw ? jg[q] : 0u;            // H[0][j] = j*g (NW) / 0 (SW)
-                c0p = 0;
-            } else if (delta <= (uint32_t)RING) {
-                const uint32_t rs = pr % RING;
-#pragma unroll
-                for (int q = 0; q < ND; ++q) hp[q] = ring[rs][q][lane];
-                c0p = ring_c0[rs];
-            } else {
-                const uint32_t* hr = hrow0 + (uint64_t)(pr - 1) * (ND * 64);      // my own earlier stores
-#pragma unroll
-                for (int q = 0; q < ND; ++q) hp[q] = hr[q * 64 + lane];
-                c0p = (int)__builtin_amdgcn_readfirstlane((int)c0p_out[pr - 1]);
-                far_reads++;
-            }
-        };
-        auto relax = [&](uint32_t p, const uint32_t (&hp)[ND], int c0p) {
-            // cell j-1 for each of my cells: shift the row right by one int16; the hole is filled by the
-            // left lane's last cell, lane 0 takes the predecessor's column 0
-            const uint32_t left = (uint32_t)VC_DPP_SHR((int)hp[ND - 1], (int)((uint32_t)c0p << 16), 0x138, 0xF);
-#pragma unroll
-            for (int q = 0; q < ND; ++q) {
-                const uint32_t sh = __builtin_amdgcn_alignbit(hp[q], q == 0 ? left : hp[q - 1], 16);
-                const uint32_t cand = pk_max(pk_add(sh, prof[q]), pk_add(hp[q], gg));
-                bm[q] = p == 0 ? cand : pk_max(bm[q], cand);
-            }
-            b0 = max(b0, c0p + g);
-        };
-        {
-            // two buffers: the next predecessor's row is in flight while the current one is relaxed
-            uint32_t hA[ND], hB[ND];
-            int cA = 0, cB = 0;
-            fetch(0, hA, cA);
-            for (uint32_t p = 0;;) {
-                if (p + 1 < np) fetch(p + 1, hB, cB);
-                relax(p, hA, cA);
-                if (++p >= np) break;
-                if (p + 1 < np) fetch(p + 1, hA, cA);
-                relax(p, hB, cB);
-                if (++p >= np) break;
-            }
-        }
-
-        // column 0: NW max over predecessors (Initialize, sisd :210-222); SW 0
-        const int col0 = nw ? b0 : 0;
-        // horizontal pass H[j] = max(H[j], H[j-1]+g) as a prefix max of H[j] - j*g  (sisd :347-349)
-        uint32_t P[ND];
-#pragma unroll
-        for (int q = 0; q < ND; ++q) {
-            uint32_t mx = bm[q];
-            if (!nw) mx = pk_max(mx, 0u);
-            P[q] = pk_max_hi_with_lo(pk_sub(mx, jg[q]));
+                P[q] = pk_add(P[q], ((uint32_t)(((sbp[q] & 0xFFFFu) == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)(((sbp[q] >> 16) == x) ? mt : nt) << 16));
         }
 #pragma unroll
-        for (int q = 1; q < ND; ++q) P[q] = pk_max_bcast_hi(P[q], P[q - 1]);
+        for (int q = 0; q < ND; ++q) P[q] = pk_max(P[q], pk_add(acc[q], gg));
+        // column 0: NW max over predecessors + g (Initialize, sisd :210-222); SW 0
+        const int col0 = nw ? c0m + g : 0;
+        if (!nw) {                                         // SW floor H >= 0 (sisd :350-352)
+#pragma unroll
+            for (int q = 0; q < ND; ++q) P[q] = pk_max(P[q], njg[q]);
+        }
+        // ---- horizontal pass (sisd :347-349): prefix maximum, in-lane then across lanes
+        P[0] = pk_max_hi_with_lo(P[0]);
+#pragma unroll
+        for (int q = 1; q < ND; ++q) P[q] = pk_max_bcast_hi(pk_max_hi_with_lo(P[q]), P[q - 1]);
         int sc = pk_hi(P[ND - 1]);
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x111, 0xF));
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x112, 0xF));
@@ -1108,18 +1253,17 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x142, 0xA));
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x143, 0xC));
         int carry = VC_DPP_SHR(sc, VC_INT_MIN, 0x138, 0xF);
-        carry = max(carry, col0);                     // column 0 enters as A[0] = H[i][0] - 0*g
+        carry = max(carry, col0);                     // column 0 enters as T[i][0] = H[i][0]
         const uint32_t cc = pk_dup(carry);
-        uint32_t H[ND];
 #pragma unroll
-        for (int q = 0; q < ND; ++q) H[q] = pk_add(pk_max(P[q], cc), jg[q]);
+        for (int q = 0; q < ND; ++q) acc[q] = pk_max(P[q], cc);
 
-        // end cell
+        // ---- end cell
         if (nw) {
-            if (fl & VC_RF_SINK) {                           // sisd :353-355
-                uint32_t hv = H[0];
+            if (fl & VC_RF_SINK) {                           // sisd :353-355 (same column: tilted compare is exact)
+                uint32_t hv = acc[0];
 #pragma unroll
-                for (int q = 1; q < ND; ++q) hv = (c_e / 2 == (uint32_t)q) ? H[q] : hv;
+                for (int q = 1; q < ND; ++q) hv = (c_e / 2 == (uint32_t)q) ? acc[q] : hv;
                 int v = (c_e & 1) ? pk_hi(hv) : pk_lo(hv);
                 v = __builtin_amdgcn_readlane(v, lane_e);
                 if (v > best) {
@@ -1131,32 +1275,45 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
                 }
             }
         } else {                                             // sisd :350-352 (first row with the best score)
-            uint32_t rmx = H[0] & vmask[0];
+            uint32_t rmx = pk_sub(acc[0], njg[0]);
 #pragma unroll
-            for (int q = 1; q < ND; ++q) rmx = pk_max(rmx, H[q] & vmask[q]);
+            for (int q = 1; q < ND; ++q) rmx = pk_max(rmx, pk_sub(acc[q], njg[q]));
             const int rm = max(pk_lo(rmx), pk_hi(rmx));
             if (rm > best) { best = rm; best_row = i; }
         }
 
-        // keep the row: registers, LDS ring, HBM
-#pragma unroll
-        for (int q = 0; q < ND; ++q) Hprev[q] = H[q];
+        // ---- keep the row: registers (acc), LDS ring, HBM
         c0prev = col0;
+        c0vec = ((uint32_t)lane == ri) ? col0 : c0vec;
         const uint32_t ws = i % RING;
         // one wave per workgroup: LDS operations of a wave retire in order, so no s_barrier (and no
         // vmcnt(0) drain of the H stores) is needed -- only keep the compiler from reordering
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < ND; ++q) ring[ws][q][lane] = H[q];
-        if (lane == 0) { ring_c0[ws] = col0; c0p_out[i - 1] = (int16_t)col0; }
-        {
-            uint32_t* hr = hrow0 + (uint64_t)(i - 1) * (ND * 64);
+        for (int q = 0; q < ND; ++q) ring[ws][q][lane] = acc[q];
+        if (packed) {
+            uint32_t wv[NDS];
+            vc_pack_row<ND, NDS>(acc, wv);
+            uint32_t* hr = hrow + lane * NDS;
+            if (NDS == 2) *reinterpret_cast<uint2*>(hr) = make_uint2(wv[0], wv[1]);
+            else if (NDS == 4) *reinterpret_cast<uint4*>(hr) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            else {
+#pragma unroll
+                for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
+            }
+        } else {
             // full 256-B rows on purpose: masking the lanes past the sequence end was measured SLOWER
             // (partial cache-line writes), although it would save 20 % of the bytes
 #pragma unroll
-            for (int q = 0; q < ND; ++q) hr[q * 64 + lane] = H[q];
+            for (int q = 0; q < ND; ++q) hrow[q * 64 + lane] = acc[q];
         }
-        if (fl & VC_RF_SPILL) __threadfence_block();          // a far successor will load this row back
+        hrow += rowdw;
+        bool fence = (fl & VC_RF_SPILL) != 0;                 // a far successor will load this row back
+        if (ri == 63 || i == nrows) {                         // column 0 of the block just completed
+            if ((uint32_t)lane <= ri) c0p_out[i - 1 - ri + lane] = (int16_t)c0vec;
+            fence = true;
+        }
+        if (fence) __threadfence_block();
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && far_reads) atomicAdd(a.stat + 3, (unsigned long long)far_reads);
@@ -1176,11 +1333,22 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
             const uint32_t rstar = wave_min_u32(rowc);
             // first column of that row holding the best score: re-read my part of the row
             __threadfence_block();
-            const uint32_t* hr = hrow0 + (uint64_t)(rstar - 1) * (ND * 64);
+            uint32_t trow[ND];
+            if (packed) {
+                const uint32_t* hr = hrow0 + (uint64_t)(rstar - 1) * (NDS * 64) + lane * NDS;
+                uint32_t wv[NDS];
+#pragma unroll
+                for (int t = 0; t < NDS; ++t) wv[t] = hr[t];
+                vc_unpack_row<ND, NDS>(wv, trow);
+            } else {
+                const uint32_t* hr = hrow0 + (uint64_t)(rstar - 1) * (ND * 64);
+#pragma unroll
+                for (int q = 0; q < ND; ++q) trow[q] = hr[q * 64 + lane];
+            }
             uint32_t firstc = 0xFFFFFFFFu;
 #pragma unroll
             for (int q = ND - 1; q >= 0; --q) {
-                const uint32_t hv = hr[q * 64 + lane];
+                const uint32_t hv = pk_sub(trow[q], njg[q]);
                 const uint32_t c1 = lane * CPL + 2 * q + 1, c0i = c1 - 1;
                 if (c1 < len && pk_hi(hv) == gmax) firstc = c1;
                 if (c0i < len && pk_lo(hv) == gmax) firstc = c0i;
@@ -1197,7 +1365,6 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
 template <int CA, int CB, int RING>
 __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     __shared__ uint32_t ring_raw[RING * (CB / 2) * 64];
-    __shared__ int ring_c0[RING];
     if (CA != CB) {
         // sequence length of this job decides the body (uniform per wave)
         const uint32_t job = blockIdx.x, slot = job / a.group;
@@ -1206,13 +1373,13 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
         uint32_t cls = CB;
         if (k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + k + 1] - a.b.seq_off[s0 + k]));
-        if (cls == (uint32_t)CA) { vc_fwd_body<CA, RING>(a, ring_raw, ring_c0); return; }
+        if (cls == (uint32_t)CA) { vc_fwd_body<CA, RING>(a, ring_raw); return; }
     }
-    vc_fwd_body<CB, RING>(a, ring_raw, ring_c0);
+    vc_fwd_body<CB, RING>(a, ring_raw);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_trace: backtrack, one alignment per thread, straight from H like sisd_alignment_engine.cpp:362-459:
+// k_trace: backtrack, one alignment per thread, straight from the stored matrix like sisd_alignment_engine.cpp:362-459:
 // diagonal over the in-edges in list order, then vertical over the in-edges in list order, then
 // horizontal.  Pairs are emitted tail-first as (row << 16) | column, 0 meaning "-1"; consumers read
 // them back to front.
@@ -1231,6 +1398,7 @@ struct VcTraceArgs {
     uint32_t PC;
     uint32_t pair_group, pair_k0;   // pairs index = slot*pair_group + (k - pair_k0)
     uint32_t k0;
+    unsigned long long* stat;   // [8], see vc_ctx::d_stat
 };
 
 // One alignment per THREAD: the walk is a chain of dependent lookups, so the instruction cost is shared
@@ -1239,6 +1407,7 @@ struct VcTraceArgs {
 // slots and CUs away from k_fwd).  Loads stop at the first matching move, like the reference's scan.
 #define VC_TRACE_LANES 8     // alignments per wave: lanes walk in lockstep, so fewer per wave = less waiting on the slowest
 __global__ void k_trace(VcTraceArgs a) {
+    VC_LATENCY_KERNEL_PRIO();
     if (threadIdx.x >= VC_TRACE_LANES) return;
     const uint32_t job = blockIdx.x * VC_TRACE_LANES + threadIdx.x;
     if (job >= a.nslots * a.group) return;
@@ -1255,13 +1424,18 @@ __global__ void k_trace(VcTraceArgs a) {
     const bool nw = type == 1;
     const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
     const uint64_t so = a.b.seq_off[a.b.win_seq_off[w] + k];
-    const uint16_t* hm = (const uint16_t*)(a.hmat + (uint64_t)job * a.hstride);
+    const uint32_t* hm32 = a.hmat + (uint64_t)job * a.hstride;
+    const uint16_t* hm = (const uint16_t*)hm32;
+    const bool packed = vc_row_packed(m, n, g);
     const int16_t* c0 = a.c0 + (uint64_t)job * a.NC;
-    const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[a.b.win_seq_off[w] + k + 1] - so)), nd = cpl / 2;
-    auto Hat = [&](uint32_t r, uint32_t col) -> int {     // H[r][col] incl. the virtual row 0 / column 0
-        if (r == 0) return nw ? (int)col * g : 0;
+    const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[a.b.win_seq_off[w] + k + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
+    // k_fwd stores the tilted matrix T[r][col] = H[r][col] - col*g; the tests of sisd :392-448 become
+    // diagonal T == T' + (score - g), vertical T == T' + g, horizontal T == T', SW stop T == -col*g
+    auto Hat = [&](uint32_t r, uint32_t col) -> int {     // T[r][col] incl. the virtual row 0 / column 0
+        if (r == 0) return nw ? 0 : -(int)col * g;
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
+        if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc);
         return (int)(short)hm[((uint64_t)(r - 1) * nd * 64 + (cc >> 1) * 64 + lc) * 2 + (cc & 1)];
     };
     uint32_t nout = 0;
@@ -1272,7 +1446,7 @@ __global__ void k_trace(VcTraceArgs a) {
         uint4 rec = i ? a.dp.rec[nb + i - 1] : zero4;
         for (;;) {
             if (nw) { if (i == 0 && j == 0) break; }
-            else if (Hij == 0) break;
+            else if (Hij == -(int)j * g) break;
             uint32_t pi_ = 0, pj_ = 0;
             int hv = 0;
             uint4 nrec = zero4;
@@ -1291,12 +1465,13 @@ __global__ void k_trace(VcTraceArgs a) {
                     const uint32_t pr0 = i - (isovf ? delta_of(0) : (rec.y & 0xFFFF));
                     // unconditional, branch-free addresses so the three loads are in flight together
                     const uint32_t rr = pr0 ? pr0 : 1, cc1 = j > 1 ? j - 2 : 0, lc = cc1 / cpl, cw = cc1 % cpl;
-                    const int v0raw = (int)(short)hm[((uint64_t)(rr - 1) * nd * 64 + (cw >> 1) * 64 + lc) * 2 + (cw & 1)];
+                    const int v0raw = packed ? vc_packed_cell(hm32 + (uint64_t)(rr - 1) * nds * 64 + lc * nds, cw)
+                                             : (int)(short)hm[((uint64_t)(rr - 1) * nd * 64 + (cw >> 1) * 64 + lc) * 2 + (cw & 1)];
                     const uint32_t bs = a.b.bases[so + j - 1];
                     const uint4 q0 = a.dp.rec[nb + rr - 1];
                     int v0 = v0raw;
                     if (pr0 == 0 || j == 1) v0 = Hat(pr0, j - 1);
-                    const int sc = (bs == (rec.x & 0xFF)) ? m : n;
+                    const int sc = ((bs == (rec.x & 0xFF)) ? m : n) - g;
                     if (Hij == v0 + sc) { pi_ = pr0; pj_ = j - 1; hv = v0; nrec = pr0 ? q0 : zero4; have_nrec = true; found = true; }
                     for (uint32_t p = 1; p < np && !found; ++p) {
                         const uint32_t pr = i - delta_of(p);
@@ -1314,7 +1489,7 @@ __global__ void k_trace(VcTraceArgs a) {
             }
             if (!found && j != 0) {
                 const int v = Hat(i, j - 1);
-                if (Hij == v + g) { pi_ = i; pj_ = j - 1; hv = v; nrec = rec; have_nrec = true; found = true; }
+                if (Hij == v) { pi_ = i; pj_ = j - 1; hv = v; nrec = rec; have_nrec = true; found = true; }
             }
             if (!found) { broken = true; break; }
             if (nout >= a.PC) { ovf = true; break; }
@@ -1326,6 +1501,190 @@ __global__ void k_trace(VcTraceArgs a) {
     if (broken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, i); nout = 0; }
     if (ovf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, nout); nout = 0; }
     a.npairs[pj] = nout;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tracew: the same backtrack, one alignment per WAVE.  The walk is a chain of dependent HBM round
+// trips, and ~85 % of its moves are "diagonal through the first in-edge".  Each round therefore
+//   A. follows first in-edges for up to VC_SPEC positions using a per-graph table in LDS (no HBM),
+//   B. lets lane k fetch the diagonal cell (and the row record) of speculated position k -- one
+//      round trip for all of them,
+//   C. accepts the longest prefix whose cells confirm the move (exactly the reference's first test at
+//      each of those cells, so nothing is skipped), and
+//   D. takes one fully general step at the first position that did not confirm: lanes 0..30 test the
+//      diagonal through in-edge p, lanes 32..62 the vertical one, lane 63 the horizontal move, all in
+//      one round trip; ballots pick the first match in the reference's order (sisd :392-448).
+// ------------------------------------------------------------------------------------------------
+#define VC_SPEC 16
+__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t NC) { return 3 * (NC + 2) + 16; }
+
+__global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
+    VC_LATENCY_KERNEL_PRIO();
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t* s_d0 = reinterpret_cast<uint16_t*>(smem);                 // [NC+2] first in-edge distance of row r (0: do not speculate)
+    uint8_t* s_code = smem + 2 * (a.NC + 2);                            // [NC+2]
+    const uint32_t job = blockIdx.x;
+    if (job >= a.nslots * a.group) return;
+    const int lane = vc_lane();
+    const uint32_t slot = job / a.group, k = a.k0 + job % a.group;
+    const uint32_t w = a.w0 + slot;
+    const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
+    const uint8_t type = a.job_type[job];
+    if (type == 255) return;
+    if (a.b.status[w] != VC_WIN_OK) return;
+    uint32_t* out = a.pairs + pj * a.PC;
+    const uint32_t end = a.job_end[job];
+    const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
+    const bool nw = type == 1;
+    const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
+    const uint64_t so = a.b.seq_off[a.b.win_seq_off[w] + k];
+    const uint32_t* hm32 = a.hmat + (uint64_t)job * a.hstride;
+    const uint16_t* hm = (const uint16_t*)hm32;
+    const bool packed = vc_row_packed(m, n, g);
+    const int16_t* c0 = a.c0 + (uint64_t)job * a.NC;
+    const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[a.b.win_seq_off[w] + k + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
+    const uint32_t nrows = a.dp.nrows[slot];
+    // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
+    // horizontal T == T', SW stop T == -col*g
+    auto Tat = [&](uint32_t r, uint32_t col) __attribute__((always_inline)) -> int {
+        if (r == 0) return nw ? 0 : -(int)col * g;
+        if (col == 0) return nw ? (int)c0[r - 1] : 0;
+        const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
+        if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc);
+        return (int)(short)hm[((uint64_t)(r - 1) * nd * 64 + (cc >> 1) * 64 + lc) * 2 + (cc & 1)];
+    };
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto bcast4 = [&](const uint4& v, uint32_t l) __attribute__((always_inline)) -> uint4 {
+        return make_uint4((uint32_t)__shfl((int)v.x, (int)l, 64), (uint32_t)__shfl((int)v.y, (int)l, 64),
+                          (uint32_t)__shfl((int)v.z, (int)l, 64), (uint32_t)__shfl((int)v.w, (int)l, 64));
+    };
+    uint32_t nout = 0, nspec_ok = 0, nrounds = 0;
+    bool ovf = false, broken = false;
+    uint32_t i = end >> 16, j = end & 0xFFFF;
+    if (end != 0) {
+        for (uint32_t r = lane; r < nrows; r += 64) {
+            const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + r]);
+            s_d0[r + 1] = ((q.x >> 8) & VC_RF_OVF) ? (uint16_t)0 : (uint16_t)(q.y & 0xFFFF);
+            s_code[r + 1] = (uint8_t)(q.x & 0xFF);
+        }
+        __syncthreads();
+        int Tij = Tat(i, j);
+        uint4 rec = i ? a.dp.rec[nb + i - 1] : zero4;
+        for (;;) {
+            if (nw) { if (i == 0 && j == 0) break; }
+            else if (Tij == -(int)j * g) break;
+            // ---- A: speculated positions (row my_i, column j - lane), next row my_in
+            uint32_t my_i = 0, my_in = 0, nspec = 0;
+            if (i != 0 && j != 0) {
+                uint32_t ci = i;
+#pragma unroll 1
+                for (uint32_t t = 0; t < VC_SPEC; ++t) {
+                    if (ci == 0 || j <= t) break;
+                    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_d0[ci]);
+                    if (d == 0) break;
+                    if ((uint32_t)lane == t) { my_i = ci; my_in = ci - d; }
+                    ci -= d;
+                    nspec = t + 1;
+                }
+            }
+            if (nspec) {
+                nrounds++;
+                // ---- B: one round trip for all speculated diagonal cells and the records behind them
+                const uint32_t jk = j - (uint32_t)lane;
+                int tv = 0, sc = 0;
+                uint4 rnext = zero4;
+                if ((uint32_t)lane < nspec) {
+                    const uint32_t bs = a.b.bases[so + jk - 1];
+                    if (my_in) rnext = a.dp.rec[nb + my_in - 1];
+                    tv = Tat(my_in, jk - 1);
+                    sc = ((bs == (uint32_t)s_code[my_i]) ? m : n) - g;
+                }
+                int tprev = __shfl_up(tv, 1, 64);
+                if (lane == 0) tprev = Tij;
+                bool ok = (uint32_t)lane < nspec && tprev == tv + sc;
+                if (!nw && tprev == -(int)jk * g) ok = false;                  // SW: the walk ends at this position
+                // ---- C: longest confirmed prefix
+                const unsigned long long okm = __ballot(ok);
+                const uint32_t f = okm == ~0ull ? 64u : (uint32_t)(__ffsll((long long)~okm) - 1);
+                if (f) {
+                    if (nout + f > a.PC) { ovf = true; break; }
+                    if ((uint32_t)lane < f) out[nout + lane] = (my_i << 16) | jk;
+                    nout += f; nspec_ok += f;
+                    i = (uint32_t)__shfl((int)my_in, (int)(f - 1), 64);
+                    Tij = __shfl(tv, (int)(f - 1), 64);
+                    rec = bcast4(rnext, f - 1);
+                    j -= f;
+                    if (f == VC_SPEC) continue;                                // everything confirmed: speculate again
+                    if (nw) { if (i == 0 && j == 0) break; }
+                    else if (Tij == -(int)j * g) break;
+                }
+            }
+            // ---- D: one general step at (i, j)
+            uint32_t pi_ = 0, pj_ = 0;
+            int hv = 0;
+            uint4 nrec = zero4;
+            bool found = false, have_v = false;
+            uint32_t v_pi = 0; int v_hv = 0; uint4 v_rec = zero4;
+            int hz = 0;                                                         // lane 63: T[i][j-1]
+            if (lane == 63 && j != 0) hz = Tat(i, j - 1);
+            if (i != 0) {
+                const uint32_t np = (rec.x >> 16) & 0xFF;
+                const bool isovf = ((rec.x >> 8) & VC_RF_OVF) != 0;
+                int sc = 0;
+                if (j != 0) sc = ((a.b.bases[so + j - 1] == (rec.x & 0xFF)) ? m : n) - g;
+                for (uint32_t base = 0; base < np && !found; base += 31) {
+                    const uint32_t hl = (uint32_t)lane & 31, p = base + hl;
+                    const bool isd = lane < 32;
+                    const bool act = hl < 31 && p < np && (!isd || j != 0) && (isd || !have_v);
+                    uint32_t delta = 0;
+                    if (act) {
+                        if (isovf) delta = a.dp.ovf[eb + rec.y + p];
+                        else {
+                            const uint32_t wsel = p < 2 ? rec.y : (p < 4 ? rec.z : rec.w);
+                            delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
+                        }
+                    }
+                    const uint32_t pr = i - delta;
+                    int tv = 0;
+                    uint4 rr = zero4;
+                    if (act) {
+                        if (pr) rr = a.dp.rec[nb + pr - 1];
+                        tv = Tat(pr, isd ? j - 1 : j);
+                    }
+                    const bool match = act && Tij == tv + (isd ? sc : g);
+                    const unsigned long long mm = __ballot(match);
+                    const uint32_t dm = (uint32_t)(mm & 0x7FFFFFFFull), vm = (uint32_t)((mm >> 32) & 0x7FFFFFFFull);
+                    if (dm) {
+                        const int l = __ffs((int)dm) - 1;
+                        pi_ = (uint32_t)__shfl((int)pr, l, 64); pj_ = j - 1; hv = __shfl(tv, l, 64); nrec = bcast4(rr, (uint32_t)l);
+                        found = true;
+                    } else if (vm && !have_v) {
+                        const int l = 32 + __ffs((int)vm) - 1;
+                        v_pi = (uint32_t)__shfl((int)pr, l, 64); v_hv = __shfl(tv, l, 64); v_rec = bcast4(rr, (uint32_t)l);
+                        have_v = true;
+                    }
+                }
+                if (!found && have_v) { pi_ = v_pi; pj_ = j; hv = v_hv; nrec = v_rec; found = true; }
+            }
+            if (!found && j != 0) {
+                const int v = __shfl(hz, 63, 64);
+                if (Tij == v) { pi_ = i; pj_ = j - 1; hv = v; nrec = rec; found = true; }
+            }
+            if (!found) { broken = true; break; }
+            if (nout >= a.PC) { ovf = true; break; }
+            if (lane == 0) out[nout] = ((i == pi_ ? 0u : i) << 16) | (j == pj_ ? 0u : j);
+            nout++;
+            i = pi_; j = pj_; Tij = hv; rec = pi_ ? nrec : zero4;
+        }
+    }
+    if (lane == 0) {
+        if (broken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, i); nout = 0; }
+        if (ovf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, nout); nout = 0; }
+        a.npairs[pj] = nout;
+        atomicAdd(a.stat + 4, (unsigned long long)nout);
+        atomicAdd(a.stat + 5, (unsigned long long)nspec_ok);
+        atomicAdd(a.stat + 6, (unsigned long long)nrounds);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1345,6 +1704,7 @@ struct VcAddArgs {
 };
 
 __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
+    VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* s_curr = (uint16_t*)smem;                 // [PC] node chosen for each pair (forward order)
     uint16_t* s_anchor = s_curr + a.PC;                 // [max_len] new node t goes in front of old position anchor[t]
@@ -1593,6 +1953,7 @@ __host__ __device__ inline uint32_t vc_prune_lds_bytes(uint32_t NC, uint32_t EC)
 }
 
 __global__ __launch_bounds__(64) void k_prune_lcc(VcPruneArgs a) {
+    VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t slot = blockIdx.x;
     if (slot >= a.nslots) return;
@@ -1776,6 +2137,7 @@ struct VcAddwArgs {
 };
 
 __global__ __launch_bounds__(64) void k_addw(VcAddwArgs a) {
+    VC_LATENCY_KERNEL_PRIO();
     const uint32_t slot = blockIdx.x;
     if (slot >= a.nslots) return;
     const uint32_t w = a.w0 + slot;
@@ -1823,6 +2185,7 @@ struct VcFinishArgs {
 };
 
 __global__ __launch_bounds__(64) void k_finish(VcFinishArgs a) {
+    VC_LATENCY_KERNEL_PRIO();
     const uint32_t slot = blockIdx.x;
     if (slot >= a.nslots) return;
     const uint32_t w = a.w0 + slot;
@@ -1869,6 +2232,7 @@ struct VcConsArgs {
 __host__ __device__ inline uint32_t vc_cons_lds_bytes(uint32_t NC, uint32_t EC) { return 12 * NC + 12 * EC + 8 * NC + 128; }
 
 __global__ __launch_bounds__(64) void k_consensus(VcConsArgs a) {
+    VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t slot = blockIdx.x;
     if (slot >= a.nslots) return;
