@@ -84,6 +84,7 @@ struct vc_ctx {
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
     bool trace_wave = true;
+    uint32_t trace_lds_mult = 1;
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
 
@@ -343,7 +344,7 @@ struct Plan {
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
         { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) hipLaunchKernelGGL(k_tracew, dim3(ns), dim3(64), vc_tracew_lds_bytes(NC), wk.stream, ta);
+          if (c->trace_wave) hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(NC) * c->trace_lds_mult, wk.stream, ta);
           else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
@@ -392,7 +393,7 @@ struct Plan {
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
             { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) hipLaunchKernelGGL(k_tracew, dim3(ns * gsz), dim3(64), vc_tracew_lds_bytes(NC), wk.stream, ta);
+          if (c->trace_wave) hipLaunchKernelGGL(k_tracew, dim3((ns * gsz + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(NC) * c->trace_lds_mult, wk.stream, ta);
           else hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         }
         VcAddwArgs wa{};
@@ -426,7 +427,7 @@ struct Plan {
         ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
         { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) hipLaunchKernelGGL(k_tracew, dim3(ns), dim3(64), vc_tracew_lds_bytes(NC), wk.stream, ta);
+          if (c->trace_wave) hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(NC) * c->trace_lds_mult, wk.stream, ta);
           else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcFinishArgs fn{};
         fn.b = c->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;
@@ -463,6 +464,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->prm = *p;
     c->device = p->device;
     c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 2;
+    if (getenv("VC_TRACE_LDS_MULT")) c->trace_lds_mult = (uint32_t)atoi(getenv("VC_TRACE_LDS_MULT"));
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }
     for (uint32_t s = 0; s < c->n_streams; ++s) {

@@ -1504,46 +1504,56 @@ __global__ void k_trace(VcTraceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_tracew: the same backtrack, one alignment per WAVE.  The walk is a chain of dependent HBM round
-// trips, and ~85 % of its moves are "diagonal through the first in-edge".  Each round therefore
-//   A. follows first in-edges for up to VC_SPEC positions using a per-graph table in LDS (no HBM),
-//   B. lets lane k fetch the diagonal cell (and the row record) of speculated position k -- one
-//      round trip for all of them,
+// k_tracew: the same backtrack, cooperative: VC_TG alignments per wave, VC_TL = 16 lanes each.  The walk
+// is a chain of dependent HBM round trips, and ~85 % of its moves are "diagonal through the first
+// in-edge".  Each round therefore
+//   A. follows first in-edges for up to 16 positions using a per-graph table in LDS (no HBM),
+//   B. lets lane k of the group fetch the diagonal cell (and the row record) of speculated position k --
+//      one round trip for all of them,
 //   C. accepts the longest prefix whose cells confirm the move (exactly the reference's first test at
 //      each of those cells, so nothing is skipped), and
-//   D. takes one fully general step at the first position that did not confirm: lanes 0..30 test the
-//      diagonal through in-edge p, lanes 32..62 the vertical one, lane 63 the horizontal move, all in
-//      one round trip; ballots pick the first match in the reference's order (sisd :392-448).
+//   D. takes one fully general step at the first position that did not confirm: lanes 0..6 of the group
+//      test the diagonal through in-edge p, lanes 8..14 the vertical one, lane 15 the horizontal move,
+//      all in one round trip; ballots pick the first match in the reference's order (sisd :392-448).
+// Four alignments share every instruction of the round; the kernel is instruction-issue bound when the
+// chip is full, so this is what sets its throughput.
 // ------------------------------------------------------------------------------------------------
-#define VC_SPEC 16
-__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t NC) { return 3 * (NC + 2) + 16; }
+#define VC_TG 4
+#define VC_TL 16
+__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t NC) { return VC_TG * 2 * (NC + 2); }
+__device__ __forceinline__ int vc_row_shr1(int v, int first) {          // value of the lane to the left inside a 16-lane row
+    return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false);
+}
 
 __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t* s_d0 = reinterpret_cast<uint16_t*>(smem);                 // [NC+2] first in-edge distance of row r (0: do not speculate)
-    uint8_t* s_code = smem + 2 * (a.NC + 2);                            // [NC+2]
-    const uint32_t job = blockIdx.x;
-    if (job >= a.nslots * a.group) return;
     const int lane = vc_lane();
-    const uint32_t slot = job / a.group, k = a.k0 + job % a.group;
+    const uint32_t grp = (uint32_t)lane / VC_TL, gl = (uint32_t)lane % VC_TL, gbase = grp * VC_TL;
+    uint16_t* tab = reinterpret_cast<uint16_t*>(smem) + grp * (a.NC + 2);   // first in-edge distance of row r (0: do not speculate)
+    const uint32_t njobs = a.nslots * a.group;
+    const uint32_t job = blockIdx.x * VC_TG + grp;
+    bool valid = job < njobs;
+    const uint32_t slot = valid ? job / a.group : 0, k = valid ? a.k0 + job % a.group : 0;
     const uint32_t w = a.w0 + slot;
     const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
-    const uint8_t type = a.job_type[job];
-    if (type == 255) return;
-    if (a.b.status[w] != VC_WIN_OK) return;
+    const uint8_t type = valid ? a.job_type[job] : (uint8_t)255;
+    valid = valid && type != 255;
+    if (valid && a.b.status[w] != VC_WIN_OK) valid = false;
+    if (!__any(valid)) return;
     uint32_t* out = a.pairs + pj * a.PC;
-    const uint32_t end = a.job_end[job];
+    const uint32_t end = valid ? a.job_end[job] : 0u;
     const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
     const bool nw = type == 1;
     const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
-    const uint64_t so = a.b.seq_off[a.b.win_seq_off[w] + k];
-    const uint32_t* hm32 = a.hmat + (uint64_t)job * a.hstride;
+    const uint32_t sq = a.b.win_seq_off[w] + (valid ? k : 0);
+    const uint64_t so = a.b.seq_off[sq];
+    const uint32_t* hm32 = a.hmat + (uint64_t)(valid ? job : 0) * a.hstride;
     const uint16_t* hm = (const uint16_t*)hm32;
     const bool packed = vc_row_packed(m, n, g);
-    const int16_t* c0 = a.c0 + (uint64_t)job * a.NC;
-    const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[a.b.win_seq_off[w] + k + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
-    const uint32_t nrows = a.dp.nrows[slot];
+    const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
+    const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
+    const uint32_t nrows = valid ? a.dp.nrows[slot] : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
     // horizontal T == T', SW stop T == -col*g
     auto Tat = [&](uint32_t r, uint32_t col) __attribute__((always_inline)) -> int {
@@ -1554,134 +1564,150 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         return (int)(short)hm[((uint64_t)(r - 1) * nd * 64 + (cc >> 1) * 64 + lc) * 2 + (cc & 1)];
     };
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    auto bcast4 = [&](const uint4& v, uint32_t l) __attribute__((always_inline)) -> uint4 {
+    auto perm4 = [&](const uint4& v, uint32_t l) __attribute__((always_inline)) -> uint4 {
         return make_uint4((uint32_t)__shfl((int)v.x, (int)l, 64), (uint32_t)__shfl((int)v.y, (int)l, 64),
                           (uint32_t)__shfl((int)v.z, (int)l, 64), (uint32_t)__shfl((int)v.w, (int)l, 64));
     };
-    uint32_t nout = 0, nspec_ok = 0, nrounds = 0;
-    bool ovf = false, broken = false;
-    uint32_t i = end >> 16, j = end & 0xFFFF;
-    if (end != 0) {
-        for (uint32_t r = lane; r < nrows; r += 64) {
-            const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + r]);
-            s_d0[r + 1] = ((q.x >> 8) & VC_RF_OVF) ? (uint16_t)0 : (uint16_t)(q.y & 0xFFFF);
-            s_code[r + 1] = (uint8_t)(q.x & 0xFF);
-        }
-        __syncthreads();
-        int Tij = Tat(i, j);
-        uint4 rec = i ? a.dp.rec[nb + i - 1] : zero4;
-        for (;;) {
-            if (nw) { if (i == 0 && j == 0) break; }
-            else if (Tij == -(int)j * g) break;
-            // ---- A: speculated positions (row my_i, column j - lane), next row my_in
-            uint32_t my_i = 0, my_in = 0, nspec = 0;
-            if (i != 0 && j != 0) {
-                uint32_t ci = i;
+    auto gmask = [&](unsigned long long mm) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(mm >> gbase) & 0xFFFFu; };
+
+    bool walking = valid && end != 0;
+    for (uint32_t r = gl; walking && r < nrows; r += VC_TL) {
+        const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + r]);
+        tab[r + 1] = ((q.x >> 8) & VC_RF_OVF) ? (uint16_t)0 : (uint16_t)(q.y & 0xFFFF);
+    }
+    __syncthreads();
+    uint32_t gi = end >> 16, gj = end & 0xFFFF, gnout = 0, nspec_ok = 0, nrounds = 0;
+    bool govf = false, gbroken = false;
+    int gT = 0;
+    uint4 grec = zero4;
+    if (walking) {
+        gT = Tat(gi, gj);
+        if (gi) grec = a.dp.rec[nb + gi - 1];
+    }
+    for (;;) {
+        if (walking && (nw ? (gi == 0 && gj == 0) : (gT == -(int)gj * g))) walking = false;
+        if (!__any(walking)) break;
+        // ---- A: speculated positions (row my_i, column gj - gl), next row my_in
+        uint32_t my_i = 0, my_in = 0, nspec = 0;
+        {
+            uint32_t ci = gi;
+            bool can = walking && gi != 0 && gj != 0;
 #pragma unroll 1
-                for (uint32_t t = 0; t < VC_SPEC; ++t) {
-                    if (ci == 0 || j <= t) break;
-                    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_d0[ci]);
-                    if (d == 0) break;
-                    if ((uint32_t)lane == t) { my_i = ci; my_in = ci - d; }
+            for (uint32_t t = 0; t < VC_TL; ++t) {
+                can = can && ci != 0 && gj > t;
+                const uint32_t d = can ? (uint32_t)tab[ci] : 0u;
+                can = can && d != 0;
+                if (!__any(can)) break;
+                if (can) {
+                    if (gl == t) { my_i = ci; my_in = ci - d; }
                     ci -= d;
                     nspec = t + 1;
                 }
             }
-            if (nspec) {
-                nrounds++;
-                // ---- B: one round trip for all speculated diagonal cells and the records behind them
-                const uint32_t jk = j - (uint32_t)lane;
-                int tv = 0, sc = 0;
-                uint4 rnext = zero4;
-                if ((uint32_t)lane < nspec) {
-                    const uint32_t bs = a.b.bases[so + jk - 1];
-                    if (my_in) rnext = a.dp.rec[nb + my_in - 1];
-                    tv = Tat(my_in, jk - 1);
-                    sc = ((bs == (uint32_t)s_code[my_i]) ? m : n) - g;
-                }
-                int tprev = __shfl_up(tv, 1, 64);
-                if (lane == 0) tprev = Tij;
-                bool ok = (uint32_t)lane < nspec && tprev == tv + sc;
-                if (!nw && tprev == -(int)jk * g) ok = false;                  // SW: the walk ends at this position
-                // ---- C: longest confirmed prefix
-                const unsigned long long okm = __ballot(ok);
-                const uint32_t f = okm == ~0ull ? 64u : (uint32_t)(__ffsll((long long)~okm) - 1);
-                if (f) {
-                    if (nout + f > a.PC) { ovf = true; break; }
-                    if ((uint32_t)lane < f) out[nout + lane] = (my_i << 16) | jk;
-                    nout += f; nspec_ok += f;
-                    i = (uint32_t)__shfl((int)my_in, (int)(f - 1), 64);
-                    Tij = __shfl(tv, (int)(f - 1), 64);
-                    rec = bcast4(rnext, f - 1);
-                    j -= f;
-                    if (f == VC_SPEC) continue;                                // everything confirmed: speculate again
-                    if (nw) { if (i == 0 && j == 0) break; }
-                    else if (Tij == -(int)j * g) break;
-                }
+        }
+        // ---- B: one round trip for all speculated diagonal cells and the records behind them
+        const uint32_t jk = gj - gl;
+        const bool lb = walking && gl < nspec;
+        int tv = 0;
+        uint32_t bs = 0;
+        uint4 rnext = zero4;
+        if (lb) {
+            bs = a.b.bases[so + jk - 1];
+            if (my_in) rnext = a.dp.rec[nb + my_in - 1];
+            tv = Tat(my_in, jk - 1);
+            nrounds += gl == 0;
+        }
+        const uint32_t codek = (uint32_t)vc_row_shr1((int)rnext.x, (int)grec.x) & 0xFF;       // code of position k's row
+        const int tprev = vc_row_shr1(tv, gT);                                               // T at position k
+        bool ok = lb && tprev == tv + (((bs == codek) ? m : n) - g);
+        if (!nw && tprev == -(int)jk * g) ok = false;                   // SW: the walk ends at this position
+        // ---- C: longest confirmed prefix
+        uint32_t f = 0;
+        {
+            const uint32_t gm = gmask(__ballot(ok));
+            f = (uint32_t)__ffs((int)(~gm & 0x1FFFFu)) - 1;
+            if (!walking) f = 0;
+            if (f && gnout + f > a.PC) { govf = true; walking = false; f = 0; }
+        }
+        if (gl < f) out[gnout + gl] = (my_i << 16) | jk;
+        bool cont = false;
+        {
+            const uint32_t src = gbase + (f ? f - 1 : 0);
+            const uint32_t ni = (uint32_t)__shfl((int)my_in, (int)src, 64);
+            const int nT = __shfl(tv, (int)src, 64);
+            const uint4 nr = perm4(rnext, src);
+            if (f) {
+                gnout += f; nspec_ok += f;
+                gi = ni; gT = nT; grec = ni ? nr : zero4; gj -= f;
+                cont = f == VC_TL;                                        // everything confirmed: speculate again
+                if (!cont && (nw ? (gi == 0 && gj == 0) : (gT == -(int)gj * g))) walking = false;
             }
-            // ---- D: one general step at (i, j)
+        }
+        // ---- D: one general step at (gi, gj) for the groups that stopped short
+        const bool need = walking && !cont;
+        if (__any(need)) {
             uint32_t pi_ = 0, pj_ = 0;
             int hv = 0;
             uint4 nrec = zero4;
             bool found = false, have_v = false;
             uint32_t v_pi = 0; int v_hv = 0; uint4 v_rec = zero4;
-            int hz = 0;                                                         // lane 63: T[i][j-1]
-            if (lane == 63 && j != 0) hz = Tat(i, j - 1);
-            if (i != 0) {
-                const uint32_t np = (rec.x >> 16) & 0xFF;
-                const bool isovf = ((rec.x >> 8) & VC_RF_OVF) != 0;
-                int sc = 0;
-                if (j != 0) sc = ((a.b.bases[so + j - 1] == (rec.x & 0xFF)) ? m : n) - g;
-                for (uint32_t base = 0; base < np && !found; base += 31) {
-                    const uint32_t hl = (uint32_t)lane & 31, p = base + hl;
-                    const bool isd = lane < 32;
-                    const bool act = hl < 31 && p < np && (!isd || j != 0) && (isd || !have_v);
-                    uint32_t delta = 0;
-                    if (act) {
-                        if (isovf) delta = a.dp.ovf[eb + rec.y + p];
-                        else {
-                            const uint32_t wsel = p < 2 ? rec.y : (p < 4 ? rec.z : rec.w);
-                            delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
-                        }
-                    }
-                    const uint32_t pr = i - delta;
-                    int tv = 0;
-                    uint4 rr = zero4;
-                    if (act) {
-                        if (pr) rr = a.dp.rec[nb + pr - 1];
-                        tv = Tat(pr, isd ? j - 1 : j);
-                    }
-                    const bool match = act && Tij == tv + (isd ? sc : g);
-                    const unsigned long long mm = __ballot(match);
-                    const uint32_t dm = (uint32_t)(mm & 0x7FFFFFFFull), vm = (uint32_t)((mm >> 32) & 0x7FFFFFFFull);
-                    if (dm) {
-                        const int l = __ffs((int)dm) - 1;
-                        pi_ = (uint32_t)__shfl((int)pr, l, 64); pj_ = j - 1; hv = __shfl(tv, l, 64); nrec = bcast4(rr, (uint32_t)l);
-                        found = true;
-                    } else if (vm && !have_v) {
-                        const int l = 32 + __ffs((int)vm) - 1;
-                        v_pi = (uint32_t)__shfl((int)pr, l, 64); v_hv = __shfl(tv, l, 64); v_rec = bcast4(rr, (uint32_t)l);
-                        have_v = true;
+            int hz = 0;                                                  // lane 15 of the group: T[gi][gj-1]
+            if (need && gl == VC_TL - 1 && gj != 0) hz = Tat(gi, gj - 1);
+            const uint32_t np = (need && gi != 0) ? ((grec.x >> 16) & 0xFF) : 0u;
+            const bool isovf = ((grec.x >> 8) & VC_RF_OVF) != 0;
+            int sc = 0;
+            if (np && gj != 0) sc = ((a.b.bases[so + gj - 1] == (grec.x & 0xFF)) ? m : n) - g;
+            const bool isd = gl < 7, isv = gl >= 8 && gl < 15;
+            for (uint32_t base = 0; __any(!found && base < np); base += 7) {
+                const uint32_t p = base + (isd ? gl : gl - 8);
+                const bool act = !found && (isd || isv) && p < np && (!isd || gj != 0) && (isd || !have_v);
+                uint32_t delta = 0;
+                if (act) {
+                    if (isovf) delta = a.dp.ovf[eb + grec.y + p];
+                    else {
+                        const uint32_t wsel = p < 2 ? grec.y : (p < 4 ? grec.z : grec.w);
+                        delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
                     }
                 }
-                if (!found && have_v) { pi_ = v_pi; pj_ = j; hv = v_hv; nrec = v_rec; found = true; }
+                const uint32_t pr = gi - delta;
+                int cv = 0;
+                uint4 rr = zero4;
+                if (act) {
+                    if (pr) rr = a.dp.rec[nb + pr - 1];
+                    cv = Tat(pr, isd ? gj - 1 : gj);
+                }
+                const bool match = act && gT == cv + (isd ? sc : g);
+                const uint32_t gm = gmask(__ballot(match));
+                const uint32_t dm = gm & 0x7Fu, vm = (gm >> 8) & 0x7Fu;
+                const bool take_d = !found && dm != 0, take_v = !found && dm == 0 && vm != 0 && !have_v;
+                const uint32_t src = gbase + (dm ? (uint32_t)__ffs((int)dm) - 1 : (vm ? 8u + (uint32_t)__ffs((int)vm) - 1 : 0u));
+                const uint32_t s_pr = (uint32_t)__shfl((int)pr, (int)src, 64);
+                const int s_cv = __shfl(cv, (int)src, 64);
+                const uint4 s_rr = perm4(rr, src);
+                if (take_d) { pi_ = s_pr; pj_ = gj - 1; hv = s_cv; nrec = s_rr; found = true; }
+                else if (take_v) { v_pi = s_pr; v_hv = s_cv; v_rec = s_rr; have_v = true; }
             }
-            if (!found && j != 0) {
-                const int v = __shfl(hz, 63, 64);
-                if (Tij == v) { pi_ = i; pj_ = j - 1; hv = v; nrec = rec; found = true; }
+            if (need && !found && have_v) { pi_ = v_pi; pj_ = gj; hv = v_hv; nrec = v_rec; found = true; }
+            {
+                const int v = __shfl(hz, (int)(gbase + VC_TL - 1), 64);
+                if (need && !found && gj != 0 && gT == v) { pi_ = gi; pj_ = gj - 1; hv = v; nrec = grec; found = true; }
             }
-            if (!found) { broken = true; break; }
-            if (nout >= a.PC) { ovf = true; break; }
-            if (lane == 0) out[nout] = ((i == pi_ ? 0u : i) << 16) | (j == pj_ ? 0u : j);
-            nout++;
-            i = pi_; j = pj_; Tij = hv; rec = pi_ ? nrec : zero4;
+            if (need) {
+                if (!found) { gbroken = true; walking = false; }
+                else if (gnout >= a.PC) { govf = true; walking = false; }
+                else {
+                    if (gl == 0) out[gnout] = ((gi == pi_ ? 0u : gi) << 16) | (gj == pj_ ? 0u : gj);
+                    gnout++;
+                    gi = pi_; gj = pj_; gT = hv; grec = pi_ ? nrec : zero4;
+                }
+            }
         }
     }
-    if (lane == 0) {
-        if (broken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, i); nout = 0; }
-        if (ovf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, nout); nout = 0; }
-        a.npairs[pj] = nout;
-        atomicAdd(a.stat + 4, (unsigned long long)nout);
+    if (valid && gl == 0) {
+        if (gbroken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, gi); gnout = 0; }
+        if (govf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, gnout); gnout = 0; }
+        a.npairs[pj] = gnout;
+        atomicAdd(a.stat + 4, (unsigned long long)gnout);
         atomicAdd(a.stat + 5, (unsigned long long)nspec_ok);
         atomicAdd(a.stat + 6, (unsigned long long)nrounds);
     }
