@@ -233,7 +233,8 @@ void flush_events(vc_ctx* c) {
 
 template <int CA, int CB>
 void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs) {
-    hipLaunchKernelGGL((k_fwd<CA, CB, kRing>), dim3(jobs), dim3(64), 0, st, a);
+    static const uint32_t pad = getenv("VC_FWD_LDS_PAD") ? (uint32_t)atoi(getenv("VC_FWD_LDS_PAD")) : 0u;   // experiment: cap k_fwd's share of a CU
+    hipLaunchKernelGGL((k_fwd<CA, CB, kRing>), dim3(jobs), dim3(64), pad, st, a);
 }
 
 // One launch when the batch's sequences fall into one width class or two adjacent ones (the usual case:

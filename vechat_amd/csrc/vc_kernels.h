@@ -965,54 +965,42 @@ __device__ __forceinline__ int pk_lo(uint32_t a) { return (int)(short)(a & 0xFFF
 __device__ __forceinline__ int pk_hi(uint32_t a) { return (int)a >> 16; }
 
 // Stored form of a DP row.  Along a row the tilted scores never decrease and two neighbours differ by at
-// most max(m, n) - 2g (diagonal vs the vertical-then-horizontal detour), so when that bound fits a nibble
-// (it is 11 for the scores VeChat uses) a lane's CPL cells are kept as one absolute int16 (its first cell)
-// plus CPL-1 four-bit steps: word 0 = first cell | step_1 << 16; word 1+t holds the step pairs
-// q = 1+4t .. 4+4t (cells 2q, 2q+1) as (step_2q << 4u) | (step_2q+1 << (16 + 4u)), u = q-1-4t.
-// That is 8 bytes per lane per row for 6..12 cells per lane instead of 2 bytes per cell -- the kernel is
-// bound by HBM write bandwidth, not by VALU.  Other score sets keep raw packed int16 pairs.
-__host__ __device__ constexpr int vc_nds(int cpl) { return 1 + (cpl / 2 - 1 + 3) / 4; }
-__host__ __device__ inline bool vc_row_packed(int m, int n, int g) { return g < 0 && (m > n ? m : n) - 2 * g <= 15; }
+// most max(m, n) - 2g (diagonal vs the vertical-then-horizontal detour), so inside a lane's CPL cells a
+// score stays within (CPL-1)*(max(m,n)-2g) of the lane's first cell.  When that fits a byte (99 for the
+// scores VeChat uses at 10 cells per lane) only the LOW BYTE of every cell is stored, followed by the
+// first cell as a full int16: bytes 0..CPL-1 = cells, bytes CPL, CPL+1 = anchor.  A reader rebuilds
+// T_c = anchor + ((byte_c - anchor) & 0xFF).  That is CPL+2 bytes per lane per row instead of 2*CPL, and
+// packing costs one v_perm_b32 per four cells.  Other score sets keep raw packed int16 pairs.
+__host__ __device__ constexpr int vc_nds(int cpl) { return (cpl + 2 + 3) / 4; }
+__host__ __device__ inline bool vc_row_packed(int m, int n, int g, int cpl) {
+    return g < 0 && (cpl - 1) * ((m > n ? m : n) - 2 * g) <= 255;
+}
 
 template <int ND, int NDS>
 __device__ __forceinline__ void vc_pack_row(const uint32_t (&T)[ND], uint32_t (&w)[NDS]) {
-    w[0] = pk_sub(T[0], T[0] << 16);
 #pragma unroll
-    for (int q = 1; q < ND; ++q) {
-        const uint32_t e = pk_sub(T[q], __builtin_amdgcn_alignbit(T[q], T[q - 1], 16));
-        const int t = (q - 1) / 4, u = (q - 1) & 3;
-        w[1 + t] = u == 0 ? e : ((e << (4 * u)) | w[1 + t]);
-    }
+    for (int t = 0; t < ND / 2; ++t) w[t] = __builtin_amdgcn_perm(T[2 * t + 1], T[2 * t], 0x06040200u);
+    if (ND & 1) w[ND / 2] = __builtin_amdgcn_perm(T[0], T[ND - 1], 0x05040200u);     // two cells + the anchor
+    else        w[ND / 2] = T[0];                                                    // anchor in the low half
 }
 template <int ND, int NDS>
 __device__ __forceinline__ void vc_unpack_row(const uint32_t (&w)[NDS], uint32_t (&T)[ND]) {
-    uint32_t c = w[0] & 0xFFFFu;
-    uint32_t d = c + ((w[0] >> 16) & 15u);
-    T[0] = c | (d << 16);
+    const uint32_t aw = (ND & 1) ? (w[ND / 2] >> 16) : (w[ND / 2] & 0xFFFFu);
+    const uint32_t a2 = aw * 0x10001u, alo = (aw & 0xFFu) * 0x10001u;
 #pragma unroll
-    for (int q = 1; q < ND; ++q) {
-        const int t = (q - 1) / 4, u = (q - 1) & 3;
-        c = d + ((w[1 + t] >> (4 * u)) & 15u);
-        d = c + ((w[1 + t] >> (16 + 4 * u)) & 15u);
-        T[q] = (c & 0xFFFFu) | (d << 16);
+    for (int q = 0; q < ND; ++q) {
+        // bytes 2q, 2q+1 of the cell string -> low bytes of the two halves
+        const uint32_t src = w[q / 2];
+        const uint32_t two = (q & 1) ? __builtin_amdgcn_perm(0u, src, 0x0C030C02u) : __builtin_amdgcn_perm(0u, src, 0x0C010C00u);
+        T[q] = pk_add(a2, pk_sub(two, alo) & 0x00FF00FFu);
     }
 }
-// one cell of a packed row (k_trace): words of the lane that owns the cell, cell index cc inside the lane
-__device__ __forceinline__ int vc_packed_cell(const uint32_t* w, uint32_t cc) {
-    const uint32_t w0 = w[0], w1 = w[1];                      // both unconditional: one round trip
-    int v = (int)(short)(w0 & 0xFFFFu);
-    if (cc >= 1) v += (int)((w0 >> 16) & 15u);
-    if (cc >= 2) {
-        const uint32_t ne = cc >> 1, no = (cc - 1) >> 1;      // pairs whose even / odd cell is <= cc
-        for (uint32_t t = 0; 4 * t < ne; ++t) {
-            const uint32_t ae = min(ne - 4 * t, 4u), ao = no > 4 * t ? min(no - 4 * t, 4u) : 0u;
-            const uint32_t mask = ((1u << (4 * ae)) - 1u) | (((1u << (4 * ao)) - 1u) << 16);
-            const uint32_t x = (t == 0 ? w1 : w[1 + t]) & mask;
-            const uint32_t y = (x & 0x0F0F0F0Fu) + ((x >> 4) & 0x0F0F0F0Fu);
-            v += (int)((y * 0x01010101u) >> 24);
-        }
-    }
-    return v;
+// one cell of a packed row (backtrack): words of the lane that owns the cell, cell index cc inside the lane
+__device__ __forceinline__ int vc_packed_cell(const uint32_t* w, uint32_t cc, uint32_t cpl) {
+    const uint32_t wc = w[cc >> 2], wa = w[cpl >> 2];                 // both unconditional: one round trip
+    const uint32_t an = (wa >> ((cpl & 2) * 8)) & 0xFFFFu;
+    const uint32_t b = (wc >> ((cc & 3) * 8)) & 0xFFu;
+    return (int)(short)an + (int)((b - an) & 0xFFu);
 }
 
 // The forward DP works on the TILTED matrix T[i][j] = H[i][j] - j*g.  In that domain the horizontal
@@ -1092,7 +1080,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     }
 
     uint32_t* const hrow0 = a.hmat + (uint64_t)job * a.hstride;
-    const bool packed = vc_row_packed(m, n, g);
+    const bool packed = vc_row_packed(m, n, g, CPL);
     int16_t* const c0p_out = a.c0 + (uint64_t)job * a.NC;
     const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
 
@@ -1297,6 +1285,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
             uint32_t* hr = hrow + lane * NDS;
             if (NDS == 2) *reinterpret_cast<uint2*>(hr) = make_uint2(wv[0], wv[1]);
             else if (NDS == 4) *reinterpret_cast<uint4*>(hr) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            else if (NDS == 3) { struct __attribute__((packed, aligned(4))) u3 { uint32_t a, b, c; }; *reinterpret_cast<u3*>(hr) = u3{wv[0], wv[1], wv[2]}; }
             else {
 #pragma unroll
                 for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
@@ -1365,6 +1354,9 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
 template <int CA, int CB, int RING>
 __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     __shared__ uint32_t ring_raw[RING * (CB / 2) * 64];
+#ifdef VC_EXP_VGPR_CLOBBER
+    asm volatile("" ::: VC_EXP_VGPR_CLOBBER);
+#endif
     if (CA != CB) {
         // sequence length of this job decides the body (uniform per wave)
         const uint32_t job = blockIdx.x, slot = job / a.group;
@@ -1426,16 +1418,16 @@ __global__ void k_trace(VcTraceArgs a) {
     const uint64_t so = a.b.seq_off[a.b.win_seq_off[w] + k];
     const uint32_t* hm32 = a.hmat + (uint64_t)job * a.hstride;
     const uint16_t* hm = (const uint16_t*)hm32;
-    const bool packed = vc_row_packed(m, n, g);
     const int16_t* c0 = a.c0 + (uint64_t)job * a.NC;
     const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[a.b.win_seq_off[w] + k + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
+    const bool packed = vc_row_packed(m, n, g, (int)cpl);
     // k_fwd stores the tilted matrix T[r][col] = H[r][col] - col*g; the tests of sisd :392-448 become
     // diagonal T == T' + (score - g), vertical T == T' + g, horizontal T == T', SW stop T == -col*g
     auto Hat = [&](uint32_t r, uint32_t col) -> int {     // T[r][col] incl. the virtual row 0 / column 0
         if (r == 0) return nw ? 0 : -(int)col * g;
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
-        if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc);
+        if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl);
         return (int)(short)hm[((uint64_t)(r - 1) * nd * 64 + (cc >> 1) * 64 + lc) * 2 + (cc & 1)];
     };
     uint32_t nout = 0;
@@ -1465,7 +1457,7 @@ __global__ void k_trace(VcTraceArgs a) {
                     const uint32_t pr0 = i - (isovf ? delta_of(0) : (rec.y & 0xFFFF));
                     // unconditional, branch-free addresses so the three loads are in flight together
                     const uint32_t rr = pr0 ? pr0 : 1, cc1 = j > 1 ? j - 2 : 0, lc = cc1 / cpl, cw = cc1 % cpl;
-                    const int v0raw = packed ? vc_packed_cell(hm32 + (uint64_t)(rr - 1) * nds * 64 + lc * nds, cw)
+                    const int v0raw = packed ? vc_packed_cell(hm32 + (uint64_t)(rr - 1) * nds * 64 + lc * nds, cw, cpl)
                                              : (int)(short)hm[((uint64_t)(rr - 1) * nd * 64 + (cw >> 1) * 64 + lc) * 2 + (cw & 1)];
                     const uint32_t bs = a.b.bases[so + j - 1];
                     const uint4 q0 = a.dp.rec[nb + rr - 1];
@@ -1550,9 +1542,9 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     const uint64_t so = a.b.seq_off[sq];
     const uint32_t* hm32 = a.hmat + (uint64_t)(valid ? job : 0) * a.hstride;
     const uint16_t* hm = (const uint16_t*)hm32;
-    const bool packed = vc_row_packed(m, n, g);
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
     const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
+    const bool packed = vc_row_packed(m, n, g, (int)cpl);
     const uint32_t nrows = valid ? a.dp.nrows[slot] : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
     // horizontal T == T', SW stop T == -col*g
@@ -1560,7 +1552,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         if (r == 0) return nw ? 0 : -(int)col * g;
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
-        if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc);
+        if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl);
         return (int)(short)hm[((uint64_t)(r - 1) * nd * 64 + (cc >> 1) * 64 + lc) * 2 + (cc & 1)];
     };
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
