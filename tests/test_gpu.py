@@ -73,6 +73,16 @@ def test_racon_linear_overload_parity(built, seed, L, D, n, kw):
         c.close()
 
 
+def test_tie_resolution_by_exact_dfs(built, monkeypatch):
+    """End-cell ties are normally settled by the closure shortcut; force the exact-DFS fallback (which works
+    out of an HBM workspace) on every tie and require the same bytes."""
+    monkeypatch.setenv("VC_RESOLVE_FORCE_DFS", "1")
+    c = HipContext(device=0)
+    for seed, L, D, n, kw in [(1001, 500, 32, 8, {}), (13, 500, 40, 6, dict(n_haplotypes=2, snp_rate=0.02, frac_partial=0.2))]:
+        _check(c, capi.synth_batch(capi.synth_cfg(seed, L, D, **kw), 0, n), f"dfs seed{seed}")
+    c.close()
+
+
 def test_prune_parameters_and_rounds(built):
     batch = capi.synth_batch(capi.synth_cfg(41, 180, 14, n_haplotypes=2, snp_rate=0.03), 0, 6)
     for kw in (dict(num_prune=1), dict(num_prune=2), dict(num_prune=4, min_confidence=0.22, min_support=0.19),

@@ -34,6 +34,7 @@ const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace"
 
 constexpr int kRing = 8;      // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
 constexpr int kMaxStreams = 4;
+constexpr uint32_t kResolveGrid = 128;   // workgroups of k_resolve (each owns one DFS workspace in HBM)
 
 uint32_t topo_lds_bytes(uint32_t NC, uint32_t EC, uint32_t STK) {
     return ((2 * NC + 15) & ~15u) + 4 * EC + 8 * NC + ((NC + 15) & ~15u) + 2 * STK + 2 * NC + 64;
@@ -44,7 +45,7 @@ struct Work {
     hipStream_t stream = nullptr;
     VcGraph gr[2]{};
     VcDp dp{};
-    uint32_t* d_hmat = nullptr; int16_t* d_c0 = nullptr;
+    uint32_t* d_hmat = nullptr; int16_t* d_c0 = nullptr; uint8_t* d_resolve_ws = nullptr;
     uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
     uint16_t* d_tie_rows = nullptr; uint8_t* d_tie_cnt = nullptr; uint32_t* d_tie_list = nullptr; uint32_t* d_tie_n = nullptr;
     uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
@@ -84,6 +85,7 @@ struct vc_ctx {
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
     bool trace_wave = true;
+    bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
     uint32_t trace_lds_mult = 1;
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
@@ -163,6 +165,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_resolve_ws, (size_t)kResolveGrid * ((topo_lds_bytes(NC, c->EC, c->STK) + 15u) & ~15u))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_c0, (size_t)c->jobs_cap * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_end, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_type, c->jobs_cap)) ||
@@ -338,9 +341,11 @@ struct Plan {
         int rc = launch_fwd(c, wk.stream, fa, ns);
         if (rc) return rc;
         { Timer t(c, KC_RESOLVE, wk.stream);
-          hipLaunchKernelGGL(k_resolve, dim3(128), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
+          const uint32_t rs_lds = 4 * ((NC + 31) / 32 + 1) + 2 * 256 + 16;
+          hipLaunchKernelGGL(k_resolve, dim3(kResolveGrid), dim3(64), rs_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
                              (const uint16_t*)wk.d_tie_rows, (const uint8_t*)wk.d_tie_cnt, wk.d_job_end,
-                             (const uint32_t*)wk.d_tie_list, (const uint32_t*)wk.d_tie_n, (const uint32_t*)wk.d_submask, (int)j); }
+                             (const uint32_t*)wk.d_tie_list, (const uint32_t*)wk.d_tie_n, (const uint32_t*)wk.d_submask, (int)j,
+                             wk.d_resolve_ws, (topo_lds + 15u) & ~15u, c->force_dfs ? 1 : 0); }
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
@@ -466,6 +471,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->device = p->device;
     c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 2;
     if (getenv("VC_TRACE_LDS_MULT")) c->trace_lds_mult = (uint32_t)atoi(getenv("VC_TRACE_LDS_MULT"));
+    c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }
     for (uint32_t s = 0; s < c->n_streams; ++s) {
@@ -655,7 +661,6 @@ int vc_run(vc_ctx* c) {
     HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.topo_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prune_lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.topo_lds));
     if (c->prm.mode == 1)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.cons_lds));
     HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64, c->stream));

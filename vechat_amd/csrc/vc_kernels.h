@@ -750,10 +750,10 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
 // order (sisd :353-355 with `<`).  For alignments done on the incremental order and ending in such a
 // tie, run the exact TopologicalSort DFS now and choose the tied sink with the smallest rank.
 // ------------------------------------------------------------------------------------------------
-__device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b, const VcGraph& g, const VcDp& dp,
+__device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const VcBatchDev& b, const VcGraph& g, const VcDp& dp,
                                uint32_t w0, uint32_t nslots, uint32_t NC, uint32_t EC, uint32_t STK,
                                const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end,
-                               const uint32_t* submask, int layer) {
+                               const uint32_t* submask, int layer, int force_dfs) {
     if (slot >= nslots) return;
     const uint32_t w = w0 + slot;
     const uint32_t nt = tie_cnt[slot];
@@ -856,11 +856,15 @@ __device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b
             if (win) job_end[slot] = (win << 16) | (job_end[slot] & 0xFFFF);
         }
         __syncthreads();
-        if (s_fast) return;
+        if (s_fast && !force_dfs) return;
     }
 
-    const VcTopoLds t = vc_topo_carve(smem, NC, EC, STK);
+    // exact DFS for what the shortcut left undecided.  It is rare (none in the benchmark workload), so it
+    // works out of this workgroup's HBM workspace: the kernel then needs ~1 KB of LDS and can start next
+    // to the forward kernel of another chunk instead of waiting for 60 KB to drain.
+    const VcTopoLds t = vc_topo_carve(gws, NC, EC, STK);
     vc_topo_load(g, nb, eb, N, E, t, lane);
+    __threadfence_block();
     __syncthreads();
     __shared__ uint32_t s_nrows;
     __shared__ int s_err;
@@ -871,6 +875,7 @@ __device__ void vc_resolve_one(uint8_t* smem, uint32_t slot, const VcBatchDev& b
         s_err = vc_topo_dfs(t, N, STK, masked, mb, me, &nr);
         s_nrows = nr;
     }
+    __threadfence_block();
     __syncthreads();
     if (s_err) { if (lane == 0) vc_fail(b, w, s_err, 14, s_nrows); return; }
     // exact rank of each tied row's node
@@ -893,13 +898,14 @@ __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp
                                                 uint32_t NC, uint32_t EC, uint32_t STK,
                                                 const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end,
                                                 const uint32_t* tie_list, const uint32_t* tie_n,
-                                                const uint32_t* submask, int layer) {
+                                                const uint32_t* submask, int layer, uint8_t* workspace, uint32_t ws_bytes, int force_dfs) {
     VC_LATENCY_KERNEL_PRIO();
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];     // visit bitmap [NC/32 + 1] words + stack [256] u16
     const uint32_t n = *tie_n;
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
         __syncthreads();
-        vc_resolve_one(smem, tie_list[idx], b, g, dp, w0, nslots, NC, EC, STK, tie_rows, tie_cnt, job_end, submask, layer);
+        vc_resolve_one(smem, workspace + (size_t)blockIdx.x * ws_bytes, tie_list[idx], b, g, dp, w0, nslots, NC, EC, STK, tie_rows, tie_cnt,
+                       job_end, submask, layer, force_dfs);
     }
 }
 
