@@ -655,7 +655,7 @@ int vc_run(vc_ctx* c) {
     pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK);
     pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
     pl.add_lds = 2 * c->PC + 2 * (c->PC - c->NC) + 64;
-    pl.rows_lds = c->NC + 64;
+    pl.rows_lds = 0;
     pl.cons_lds = vc_cons_lds_bytes(c->NC, c->EC);
     pl.rowd = 64ull * (c->cpl / 2);
     HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.topo_lds));

@@ -19,7 +19,6 @@
 
 // row record flags
 #define VC_RF_SINK  1u
-#define VC_RF_SPILL 2u     // a successor lies beyond the LDS ring and will read this row back from the H matrix
 #define VC_RF_OVF   4u
 #define VC_RF_PREV  8u     // one of the predecessors is the row directly above (still in registers)
 #define VC_RF_SLOW  16u    // frec only: a listed predecessor is the virtual row 0 or lies beyond the LDS ring, or the list overflowed

@@ -79,7 +79,7 @@ __device__ __forceinline__ bool vc_full_span(uint32_t begin, uint32_t end, uint3
 // the virtual row 0, a row older than the LDS ring, or more predecessors than fit (list in VcDp::ovf).
 __device__ __forceinline__ uint4 vc_make_frec(uint32_t code, uint32_t fl, uint32_t np, const uint16_t (&dl)[VC_INLINE_PRED],
                                               bool is_ovf, bool hasprev, uint32_t r, uint32_t ring) {
-    uint32_t f = fl & (VC_RF_SINK | VC_RF_SPILL | VC_RF_OVF);
+    uint32_t f = fl & (VC_RF_SINK | VC_RF_OVF);
     uint16_t out[VC_INLINE_PRED];
 #pragma unroll
     for (int k = 0; k < VC_INLINE_PRED; ++k) out[k] = 0;
@@ -360,8 +360,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
     // ---- row records (wave-parallel).  s_al is dead now: alias node->rank and two byte maps into it.
     uint16_t* s_noderank = s_al;                       // [NC]
     uint8_t*  s_hasout = (uint8_t*)(s_al + NC);        // [NC] by node
-    uint8_t*  s_spill = s_hasout + NC;                 // [NC] by rank
-    for (uint32_t i = lane; i < N; i += 64) { s_hasout[i] = 0; s_spill[i] = 0; }
+    for (uint32_t i = lane; i < N; i += 64) s_hasout[i] = 0;
     __syncthreads();
     for (uint32_t r = lane; r < nrows; r += 64) {
         uint32_t v = s_rank[r];
@@ -370,7 +369,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
     }
     __syncthreads();
     const uint8_t need = masked ? TF_SUB : 0;
-    // pass 1: out-degree and far-successor marks
+    // pass 1: out-degree
     for (uint32_t r = lane; r < nrows; r += 64) {
         uint32_t v = s_rank[r];
         for (uint32_t e = s_in_first[v]; e != VC_NONE16; ) {
@@ -379,8 +378,6 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
             e = tn >> 16;
             if ((s_flag[t] & need) != need) continue;
             s_hasout[t] = 1;
-            uint32_t delta = r - s_noderank[t];
-            if (delta > ring) s_spill[s_noderank[t]] = 1;
         }
     }
     __syncthreads();
@@ -412,7 +409,6 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         bool is_ovf = np > VC_INLINE_PRED;
         uint32_t tot_ovf;
         uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
-        uint32_t sp_flag = act ? s_spill[r] : 0u;
         if (act) {
             if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }   // virtual row 0 is `row` rows above
             if (np > 255) bad = 1;
@@ -432,7 +428,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
                 }
                 dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
             }
-            uint32_t fl = (s_hasout[v] ? 0u : VC_RF_SINK) | (sp_flag ? VC_RF_SPILL : 0u) | (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
+            uint32_t fl = (s_hasout[v] ? 0u : VC_RF_SINK) | (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
             uint4 rec;
             rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
             rec.y = dl[0] | ((uint32_t)dl[1] << 16);
@@ -463,7 +459,6 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
                                              uint32_t NC, uint32_t EC, int next_layer, uint32_t ring) {
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* s_spill = smem;                                  // [NC] by row
     const uint32_t slot = blockIdx.x;
     if (slot >= nslots) return;
     const uint32_t w = w0 + slot;
@@ -477,22 +472,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
     }
     const uint32_t N = g.n_nodes[slot];
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
-    for (uint32_t i = lane; i < N; i += 64) s_spill[i] = 0;
-    __syncthreads();
     int bad = 0, broken = 0;
-    // pass 1: rows a far successor will need from HBM
-    for (uint32_t r = lane; r < N; r += 64) {
-        const uint32_t v = g.ord[nb + r];
-        for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
-            const uint32_t tn = g.e_tn[eb + e];
-            e = tn >> 16;
-            const uint32_t pt = g.pos[nb + (tn & 0xFFFF)];
-            if (pt >= r) broken = 1;
-            else if (r - pt > ring) s_spill[pt] = 1;
-        }
-    }
-    __syncthreads();
-    // pass 2: records
     uint32_t ovf_base = 0;
     for (uint32_t r0 = 0; r0 < N; r0 += 64) {
         const uint32_t r = r0 + lane;
@@ -507,7 +487,9 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
             for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
                 const uint32_t tn = g.e_tn[eb + e];
                 e = tn >> 16;
-                const uint32_t delta = r - g.pos[nb + (tn & 0xFFFF)];
+                const uint32_t pt = g.pos[nb + (tn & 0xFFFF)];
+                if (pt >= r) broken = 1;                         // the kept order must stay topological
+                const uint32_t delta = r - pt;
 #pragma unroll
                 for (int k = 0; k < VC_INLINE_PRED; ++k) if (np == (uint32_t)k) dl[k] = (uint16_t)delta;
                 np++;
@@ -517,7 +499,6 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
         const bool is_ovf = np > VC_INLINE_PRED;
         uint32_t tot_ovf;
         const uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
-        const uint32_t sp_flag = act ? s_spill[r] : 0u;
         if (act) {
             if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }
             if (np > 255) bad = 1;
@@ -535,7 +516,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
                 }
                 dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
             }
-            const uint32_t fl = (g.out_first[nb + v] == VC_NONE16 ? VC_RF_SINK : 0u) | (sp_flag ? VC_RF_SPILL : 0u) |
+            const uint32_t fl = (g.out_first[nb + v] == VC_NONE16 ? VC_RF_SINK : 0u) |
                                 (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
             uint4 rec;
             rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
@@ -588,10 +569,8 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
     const uint32_t nW = (NC + 63) / 64;
     unsigned long long* s_mem = (unsigned long long*)smem;                 // [nW] member bit per POSITION
     uint16_t* s_rowidx = (uint16_t*)(s_mem + nW);                          // [NC] row of a member position
-    uint8_t* s_spill = (uint8_t*)(s_rowidx + NC);                          // [NC] by row
-    uint32_t* s_sub = (uint32_t*)(s_spill + ((NC + 15) & ~15u));           // [NC/32+1] member bit per NODE id
+    uint32_t* s_sub = (uint32_t*)(s_rowidx + ((NC + 1) & ~1u));            // [NC/32+1] member bit per NODE id
     for (uint32_t i = lane; i < nW; i += 64) s_mem[i] = 0;
-    for (uint32_t i = lane; i < NC; i += 64) s_spill[i] = 0;
     for (uint32_t i = lane; i < NC / 32 + 1; i += 64) s_sub[i] = 0;
     __syncthreads();
     auto is_mem = [&](uint32_t p) -> bool { return (s_mem[p >> 6] >> (p & 63)) & 1ull; };
@@ -654,22 +633,7 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
     __syncthreads();
     if (nrows == 0) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 21, 0); return; }
     int bad = 0, broken = 0;
-    // pass 1: rows a far successor will need from HBM
-    for (uint32_t p = lane; p <= ptop && p < N; p += 64) {
-        if (!is_mem(p)) continue;
-        const uint32_t r = s_rowidx[p], v = g.ord[nb + p];
-        for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
-            const uint32_t tn = g.e_tn[eb + e];
-            e = tn >> 16;
-            const uint32_t pt = g.pos[nb + (tn & 0xFFFF)];
-            if (pt > ptop || !is_mem(pt)) continue;
-            const uint32_t rt = s_rowidx[pt];
-            if (rt >= r) broken = 1;
-            else if (r - rt > ring) s_spill[rt] = 1;
-        }
-    }
-    __syncthreads();
-    // pass 2: records, block by block in position order
+    // records, block by block in position order
     uint32_t ovf_base = 0;
     for (uint32_t B = 0; B <= (ptop >> 6); ++B) {
         const uint32_t p = B * 64 + lane;
@@ -686,6 +650,7 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
                 e = tn >> 16;
                 const uint32_t pt = g.pos[nb + (tn & 0xFFFF)];
                 if (pt > ptop || !is_mem(pt)) continue;
+                if (s_rowidx[pt] >= r) broken = 1;               // the kept order must stay topological
                 const uint32_t delta = r - s_rowidx[pt];
 #pragma unroll
                 for (int k = 0; k < VC_INLINE_PRED; ++k) if (np == (uint32_t)k) dl[k] = (uint16_t)delta;
@@ -721,8 +686,7 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
                 const uint32_t ph = g.pos[nb + (hn & 0xFFFF)];
                 hasout = ph <= ptop && is_mem(ph);
             }
-            const uint32_t sp_flag = s_spill[r];
-            const uint32_t fl = (hasout ? 0u : VC_RF_SINK) | (sp_flag ? VC_RF_SPILL : 0u) | (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
+            const uint32_t fl = (hasout ? 0u : VC_RF_SINK) | (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
             uint4 rec;
             rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
             rec.y = dl[0] | ((uint32_t)dl[1] << 16);
@@ -1182,7 +1146,8 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
                     } else if (delta <= (uint32_t)RING) {
                         ringrow(delta, hA, cA);
                     } else {
-                        if (packed) {                                                 // my own earlier stores
+                        __threadfence_block();                                        // my own earlier stores must have landed
+                        if (packed) {
                             const uint32_t* hr = hrow0 + (uint64_t)(pr - 1) * (NDS * 64) + lane * NDS;
                             uint32_t wv[NDS];
 #pragma unroll
@@ -1303,7 +1268,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
             for (int q = 0; q < ND; ++q) hrow[q * 64 + lane] = acc[q];
         }
         hrow += rowdw;
-        bool fence = (fl & VC_RF_SPILL) != 0;                 // a far successor will load this row back
+        bool fence = false;
         if (ri == 63 || i == nrows) {                         // column 0 of the block just completed
             if ((uint32_t)lane <= ri) c0p_out[i - 1 - ri + lane] = (int16_t)c0vec;
             fence = true;
