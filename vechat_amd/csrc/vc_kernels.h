@@ -1483,7 +1483,7 @@ __global__ void k_trace(VcTraceArgs a) {
 // ------------------------------------------------------------------------------------------------
 #define VC_TG 4
 #define VC_TL 16
-__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t NC) { return VC_TG * 2 * (NC + 2); }
+__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t NC) { return VC_TG * ((NC + 2 + 3) & ~3u); }
 __device__ __forceinline__ int vc_row_shr1(int v, int first) {          // value of the lane to the left inside a 16-lane row
     return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false);
 }
@@ -1493,7 +1493,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = vc_lane();
     const uint32_t grp = (uint32_t)lane / VC_TL, gl = (uint32_t)lane % VC_TL, gbase = grp * VC_TL;
-    uint16_t* tab = reinterpret_cast<uint16_t*>(smem) + grp * (a.NC + 2);   // first in-edge distance of row r (0: do not speculate)
+    uint8_t* tab = smem + grp * ((a.NC + 2 + 3) & ~3u);      // first in-edge distance of row r (0: do not speculate)
     const uint32_t njobs = a.nslots * a.group;
     const uint32_t job = blockIdx.x * VC_TG + grp;
     bool valid = job < njobs;
@@ -1536,7 +1536,8 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     bool walking = valid && end != 0;
     for (uint32_t r = gl; walking && r < nrows; r += VC_TL) {
         const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + r]);
-        tab[r + 1] = ((q.x >> 8) & VC_RF_OVF) ? (uint16_t)0 : (uint16_t)(q.y & 0xFFFF);
+        const uint32_t d0 = q.y & 0xFFFF;
+        tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint8_t)0 : (uint8_t)d0;
     }
     __syncthreads();
     uint32_t gi = end >> 16, gj = end & 0xFFFF, gnout = 0, nspec_ok = 0, nrounds = 0;
