@@ -115,6 +115,24 @@ def test_result_is_independent_of_chunking(built):
     a.close(); b.close()
 
 
+def test_overlong_sequence_is_a_per_window_status(built):
+    """A layer longer than the forward kernel's 2 048 columns marks ITS window unsupported; the rest of the
+    batch is processed and stays byte-identical to the oracle."""
+    good = capi.synth_batch(capi.synth_cfg(81, 120, 6), 0, 3)
+    wins = [good.window(w) for w in range(3)]
+    seqs, quals, b, e = good.window(1)
+    long_layer = (seqs[1] * 20)[:2100]
+    bad = (seqs[:1] + [long_layer] + seqs[2:], quals[:1] + [None] + quals[2:], b, e)
+    batch = capi.Batch.from_windows([wins[0], bad, wins[2]], [0, 0, 0], presorted=True)
+    c = HipContext(device=0)
+    cons, status = c.consensus(batch, retry_overflow=False)
+    assert int(status[1]) == capi.VC_WIN_UNSUPPORTED and cons[1] == b""
+    ref, pol, _ = oa.oracle_run(good, c.params)
+    for w in (0, 2):
+        assert int(status[w]) == capi.VC_WIN_OK and cons[w] == ref[w]
+    c.close()
+
+
 def test_overflow_is_reported_not_hidden(built):
     batch = capi.synth_batch(capi.synth_cfg(71, 200, 30), 0, 4)
     c = HipContext(device=0, max_nodes=256, max_edges=640)

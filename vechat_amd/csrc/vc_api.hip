@@ -34,6 +34,7 @@ const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace"
 
 constexpr int kRing = 8;      // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
 constexpr int kMaxStreams = 4;
+constexpr uint64_t kMaxColumns = 2048;     // longest sequence k_fwd takes (64 lanes x 32 columns)
 constexpr uint32_t kResolveGrid = 128;   // workgroups of k_resolve (each owns one DFS workspace in HBM)
 
 uint32_t topo_lds_bytes(uint32_t NC, uint32_t EC, uint32_t STK) {
@@ -84,6 +85,7 @@ struct vc_ctx {
 
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
+    std::vector<uint8_t> h_pre_status;   // per-window status decided at submit (outside the envelope), empty = none
     bool trace_wave = true;
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
     uint32_t trace_lds_mult = 1;
@@ -529,6 +531,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint32_t max_layers = 0, max_len = 0, max_nseq = 0, min_len = 0xFFFFFFFFu;
     uint64_t need_nodes = 0;
     std::vector<uint8_t> layer_partial;
+    std::vector<uint8_t> pre(nw, 0);          // windows outside the device envelope: reported, not run
+    bool any_pre = false;
     for (uint32_t w = 0; w < nw; ++w) {
         const uint32_t s0 = hb->win_seq_off[w], s1 = hb->win_seq_off[w + 1];
         if (s1 <= s0) return fail(c, VC_ERR_ARG, "window %u has no backbone", w);
@@ -536,6 +540,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         if (L == 0 || L >= 65535) return fail(c, VC_ERR_ARG, "window %u: backbone length %llu unsupported", w, (unsigned long long)L);
         if (!hb->seq_has_qual[s0]) return fail(c, VC_ERR_ARG, "window %u: backbone needs a quality string (dummy '!' for FASTA targets)", w);
         uint64_t sum = 0;
+        for (uint32_t s = s0; s < s1; ++s)                        // the forward kernel holds at most 64 lanes x 32 columns
+            if (s1 - s0 >= 3 && hb->seq_off[s + 1] - hb->seq_off[s] > kMaxColumns) pre[w] = VC_WIN_UNSUPPORTED;
         for (uint32_t s = s0; s < s1; ++s) {
             const uint64_t len = hb->seq_off[s + 1] - hb->seq_off[s];
             if (len == 0 || len >= 65535) return fail(c, VC_ERR_ARG, "window %u: sequence length %llu unsupported", w, (unsigned long long)len);
@@ -549,9 +555,12 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
                 if (layer_partial.size() <= j) layer_partial.resize(j + 1, 0);
                 if (!full) layer_partial[j] = 1;
             }
-            max_len = std::max<uint32_t>(max_len, (uint32_t)len);
-            min_len = std::min<uint32_t>(min_len, (uint32_t)len);
+            if (!pre[w]) {
+                max_len = std::max<uint32_t>(max_len, (uint32_t)len);
+                min_len = std::min<uint32_t>(min_len, (uint32_t)len);
+            }
         }
+        if (pre[w]) { any_pre = true; continue; }
         max_layers = std::max(max_layers, s1 - s0 - 1);
         max_nseq = std::max(max_nseq, s1 - s0);
         // graph growth saturates with depth: nodes ~ L + c * mean_layer_len * depth^0.55 (measured on
@@ -589,6 +598,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     c->h_layer_partial = layer_partial;
     c->h_layer_partial.resize(max_nseq + 2, 0);
     c->max_layers = max_layers; c->max_len = max_len;
+    c->h_pre_status = any_pre ? pre : std::vector<uint8_t>();
+    if (max_len == 0) { max_len = 1; min_len = 1; }              // every window was outside the envelope
 
     // capacities
     uint32_t NC = c->prm.max_nodes ? c->prm.max_nodes : (uint32_t)std::min<uint64_t>(need_nodes, 60000);
@@ -665,6 +676,7 @@ int vc_run(vc_ctx* c) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.cons_lds));
     HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
+    if (!c->h_pre_status.empty()) HIPCHK(c, hipMemcpyAsync(b.status, c->h_pre_status.data(), b.n_windows, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, (size_t)b.n_windows * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, uint32_t w
         if (lane == 0) { b.cons_len[w] = n; b.status[w] = L <= b.cons_cap ? VC_WIN_UNPOLISHED : VC_WIN_OVERFLOW; }
         return;
     }
+    if (b.status[w] != VC_WIN_OK) return;                    // marked at submit (outside the envelope)
     if (L > NC || L > EC + 1 || L >= 0xFFFF) { if (lane == 0) vc_fail(b, w, VC_WIN_OVERFLOW, 1, L); return; }
     uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
     for (uint32_t i = lane; i < L; i += 64) {
