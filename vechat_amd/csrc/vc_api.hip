@@ -54,7 +54,8 @@ struct Work {
     uint32_t* d_maxn = nullptr;
     uint16_t* d_scratch16 = nullptr;                                 // k_addaln per-pair notes
     uint32_t* d_submask = nullptr;                                   // [CW*(NC/32+1)] Subgraph membership by node id
-    uint32_t* h_maxn = nullptr;                                      // pinned
+    uint32_t* h_maxn = nullptr;                                      // pinned: [0] max rows, [1] max edges after a prune round
+    bool pruned_known = false;                                       // h_maxn describes the current graphs
     // state of the chunk currently in flight
     uint32_t w0 = 0, ns = 0, layers = 0, nseq_max = 0;
     int cur = 0;
@@ -181,7 +182,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->d_rnpairs, CW * c->max_nseq)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_scratch16, CW * (4 * PC + NC))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_submask, CW * (NC / 32 + 1))) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_maxn, 1)))
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_maxn, 2)))
         return rc;
     return VC_OK;
 }
@@ -315,7 +316,7 @@ struct Plan {
     }
 
     void begin(Work& wk, uint32_t w0, uint32_t ns) {
-        wk.w0 = w0; wk.ns = ns; wk.cur = 0; wk.layers = 0; wk.nseq_max = 0; wk.active = true;
+        wk.w0 = w0; wk.ns = ns; wk.cur = 0; wk.layers = 0; wk.nseq_max = 0; wk.active = true; wk.pruned_known = false;
         for (uint32_t w = w0; w < w0 + ns; ++w) {
             const uint32_t n = c->h_win_seq_off[w + 1] - c->h_win_seq_off[w];
             wk.nseq_max = std::max(wk.nseq_max, n);
@@ -365,17 +366,28 @@ struct Plan {
     // re-alignment round follows, so ask the device how tall the pruned graphs are
     int prune(Work& wk, bool more) {
         const uint32_t ns = wk.ns;
+        // after the first round the host knows how large the pruned graphs are (realign() read the maxima
+        // back), and a graph only shrinks from round to round: size the LDS images for that, not for NC/EC
+        uint32_t NCl = NC, ECl = EC;
+        if (wk.pruned_known) {
+            NCl = std::min(NC, ((wk.h_maxn[0] + 63u) & ~63u));
+            ECl = std::min(EC, ((wk.h_maxn[1] + 63u) & ~63u));
+            if (NCl == 0) NCl = 64;
+            if (ECl == 0) ECl = 64;
+        }
         VcPruneArgs pa{};
         pa.b = c->b; pa.src = wk.gr[wk.cur]; pa.dst = wk.gr[wk.cur ^ 1]; pa.w0 = wk.w0; pa.nslots = ns; pa.NC = NC; pa.EC = EC;
+        pa.NCl = NCl; pa.ECl = ECl;
         pa.min_conf = c->prm.min_confidence; pa.min_supp = c->prm.min_support;
-        { Timer t(c, KC_PRUNE, wk.stream); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), prune_lds, wk.stream, pa); }
+        { Timer t(c, KC_PRUNE, wk.stream); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), vc_prune_lds_bytes(NCl, ECl), wk.stream, pa); }
         wk.cur ^= 1;
         { Timer t(c, KC_TOPO, wk.stream);
-          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing); }
+          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds_bytes(NCl, ECl, c->STK), wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NCl, ECl); }
         if (more) {
-            HIPCHK(c, hipMemsetAsync(wk.d_maxn, 0, 4, wk.stream));
+            HIPCHK(c, hipMemsetAsync(wk.d_maxn, 0, 8, wk.stream));
             hipLaunchKernelGGL(k_max_u32, dim3((ns + 255) / 256), dim3(256), 0, wk.stream, wk.dp.nrows, ns, wk.d_maxn);
-            HIPCHK(c, hipMemcpyAsync(wk.h_maxn, wk.d_maxn, 4, hipMemcpyDeviceToHost, wk.stream));
+            hipLaunchKernelGGL(k_max_u32, dim3((ns + 255) / 256), dim3(256), 0, wk.stream, (const uint32_t*)wk.gr[wk.cur].n_edges, ns, wk.d_maxn + 1);
+            HIPCHK(c, hipMemcpyAsync(wk.h_maxn, wk.d_maxn, 8, hipMemcpyDeviceToHost, wk.stream));
         }
         return VC_OK;
     }
@@ -384,7 +396,8 @@ struct Plan {
     int realign(Work& wk) {
         const uint32_t ns = wk.ns;
         HIPCHK(c, hipStreamSynchronize(wk.stream));          // h_maxn
-        uint32_t maxn = *wk.h_maxn;
+        uint32_t maxn = wk.h_maxn[0];
+        wk.pruned_known = true;
         if (maxn == 0) maxn = 1;
         if (maxn > NC) maxn = NC;
         const uint64_t stride = (uint64_t)maxn * rowd;
@@ -415,7 +428,7 @@ struct Plan {
     int linear_tail(Work& wk) {
         const uint32_t ns = wk.ns;
         { Timer t(c, KC_TOPO, wk.stream);
-          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing); }
+          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NC, EC); }
         VcConsArgs ca{};
         ca.b = c->b; ca.g = wk.gr[wk.cur]; ca.dp = wk.dp; ca.w0 = wk.w0; ca.nslots = ns; ca.NC = NC; ca.EC = EC;
         ca.trim = c->prm.trim; ca.window_type = c->prm.window_type;

@@ -320,7 +320,10 @@ __device__ int vc_topo_dfs(const VcTopoLds& ls, uint32_t N, uint32_t STK, bool m
 }
 
 __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                             uint32_t NC, uint32_t EC, uint32_t STK, int next_layer, int only_masked, uint32_t ring) {
+                                             uint32_t NC, uint32_t EC, uint32_t STK, int next_layer, int only_masked, uint32_t ring,
+                                             uint32_t NCl, uint32_t ECl) {
+    // NC/EC: strides of the graph arrays in HBM; NCl/ECl: capacity the LDS image was sized for (the host
+    // passes the known maximum after a prune round, so small graphs do not reserve 60 KB per window)
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t slot = blockIdx.x;
@@ -341,7 +344,8 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
     const uint32_t N = g.n_nodes[slot], E = g.n_edges[slot];
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
 
-    const VcTopoLds t = vc_topo_carve(smem, NC, EC, STK);
+    if (N > NCl || E > ECl) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 24, N); return; }
+    const VcTopoLds t = vc_topo_carve(smem, NCl, ECl, STK);
     uint16_t* s_in_first = t.in_first; uint32_t* s_etn = t.etn; uint16_t* s_al = t.al;
     uint8_t* s_flag = t.flag; uint16_t* s_rank = t.rank;
     vc_topo_load(g, nb, eb, N, E, t, lane);
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
 
     // ---- row records (wave-parallel).  s_al is dead now: alias node->rank and two byte maps into it.
     uint16_t* s_noderank = s_al;                       // [NC]
-    uint8_t*  s_hasout = (uint8_t*)(s_al + NC);        // [NC] by node
+    uint8_t*  s_hasout = (uint8_t*)(s_al + NCl);       // [NC] by node
     for (uint32_t i = lane; i < N; i += 64) s_hasout[i] = 0;
     __syncthreads();
     for (uint32_t r = lane; r < nrows; r += 64) {
@@ -1936,6 +1940,7 @@ struct VcPruneArgs {
     VcBatchDev b;
     VcGraph src, dst;
     uint32_t w0, nslots, NC, EC;
+    uint32_t NCl, ECl;            // capacity of the LDS image (<= NC, EC; the host knows the maximum after a round)
     double min_conf, min_supp;
 };
 
@@ -1956,16 +1961,18 @@ __global__ __launch_bounds__(64) void k_prune_lcc(VcPruneArgs a) {
     const uint32_t N = a.src.n_nodes[slot], E = a.src.n_edges[slot];
     const double avg = a.b.win_avg[w];
 
-    uint16_t* s_adj_off = (uint16_t*)smem;                                     // [NC+1]
-    uint16_t* s_adj = (uint16_t*)(smem + ((2 * (NC + 1) + 15) & ~15u));        // [2*EC]
-    uint16_t* s_vis = s_adj + 2 * EC;                                          // [NC] visited, later newid
-    uint16_t* s_nin = s_vis + NC;                                              // [NC] live in-degree
-    uint8_t*  s_keep = (uint8_t*)(s_nin + NC);                                 // [EC]
-    uint32_t* s_osum = (uint32_t*)(s_keep + ((EC + 15) & ~15u));               // [NC]
-    uint32_t* s_isum = s_osum + NC;                                            // [NC]
-    uint32_t* s_frame = s_osum;                                                // [NC] (v | cursor << 16)
-    uint16_t* s_comp = (uint16_t*)(s_frame + NC);                              // [NC]
-    uint16_t* s_best = s_comp + NC;                                            // [NC]
+    const uint32_t NCl = a.NCl, ECl = a.ECl;
+    if (N > NCl || E > ECl) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 25, N); return; }
+    uint16_t* s_adj_off = (uint16_t*)smem;                                     // [NCl+1]
+    uint16_t* s_adj = (uint16_t*)(smem + ((2 * (NCl + 1) + 15) & ~15u));       // [2*ECl]
+    uint16_t* s_vis = s_adj + 2 * ECl;                                         // [NCl] visited, later newid
+    uint16_t* s_nin = s_vis + NCl;                                             // [NCl] live in-degree
+    uint8_t*  s_keep = (uint8_t*)(s_nin + NCl);                                // [ECl]
+    uint32_t* s_osum = (uint32_t*)(s_keep + ((ECl + 15) & ~15u));              // [NCl]
+    uint32_t* s_isum = s_osum + NCl;                                           // [NCl]
+    uint32_t* s_frame = s_osum;                                                // [NCl] (v | cursor << 16)
+    uint16_t* s_comp = (uint16_t*)(s_frame + NCl);                             // [NCl]
+    uint16_t* s_best = s_comp + NCl;                                           // [NCl]
 
     // 1. weight totals around every node (the reference re-sums them per edge, graph.cpp:845-872)
     for (uint32_t v = lane; v < N; v += 64) {
