@@ -323,7 +323,7 @@ struct Plan {
             if (n >= 3) wk.layers = std::max(wk.layers, n - 1);
         }
         (void)hipMemsetAsync(wk.dp.nrows, 0, (size_t)ns * 4, wk.stream);      // skipped windows must not carry a stale height
-        { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3((ns + 63) / 64), dim3(64), 0, wk.stream, c->b, w0, ns); }
+        { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3(ns), dim3(64), 0, wk.stream, c->b, w0, ns); }
         { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), 0, wk.stream, c->b, wk.gr[0], w0, ns, NC, EC); }
     }
 

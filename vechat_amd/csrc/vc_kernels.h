@@ -114,33 +114,40 @@ __device__ __forceinline__ uint4 vc_make_frec(uint32_t code, uint32_t fl, uint32
 // ------------------------------------------------------------------------------------------------
 // k_avg: average_weight per window -- a strictly ordered fp64 sum (window.cpp:225-236,283,292-309)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_avg(VcBatchDev b, uint32_t w0, uint32_t nw) {
+// One wave per window.  The sum is strictly sequential in the reference (a double accumulated base by base
+// in rank order, window.cpp:225-236,283,292-296), so the ORDER of the additions is kept; what is parallel is
+// only the fetch: 64 lanes load 64 qualities and their table values at once, then every lane performs the
+// same 64 dependent additions on values broadcast with v_readlane.
+__global__ __launch_bounds__(64) void k_avg(VcBatchDev b, uint32_t w0, uint32_t nw) {
     VC_LATENCY_KERNEL_PRIO();
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.x;
     if (t >= nw) return;
-    uint32_t w = w0 + t;
-    uint32_t s0 = b.win_seq_off[w], s1 = b.win_seq_off[w + 1];
-    uint64_t o0 = b.seq_off[s0];
-    uint32_t L = (uint32_t)(b.seq_off[s0 + 1] - o0);
-    bool fasta = b.win_fasta[w] != 0;
+    const int lane = vc_lane();
+    const uint32_t w = w0 + t;
+    const uint32_t s0 = b.win_seq_off[w], s1 = b.win_seq_off[w + 1];
+    const uint32_t L = (uint32_t)(b.seq_off[s0 + 1] - b.seq_off[s0]);
+    const bool fasta = b.win_fasta[w] != 0;
     double total = 0.0;
-    if (fasta) {
-        total += (double)L;
-    } else {
-        for (uint32_t q = 0; q < L; ++q) total += b.lut_d[b.quals[o0 + q]];
-    }
-    for (uint32_t s = s0 + 1; s < s1; ++s) {
-        uint64_t o = b.seq_off[s];
-        uint32_t len = (uint32_t)(b.seq_off[s + 1] - o);
-        if (!b.seq_has_qual[s]) {
-            total += (double)len;
-        } else {
-            for (uint32_t q = 0; q < len; ++q) total += b.lut_d[b.quals[o + q]];
+    auto add_quals = [&](uint64_t o, uint32_t len) __attribute__((always_inline)) {
+        for (uint32_t q0 = 0; q0 < len; q0 += 64) {
+            const uint32_t cnt = min(64u, len - q0);
+            const double v = (uint32_t)lane < cnt ? b.lut_d[b.quals[o + q0 + lane]] : 0.0;
+            const int lo = __double2loint(v), hi = __double2hiint(v);
+            for (uint32_t k = 0; k < cnt; ++k)
+                total += __hiloint2double(__builtin_amdgcn_readlane(hi, (int)k), __builtin_amdgcn_readlane(lo, (int)k));
         }
+    };
+    if (fasta) total += (double)L;
+    else add_quals(b.seq_off[s0], L);
+    for (uint32_t s = s0 + 1; s < s1; ++s) {
+        const uint64_t o = b.seq_off[s];
+        const uint32_t len = (uint32_t)(b.seq_off[s + 1] - o);
+        if (!b.seq_has_qual[s]) total += (double)len;
+        else add_quals(o, len);
     }
-    uint16_t wl = (uint16_t)L;                                // window.cpp:216
-    double avg = fasta ? 2.0 * total / wl : 2.0 * total / wl * 1000;
-    b.win_avg[w] = avg;
+    const uint16_t wl = (uint16_t)L;                          // window.cpp:216
+    const double avg = fasta ? 2.0 * total / wl : 2.0 * total / wl * 1000;
+    if (lane == 0) b.win_avg[w] = avg;
 }
 
 // ------------------------------------------------------------------------------------------------
