@@ -1374,6 +1374,8 @@ struct VcTraceArgs {
     uint32_t pair_group, pair_k0;   // pairs index = slot*pair_group + (k - pair_k0)
     uint32_t k0;
     unsigned long long* stat;   // [8], see vc_ctx::d_stat
+    int shared_table;           // k_tracew: the VC_TG alignments of a wave share a window (group % VC_TG == 0)
+    uint32_t tab_rows;          // k_tracew: rows the LDS table is sized for (>= every graph's height in this launch)
 };
 
 // One alignment per THREAD: the walk is a chain of dependent lookups, so the instruction cost is shared
@@ -1495,7 +1497,7 @@ __global__ void k_trace(VcTraceArgs a) {
 // ------------------------------------------------------------------------------------------------
 #define VC_TG 4
 #define VC_TL 16
-__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t NC) { return VC_TG * ((NC + 2 + 3) & ~3u); }
+__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table) { return (shared_table ? 1u : (uint32_t)VC_TG) * ((max_rows + 2 + 3) & ~3u); }
 __device__ __forceinline__ int vc_row_shr1(int v, int first) {          // value of the lane to the left inside a 16-lane row
     return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false);
 }
@@ -1505,7 +1507,10 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = vc_lane();
     const uint32_t grp = (uint32_t)lane / VC_TL, gl = (uint32_t)lane % VC_TL, gbase = grp * VC_TL;
-    uint8_t* tab = smem + grp * ((a.NC + 2 + 3) & ~3u);      // first in-edge distance of row r (0: do not speculate)
+    // first in-edge distance of row r (0: do not speculate).  In the re-alignment rounds the alignments of a
+    // wave belong to one window (group % VC_TG == 0) and share one table: a quarter of the LDS, more waves
+    const bool shared_tab = a.shared_table != 0;
+    uint8_t* tab = smem + (shared_tab ? 0u : grp) * ((a.tab_rows + 2 + 3) & ~3u);
     const uint32_t njobs = a.nslots * a.group;
     const uint32_t job = blockIdx.x * VC_TG + grp;
     bool valid = job < njobs;
@@ -1528,7 +1533,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
     const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
     const bool packed = vc_row_packed(m, n, g, (int)cpl);
-    const uint32_t nrows = valid ? a.dp.nrows[slot] : 0;
+    const uint32_t nrows = valid ? min(a.dp.nrows[slot], a.tab_rows) : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
     // horizontal T == T', SW stop T == -col*g
     auto Tat = [&](uint32_t r, uint32_t col) __attribute__((always_inline)) -> int {
@@ -1546,10 +1551,24 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     auto gmask = [&](unsigned long long mm) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(mm >> gbase) & 0xFFFFu; };
 
     bool walking = valid && end != 0;
-    for (uint32_t r = gl; walking && r < nrows; r += VC_TL) {
-        const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + r]);
-        const uint32_t d0 = q.y & 0xFFFF;
-        tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint8_t)0 : (uint8_t)d0;
+    if (shared_tab) {
+        // every lane of the wave has the same slot; the first valid lane's view of it is everybody's
+        const unsigned long long vm = __ballot(valid);
+        const int src = __ffsll((long long)vm) - 1;
+        const uint32_t nr = (uint32_t)__shfl((int)nrows, src, 64);
+        const uint32_t nb_lo = (uint32_t)__shfl((int)(uint32_t)nb, src, 64), nb_hi = (uint32_t)__shfl((int)(uint32_t)(nb >> 32), src, 64);
+        const uint64_t nbs = ((uint64_t)nb_hi << 32) | nb_lo;
+        for (uint32_t r = lane; r < nr; r += 64) {
+            const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nbs + r]);
+            const uint32_t d0 = q.y & 0xFFFF;
+            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint8_t)0 : (uint8_t)d0;
+        }
+    } else {
+        for (uint32_t r = gl; walking && r < nrows; r += VC_TL) {
+            const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + r]);
+            const uint32_t d0 = q.y & 0xFFFF;
+            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint8_t)0 : (uint8_t)d0;
+        }
     }
     __syncthreads();
     uint32_t gi = end >> 16, gj = end & 0xFFFF, gnout = 0, nspec_ok = 0, nrounds = 0;
@@ -1571,7 +1590,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
 #pragma unroll 1
             for (uint32_t t = 0; t < VC_TL; ++t) {
                 can = can && ci != 0 && gj > t;
-                const uint32_t d = can ? (uint32_t)tab[ci] : 0u;
+                const uint32_t d = (can && ci <= a.tab_rows) ? (uint32_t)tab[ci] : 0u;
                 can = can && d != 0;
                 if (!__any(can)) break;
                 if (can) {
