@@ -155,6 +155,39 @@ const uint32_t* vc_synth_orig_index(const vc_synth* s);
 uint64_t  vc_synth_n_bytes(const vc_synth* s);
 void      vc_synth_free(vc_synth* s);
 
+/* ------------------------------------------------------------------------------------------------
+ * Window assembly and stitching (host only).  Stands in for the part of
+ * Polisher::initialize that turns overlaps into windows (src/polisher.cpp:389-462, with the breaking
+ * points of src/overlap.cpp:222-292 computed from a CIGAR string) and for the stitching loop of
+ * Polisher::polish (src/polisher.cpp:520-547).  Sequences 0..n_targets-1 are the targets; overlaps are
+ * taken in the order given (it decides the order of a window's layers before the rank sort).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vc_wb vc_wb;
+vc_wb*      vc_wb_create(uint32_t window_length, double quality_threshold);
+void        vc_wb_destroy(vc_wb* b);
+const char* vc_wb_last_error(const vc_wb* b);
+/* returns the sequence id (>= 0) or -1; quality may be NULL (FASTA) */
+int         vc_wb_add_sequence(vc_wb* b, const char* name, const char* data, uint32_t length, const char* quality);
+int         vc_wb_set_targets(vc_wb* b, uint32_t n_targets);
+/* coordinates as in a PAF/SAM record: q_* on the read's forward strand, strand != 0 = reverse complement */
+int         vc_wb_add_overlap(vc_wb* b, uint32_t q_id, uint32_t t_id, int strand, uint32_t q_begin, uint32_t q_end,
+                              uint32_t q_length, uint32_t t_begin, uint32_t t_end, const char* cigar);
+uint32_t    vc_wb_n_breaking_points(const vc_wb* b, uint32_t overlap);
+void        vc_wb_breaking_points(const vc_wb* b, uint32_t overlap, uint32_t* t_pos, uint32_t* q_pos);
+/* fills `out` with arrays owned by the builder (valid until the next build / destroy): every window of every
+ * target in order, layers in the reference's rank order */
+int         vc_wb_build(vc_wb* b, vc_batch* out);
+/* add_layer() index (0 = backbone) of every stored sequence of the last build, i.e. the rank permutation */
+const uint32_t* vc_wb_seq_orig(const vc_wb* b);
+uint32_t    vc_wb_n_windows(const vc_wb* b);
+uint32_t    vc_wb_window_target(const vc_wb* b, uint32_t w);
+uint32_t    vc_wb_window_rank(const vc_wb* b, uint32_t w);
+/* per-target concatenation of the window results with the LN/RC/XC tags; fragment_correction adds the "r" */
+int         vc_wb_stitch(vc_wb* b, const vc_result* res, int drop_unpolished, int fragment_correction);
+uint32_t    vc_wb_n_polished(const vc_wb* b);
+const char* vc_wb_polished_name(const vc_wb* b, uint32_t i);
+const char* vc_wb_polished_data(const vc_wb* b, uint32_t i, uint64_t* length);
+
 #ifdef __cplusplus
 }
 #endif

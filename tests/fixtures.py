@@ -38,3 +38,17 @@ def fixture_batch(wins):
         ws.append((seqs, quals, b, e))
         fl.append(host.vc_backbone_is_fasta(bq, len(bb)))
     return capi.Batch.from_windows(ws, fl, host=host)
+
+
+def load_plumbing():
+    """BASELINE config A stand-in (tests/golden/make_plumbing.py): targets, reads, overlaps with CIGAR and the
+    real reference's per-window results; -> (fixture dict, WindowBuilder with everything added)."""
+    from vechat_amd.windows import WindowBuilder
+    fx = json.load(gzip.open(os.path.join(GOLDEN, "plumbing.json.gz"), "rt"))
+    wb = WindowBuilder(fx["window_length"], fx["quality_threshold"])
+    for name, d, q in fx["sequences"]:
+        wb.add_sequence(name, d.encode(), None if q is None else q.encode())
+    wb.set_targets(fx["n_targets"])
+    for o in fx["overlaps"]:
+        wb.add_overlap(*o)
+    return fx, wb

@@ -73,6 +73,23 @@ def test_racon_linear_overload_parity(built, seed, L, D, n, kw):
         c.close()
 
 
+@pytest.mark.parametrize("mode,key", [(0, "hap"), (1, "linear")])
+def test_plumbing_reads_to_corrected_sequences(built, mode, key):
+    """BASELINE config A stand-in, end to end on the device: overlaps (CIGAR) -> windows -> HIP consensus ->
+    stitched corrected reads, against what the real reference produced for the same windows."""
+    fx, wb = fixtures.load_plumbing()
+    batch, ids = wb.build()
+    c = HipContext(device=0, mode=mode)
+    cons, status = c.consensus(batch)
+    c.close()
+    exp = fx["expected"][key]
+    assert [x.decode() for x in cons] == exp["consensus"]
+    assert [int(s) == capi.VC_WIN_OK for s in status] == exp["polished"]
+    st = wb.stitch(cons, status)
+    assert [[n, d.decode()] for n, d in st] == exp["stitched"]
+    wb.close()
+
+
 def test_tie_resolution_by_exact_dfs(built, monkeypatch):
     """End-cell ties are normally settled by the closure shortcut; force the exact-DFS fallback (which works
     out of an HBM workspace) on every tie and require the same bytes."""

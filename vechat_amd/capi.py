@@ -177,6 +177,25 @@ def _declare_host(lib):
     lib.vc_backbone_is_fasta.restype = C.c_int
     lib.vc_weight_lut.argtypes = [C.POINTER(C.c_uint32)]
     lib.vc_weight_lut.restype = None
+    vp = C.c_void_p
+    u32 = C.c_uint32
+    lib.vc_wb_create.argtypes = [u32, C.c_double]; lib.vc_wb_create.restype = vp
+    lib.vc_wb_destroy.argtypes = [vp]; lib.vc_wb_destroy.restype = None
+    lib.vc_wb_last_error.argtypes = [vp]; lib.vc_wb_last_error.restype = C.c_char_p
+    lib.vc_wb_add_sequence.argtypes = [vp, C.c_char_p, C.c_char_p, u32, C.c_char_p]; lib.vc_wb_add_sequence.restype = C.c_int
+    lib.vc_wb_set_targets.argtypes = [vp, u32]; lib.vc_wb_set_targets.restype = C.c_int
+    lib.vc_wb_add_overlap.argtypes = [vp, u32, u32, C.c_int, u32, u32, u32, u32, u32, C.c_char_p]; lib.vc_wb_add_overlap.restype = C.c_int
+    lib.vc_wb_n_breaking_points.argtypes = [vp, u32]; lib.vc_wb_n_breaking_points.restype = u32
+    lib.vc_wb_breaking_points.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32)]; lib.vc_wb_breaking_points.restype = None
+    lib.vc_wb_build.argtypes = [vp, C.POINTER(VcBatch)]; lib.vc_wb_build.restype = C.c_int
+    lib.vc_wb_seq_orig.argtypes = [vp]; lib.vc_wb_seq_orig.restype = C.POINTER(u32)
+    lib.vc_wb_n_windows.argtypes = [vp]; lib.vc_wb_n_windows.restype = u32
+    lib.vc_wb_window_target.argtypes = [vp, u32]; lib.vc_wb_window_target.restype = u32
+    lib.vc_wb_window_rank.argtypes = [vp, u32]; lib.vc_wb_window_rank.restype = u32
+    lib.vc_wb_stitch.argtypes = [vp, C.POINTER(VcResult), C.c_int, C.c_int]; lib.vc_wb_stitch.restype = C.c_int
+    lib.vc_wb_n_polished.argtypes = [vp]; lib.vc_wb_n_polished.restype = u32
+    lib.vc_wb_polished_name.argtypes = [vp, u32]; lib.vc_wb_polished_name.restype = C.c_char_p
+    lib.vc_wb_polished_data.argtypes = [vp, u32, C.POINTER(C.c_uint64)]; lib.vc_wb_polished_data.restype = C.POINTER(C.c_char)
     lib.vc_synth_generate.argtypes = [C.POINTER(VcSynthCfg), C.c_uint64, C.c_uint32, C.c_uint32]
     lib.vc_synth_generate.restype = C.c_void_p
     lib.vc_synth_batch.argtypes = [C.c_void_p, C.POINTER(VcBatch)]
