@@ -132,6 +132,22 @@ def test_result_is_independent_of_chunking(built):
     a.close(); b.close()
 
 
+def test_graph_images_beyond_the_lds_use_the_hbm_workspace(built):
+    """Capacities whose topo / prune / consensus images exceed 160 KB are not refused: those kernels then work
+    from an HBM workspace.  Same bytes as the oracle."""
+    batch = capi.synth_batch(capi.synth_cfg(91, 300, 10, n_haplotypes=2, snp_rate=0.02, frac_partial=0.2), 0, 4)
+    c = HipContext(device=0, max_nodes=8192, max_edges=20032)             # topo image 190 KB, prune image 200 KB
+    _check(c, batch, "big images, hap")
+    c.close()
+    c = HipContext(device=0, mode=1, max_nodes=8192, max_edges=20032)     # + consensus image 400 KB
+    _check(c, batch, "big images, linear")
+    c.close()
+    big = capi.synth_batch(capi.synth_cfg(1005, 1000, 48, profile=capi.ONT), 0, 2)
+    c = HipContext(device=0, mode=1)                                      # the case that used to be refused at submit
+    _check(c, big, "1 kb x 48 linear")
+    c.close()
+
+
 def test_overlong_sequence_is_a_per_window_status(built):
     """A layer longer than the forward kernel's 2 048 columns marks ITS window unsupported; the rest of the
     batch is processed and stays byte-identical to the oracle."""

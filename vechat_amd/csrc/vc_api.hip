@@ -34,6 +34,7 @@ const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace"
 
 constexpr int kRing = 8;      // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
 constexpr int kMaxStreams = 4;
+constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may ask for (160 KB per CU minus room for static __shared__)
 constexpr uint64_t kMaxColumns = 2048;     // longest sequence k_fwd takes (64 lanes x 32 columns)
 constexpr uint32_t kResolveGrid = 128;   // workgroups of k_resolve (each owns one DFS workspace in HBM)
 
@@ -47,6 +48,7 @@ struct Work {
     VcGraph gr[2]{};
     VcDp dp{};
     uint32_t* d_hmat = nullptr; int16_t* d_c0 = nullptr; uint8_t* d_resolve_ws = nullptr;
+    uint8_t* d_big_ws = nullptr;        // [CW * big_ws_stride] graph images that do not fit the LDS (k_topo / k_prune_lcc / k_consensus)
     uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
     uint16_t* d_tie_rows = nullptr; uint8_t* d_tie_cnt = nullptr; uint32_t* d_tie_list = nullptr; uint32_t* d_tie_n = nullptr;
     uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
@@ -86,6 +88,7 @@ struct vc_ctx {
 
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
+    uint32_t big_ws_stride = 0;          // bytes per window of the HBM workspace for oversized graph images (0: all fit the LDS)
     std::vector<uint8_t> h_pre_status;   // per-window status decided at submit (outside the envelope), empty = none
     bool trace_wave = true;
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
@@ -169,6 +172,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_resolve_ws, (size_t)kResolveGrid * ((topo_lds_bytes(NC, c->EC, c->STK) + 15u) & ~15u))) ||
+        (c->big_ws_stride && (rc = dalloc(c, c->chunk_allocs, &wk->d_big_ws, (size_t)CW * c->big_ws_stride))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_c0, (size_t)c->jobs_cap * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_end, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_type, c->jobs_cap)) ||
@@ -378,11 +382,14 @@ struct Plan {
         VcPruneArgs pa{};
         pa.b = c->b; pa.src = wk.gr[wk.cur]; pa.dst = wk.gr[wk.cur ^ 1]; pa.w0 = wk.w0; pa.nslots = ns; pa.NC = NC; pa.EC = EC;
         pa.NCl = NCl; pa.ECl = ECl;
+        const bool pws = vc_prune_lds_bytes(NCl, ECl) > kLdsCap, tws = topo_lds_bytes(NCl, ECl, c->STK) > kLdsCap;
+        pa.ws = pws ? wk.d_big_ws : nullptr; pa.ws_stride = c->big_ws_stride;
         pa.min_conf = c->prm.min_confidence; pa.min_supp = c->prm.min_support;
-        { Timer t(c, KC_PRUNE, wk.stream); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), vc_prune_lds_bytes(NCl, ECl), wk.stream, pa); }
+        { Timer t(c, KC_PRUNE, wk.stream); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), pws ? 0 : vc_prune_lds_bytes(NCl, ECl), wk.stream, pa); }
         wk.cur ^= 1;
         { Timer t(c, KC_TOPO, wk.stream);
-          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds_bytes(NCl, ECl, c->STK), wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NCl, ECl); }
+          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tws ? 0 : topo_lds_bytes(NCl, ECl, c->STK), wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NCl, ECl,
+                             tws ? wk.d_big_ws : nullptr, c->big_ws_stride); }
         if (more) {
             HIPCHK(c, hipMemsetAsync(wk.d_maxn, 0, 8, wk.stream));
             hipLaunchKernelGGL(k_max_u32, dim3((ns + 255) / 256), dim3(256), 0, wk.stream, wk.dp.nrows, ns, wk.d_maxn);
@@ -428,11 +435,13 @@ struct Plan {
     int linear_tail(Work& wk) {
         const uint32_t ns = wk.ns;
         { Timer t(c, KC_TOPO, wk.stream);
-          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NC, EC); }
+          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds > kLdsCap ? 0 : topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NC, EC,
+                             topo_lds > kLdsCap ? wk.d_big_ws : nullptr, c->big_ws_stride); }
         VcConsArgs ca{};
         ca.b = c->b; ca.g = wk.gr[wk.cur]; ca.dp = wk.dp; ca.w0 = wk.w0; ca.nslots = ns; ca.NC = NC; ca.EC = EC;
         ca.trim = c->prm.trim; ca.window_type = c->prm.window_type;
-        { Timer t(c, KC_CONS, wk.stream); hipLaunchKernelGGL(k_consensus, dim3(ns), dim3(64), cons_lds, wk.stream, ca); }
+        ca.ws = cons_lds > kLdsCap ? wk.d_big_ws : nullptr; ca.ws_stride = c->big_ws_stride;
+        { Timer t(c, KC_CONS, wk.stream); hipLaunchKernelGGL(k_consensus, dim3(ns), dim3(64), cons_lds > kLdsCap ? 0 : cons_lds, wk.stream, ca); }
         wk.active = false;
         return VC_OK;
     }
@@ -624,10 +633,13 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint32_t cpl = pick_cpl(max_len);
     c->cpl_min = pick_cpl(min_len);
     if (!cpl) return fail(c, VC_ERR_ARG, "sequence length %u exceeds the kernels' 2048-column envelope", max_len);
-    const uint32_t lds_cap = 160 * 1024;
-    if (topo_lds_bytes(NC, EC, c->STK) > lds_cap || vc_prune_lds_bytes(NC, EC) > lds_cap ||
-        (c->prm.mode == 1 && vc_cons_lds_bytes(NC, EC) > lds_cap))
-        return fail(c, VC_ERR_ARG, "graph capacity %u nodes / %u edges does not fit the 160 KB LDS", NC, EC);
+    const uint32_t lds_cap = kLdsCap;
+    // graph images that do not fit the LDS are worked on in an HBM workspace (slower, not refused)
+    uint32_t big = 0;
+    if (topo_lds_bytes(NC, EC, c->STK) > lds_cap) big = std::max(big, topo_lds_bytes(NC, EC, c->STK));
+    if (vc_prune_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_prune_lds_bytes(NC, EC));
+    if (c->prm.mode == 1 && vc_cons_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_cons_lds_bytes(NC, EC));
+    big = (big + 255u) & ~255u;
     const uint32_t PC = NC + max_len + 8;
 
     // chunk size from the scratch budget (split over the streams)
@@ -637,7 +649,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6)) / S;
     const uint64_t rowd = 64ull * (cpl / 2);
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN + 6) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
-                                    PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4);
+                                    PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
     const uint64_t per_job = NC * rowd * 4 + NC * 2 + 8 + 2 * VC_MAXTIE + 8;
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);
@@ -649,11 +661,12 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint32_t group_max = 1 + (uint32_t)std::min<uint64_t>(spare / (per_job * CW), 7);
     if (group_max > max_nseq) group_max = max_nseq;
 
-    const bool same = c->NC == NC && c->EC == EC && c->CW == CW && c->cpl == cpl && c->PC == PC &&
+    const bool same = c->NC == NC && c->EC == EC && c->CW == CW && c->cpl == cpl && c->PC == PC && c->big_ws_stride == big &&
                       c->group_max == group_max && c->max_nseq == max_nseq && !c->chunk_allocs.empty();
     if (!same) {
         free_list(c->chunk_allocs);
         c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
+        c->big_ws_stride = big;
         c->jobs_cap = CW * group_max;
         c->hmat_dwords = (uint64_t)c->jobs_cap * NC * rowd;
         for (uint32_t s = 0; s < S; ++s)
@@ -682,11 +695,11 @@ int vc_run(vc_ctx* c) {
     pl.rows_lds = 0;
     pl.cons_lds = vc_cons_lds_bytes(c->NC, c->EC);
     pl.rowd = 64ull * (c->cpl / 2);
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.topo_lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prune_lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.topo_lds, kLdsCap)));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.prune_lds, kLdsCap)));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
     if (c->prm.mode == 1)
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.cons_lds));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.cons_lds, kLdsCap)));
     HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
     if (!c->h_pre_status.empty()) HIPCHK(c, hipMemcpyAsync(b.status, c->h_pre_status.data(), b.n_windows, hipMemcpyHostToDevice, c->stream));

@@ -328,7 +328,9 @@ __device__ int vc_topo_dfs(const VcTopoLds& ls, uint32_t N, uint32_t STK, bool m
 
 __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                              uint32_t NC, uint32_t EC, uint32_t STK, int next_layer, int only_masked, uint32_t ring,
-                                             uint32_t NCl, uint32_t ECl) {
+                                             uint32_t NCl, uint32_t ECl, uint8_t* ws, uint32_t ws_stride) {
+    // ws != nullptr: the graph image does not fit the 160 KB LDS; work from this workgroup's HBM workspace
+    // instead (same layout, same code; slower, but the window is computed rather than rejected).
     // NC/EC: strides of the graph arrays in HBM; NCl/ECl: capacity the LDS image was sized for (the host
     // passes the known maximum after a prune round, so small graphs do not reserve 60 KB per window)
     VC_LATENCY_KERNEL_PRIO();
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
 
     if (N > NCl || E > ECl) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 24, N); return; }
-    const VcTopoLds t = vc_topo_carve(smem, NCl, ECl, STK);
+    const VcTopoLds t = vc_topo_carve(ws ? ws + (size_t)blockIdx.x * ws_stride : smem, NCl, ECl, STK);
     uint16_t* s_in_first = t.in_first; uint32_t* s_etn = t.etn; uint16_t* s_al = t.al;
     uint8_t* s_flag = t.flag; uint16_t* s_rank = t.rank;
     vc_topo_load(g, nb, eb, N, E, t, lane);
@@ -1967,6 +1969,7 @@ struct VcPruneArgs {
     VcGraph src, dst;
     uint32_t w0, nslots, NC, EC;
     uint32_t NCl, ECl;            // capacity of the LDS image (<= NC, EC; the host knows the maximum after a round)
+    uint8_t* ws; uint32_t ws_stride;   // != nullptr: image too large for the LDS, use this HBM workspace per workgroup
     double min_conf, min_supp;
 };
 
@@ -1989,8 +1992,9 @@ __global__ __launch_bounds__(64) void k_prune_lcc(VcPruneArgs a) {
 
     const uint32_t NCl = a.NCl, ECl = a.ECl;
     if (N > NCl || E > ECl) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 25, N); return; }
-    uint16_t* s_adj_off = (uint16_t*)smem;                                     // [NCl+1]
-    uint16_t* s_adj = (uint16_t*)(smem + ((2 * (NCl + 1) + 15) & ~15u));       // [2*ECl]
+    uint8_t* const img = a.ws ? a.ws + (size_t)blockIdx.x * a.ws_stride : smem;
+    uint16_t* s_adj_off = (uint16_t*)img;                                      // [NCl+1]
+    uint16_t* s_adj = (uint16_t*)(img + ((2 * (NCl + 1) + 15) & ~15u));        // [2*ECl]
     uint16_t* s_vis = s_adj + 2 * ECl;                                         // [NCl] visited, later newid
     uint16_t* s_nin = s_vis + NCl;                                             // [NCl] live in-degree
     uint8_t*  s_keep = (uint8_t*)(s_nin + NCl);                                // [ECl]
@@ -2251,6 +2255,7 @@ struct VcConsArgs {
     VcDp dp;
     uint32_t w0, nslots, NC, EC;
     int trim, window_type;
+    uint8_t* ws; uint32_t ws_stride;   // != nullptr: image too large for the LDS, use this HBM workspace per workgroup
 };
 
 __host__ __device__ inline uint32_t vc_cons_lds_bytes(uint32_t NC, uint32_t EC) { return 12 * NC + 12 * EC + 8 * NC + 128; }
@@ -2267,7 +2272,7 @@ __global__ __launch_bounds__(64) void k_consensus(VcConsArgs a) {
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
     const uint32_t N = a.g.n_nodes[slot], E = a.g.n_edges[slot];
     const uint32_t nseq = a.b.win_seq_off[w + 1] - a.b.win_seq_off[w];
-    long long* s_score = (long long*)smem;                      // [NC]
+    long long* s_score = (long long*)(a.ws ? a.ws + (size_t)blockIdx.x * a.ws_stride : smem);   // [NC]
     uint32_t* s_etn = (uint32_t*)(s_score + NC);                // [EC]
     uint32_t* s_ehn = s_etn + EC;
     uint32_t* s_w = s_ehn + EC;
