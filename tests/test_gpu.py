@@ -90,6 +90,20 @@ def test_plumbing_reads_to_corrected_sequences(built, mode, key):
     wb.close()
 
 
+@pytest.mark.parametrize("flags,key", [(["-p"], "hap"), ([], "linear")])
+def test_command_line_from_files(built, tmp_path, capsys, flags, key):
+    """reads.fastq.gz + overlaps.sam + targets.fastq -> corrected FASTA through `python -m vechat_amd.polish`."""
+    from test_seqio import write_inputs
+    from vechat_amd import polish
+    fx, wb = fixtures.load_plumbing()
+    wb.close()
+    rp, op, tp = write_inputs(fx, tmp_path, sam=True)
+    assert polish.main([str(rp), str(op), str(tp)] + flags) == 0
+    out = capsys.readouterr().out.strip().split("\n")
+    got = [[out[i][1:], out[i + 1]] for i in range(0, len(out), 2)]
+    assert got == fx["expected"][key]["stitched"]
+
+
 def test_tie_resolution_by_exact_dfs(built, monkeypatch):
     """End-cell ties are normally settled by the closure shortcut; force the exact-DFS fallback (which works
     out of an HBM workspace) on every tie and require the same bytes."""

@@ -1,0 +1,76 @@
+"""CPU suite for the file-format layer: the plumbing fixture written out as FASTQ/FASTA + SAM
+and + PAF(cg), read back, must give the very batch the fixture's in-memory overlaps give."""
+import gzip
+
+import numpy as np
+import pytest
+
+import fixtures
+from vechat_amd import seqio
+from vechat_amd.windows import WindowBuilder
+
+
+def write_inputs(fx, d, sam=True):
+    nt = fx["n_targets"]
+    seqs = fx["sequences"]
+
+    def rec(f, name, data, qual, extra=""):
+        f.write(f"@{name}{extra}\n{data}\n+\n{qual}\n" if qual is not None else f">{name}{extra}\n{data}\n")
+    tp, rp = d / "targets.fastq", d / "reads.fastq.gz"
+    with open(tp, "w") as f:
+        for n, s, q in seqs[:nt]:
+            rec(f, n, s.lower() if n.endswith("1") else s, q if q is not None else "!" * len(s), " some description")
+    with gzip.open(rp, "wt") as f:
+        for n, s, q in seqs[nt:]:
+            rec(f, n, s, q if q is not None else "!" * len(s))
+    op = d / ("ovl.sam" if sam else "ovl.paf")
+    with open(op, "w") as f:
+        if sam:
+            f.write("@HD\tVN:1.6\n")
+        for q_id, t_id, strand, qb, qe, ql, tb, te, cigar in fx["overlaps"]:
+            qn, tn = seqs[q_id][0], seqs[t_id][0]
+            if sam:
+                lead, trail = (ql - qe, qb) if strand else (qb, ql - qe)      # clips in the orientation of the alignment
+                cg = (f"{lead}S" if lead else "") + cigar + (f"{trail}S" if trail else "")
+                f.write(f"{qn}\t{16 if strand else 0}\t{tn}\t{tb + 1}\t60\t{cg}\t*\t0\t0\t*\t*\n")
+            else:
+                f.write(f"{qn}\t{ql}\t{qb}\t{qe}\t{'-' if strand else '+'}\t{tn}\t{len(seqs[t_id][1])}\t{tb}\t{te}\t0\t0\t60\ttp:A:P\tcg:Z:{cigar}\n")
+        if sam:
+            f.write(f"{seqs[nt][0]}\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n")          # an unmapped record is skipped
+    return rp, op, tp
+
+
+@pytest.mark.parametrize("sam", [True, False])
+def test_files_round_trip_into_the_same_batch(built, tmp_path, sam):
+    fx, wb0 = fixtures.load_plumbing()
+    b0, ids0 = wb0.build()
+    rp, op, tp = write_inputs(fx, tmp_path, sam)
+    targets, reads, ovl = seqio.read_sequences(tp), seqio.read_sequences(rp), seqio.read_overlaps(op)
+    assert targets[0][0] == fx["sequences"][0][0] and targets[1][2] is None          # description cut, all-'!' quality dropped
+    assert targets[1][1] == fx["sequences"][1][1].encode()                           # lower case input is upper-cased
+    wb = WindowBuilder(fx["window_length"], fx["quality_threshold"])
+    kept, wtype = seqio.load_polisher_input(wb, targets, reads, ovl)
+    assert kept == len(fx["overlaps"]) and wtype == 1
+    b1, ids1 = wb.build()
+    assert ids1 == ids0
+    for k in ("win_seq_off", "seq_off", "seq_begin", "seq_end", "seq_has_qual", "bases", "quals", "win_fasta"):
+        assert np.array_equal(getattr(b0, k), getattr(b1, k)), k
+    wb.close(); wb0.close()
+
+
+def test_filters(built, tmp_path):
+    t = [("t", b"ACGT" * 30, None)]
+    r = [("t", b"ACGT" * 30, None), ("r", b"ACGT" * 10, None)]
+    o = [seqio.Overlap(q_name="t", t_name="t", strand=False, q_begin=0, q_end=120, q_length=120, t_begin=0, t_end=120, cigar="120M", error=0.0, length=120),
+         seqio.Overlap(q_name="r", t_name="t", strand=False, q_begin=0, q_end=40, q_length=40, t_begin=0, t_end=100, cigar="40M", error=0.6, length=100),
+         seqio.Overlap(q_name="r", t_name="t", strand=False, q_begin=0, q_end=40, q_length=40, t_begin=4, t_end=44, cigar="40M", error=0.0, length=40),
+         seqio.Overlap(q_name="zz", t_name="t", strand=False, q_begin=0, q_end=4, q_length=4, t_begin=0, t_end=4, cigar="4M", error=0.0, length=4)]
+    wb = WindowBuilder(50, 10.0)
+    kept, wtype = seqio.load_polisher_input(wb, t, r, o)
+    assert kept == 1 and wtype == 0                       # self overlap, high error and unknown read are dropped
+    wb.close()
+    with pytest.raises(ValueError):
+        seqio.read_overlaps(tmp_path / "x.mhap")
+    (tmp_path / "nocg.paf").write_text("r\t40\t0\t40\t+\tt\t120\t4\t44\t40\t40\t60\n")
+    with pytest.raises(ValueError):
+        seqio.read_overlaps(tmp_path / "nocg.paf")

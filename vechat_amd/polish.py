@@ -1,0 +1,54 @@
+"""Command line over the whole path on one MI355X (fragment correction, the way the VeChat driver calls
+vechat_racon: `-f -p -d 0.2 -s 0.2` for round 1, `-f` for round 2; scripts/vechat:70-72,91-93):
+
+  python -m vechat_amd.polish reads.fastq overlaps.sam targets.fastq > corrected.fasta
+
+Overlaps need a CIGAR (SAM, or PAF with cg:Z:).  There is no CPU path: without the HIP library and a GPU
+this exits with an error."""
+import argparse
+import sys
+
+from . import capi
+from .engine import HipContext
+from .seqio import load_polisher_input, read_overlaps, read_sequences
+from .windows import WindowBuilder
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m vechat_amd.polish", description=__doc__)
+    ap.add_argument("sequences"); ap.add_argument("overlaps"); ap.add_argument("targets")
+    ap.add_argument("-p", "--haplotype", action="store_true", help="haplotype-aware (variation graph) correction")
+    ap.add_argument("-d", "--min-confidence", type=float, default=0.2)
+    ap.add_argument("-s", "--min-support", type=float, default=0.2)
+    ap.add_argument("-k", "--num-prune", type=int, default=3)
+    ap.add_argument("-w", "--window-length", type=int, default=500)
+    ap.add_argument("-q", "--quality-threshold", type=float, default=10.0)
+    ap.add_argument("-e", "--error-threshold", type=float, default=0.3)
+    ap.add_argument("-m", "--match", type=int, default=3)
+    ap.add_argument("-x", "--mismatch", type=int, default=-5)
+    ap.add_argument("-g", "--gap", type=int, default=-4)
+    ap.add_argument("-u", "--include-unpolished", action="store_true")
+    ap.add_argument("--no-trimming", action="store_true")
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+
+    wb = WindowBuilder(a.window_length, a.quality_threshold)
+    kept, window_type = load_polisher_input(wb, read_sequences(a.targets), read_sequences(a.sequences),
+                                            read_overlaps(a.overlaps), a.error_threshold)
+    batch, ids = wb.build()
+    ctx = HipContext(device=a.device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
+                     num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
+                     window_type=window_type)
+    cons, status = ctx.consensus(batch)
+    bad = [w for w in range(batch.n_windows) if int(status[w]) > capi.VC_WIN_UNPOLISHED]
+    if bad:
+        sys.exit(f"error: {len(bad)} window(s) outside the device envelope (first: {bad[0]}, status {int(status[bad[0]])})")
+    for name, data in wb.stitch(cons, status, drop_unpolished=not a.include_unpolished, fragment_correction=True):
+        sys.stdout.write(f">{name}\n{data.decode()}\n")
+    print(f"[vechat_amd] {kept} overlaps, {batch.n_windows} windows, {sum(int(s) == capi.VC_WIN_OK for s in status)} polished",
+          file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

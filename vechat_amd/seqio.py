@@ -1,0 +1,162 @@
+"""File formats either side of the hot path, restated from the reference's use of
+bioparser and its Sequence / Overlap constructors:
+
+  read_sequences  <- src/sequence.cpp:19-42 (upper-casing; an all-'!' quality string counts as no quality),
+                     names cut at the first whitespace as bioparser does
+  read_sam        <- src/overlap.cpp:44-110 (SAM constructor: unmapped flag, strand, clips, lengths, error)
+  read_paf        <- src/overlap.cpp:29-42  (PAF constructor); a `cg:Z:` tag supplies the CIGAR -- without it
+                     the reference aligns with edlib (overlap.cpp:205-220), which this library does not do
+  load_polisher_input <- src/polisher.cpp:207-352 (reads that are also targets share one record, self-overlaps
+                     and overlaps above the error threshold are dropped, window type from the mean read length)
+Parity unpinned: plain restatements, exercised by tests/test_seqio.py.
+"""
+import gzip
+import re
+
+
+def _open(path):
+    return gzip.open(path, "rb") if str(path).endswith(".gz") else open(path, "rb")
+
+
+def read_sequences(path):
+    """FASTA or FASTQ (optionally .gz) -> [(name, data, quality|None)]"""
+    out = []
+    with _open(path) as f:
+        lines = f.read().split(b"\n")
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        if not ln:
+            i += 1
+            continue
+        if ln[:1] == b">":
+            name = ln[1:].split()[0] if ln[1:].split() else b""
+            i += 1
+            parts = []
+            while i < len(lines) and lines[i][:1] != b">":
+                parts.append(lines[i].strip())
+                i += 1
+            out.append((name.decode(), b"".join(parts).upper(), None))
+        elif ln[:1] == b"@":
+            name = ln[1:].split()[0] if ln[1:].split() else b""
+            data = lines[i + 1].strip().upper()
+            qual = lines[i + 3].strip()
+            if len(qual) != len(data):
+                raise ValueError(f"{path}: quality length differs from sequence length for {name.decode()}")
+            if sum(c - 33 for c in qual) == 0:
+                qual = None
+            out.append((name.decode(), data, qual))
+            i += 4
+        else:
+            raise ValueError(f"{path}: unrecognised record at line {i + 1}")
+    return out
+
+
+_CIG = re.compile(rb"(\d+)([MIDNSHP=X])")
+
+
+class Overlap:
+    __slots__ = ("q_name", "t_name", "strand", "q_begin", "q_end", "q_length", "t_begin", "t_end", "cigar", "error", "length")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _sam_overlap(q_name, flag, t_name, pos, cigar):
+    if flag & 0x4:
+        return None
+    if len(cigar) < 2:
+        raise ValueError("missing alignment from SAM object")
+    ops = _CIG.findall(cigar)
+    q_begin = int(ops[0][0]) if ops and ops[0][1] in b"SH" else 0
+    q_aln = sum(int(n) for n, o in ops if o in b"M=XI")
+    t_aln = sum(int(n) for n, o in ops if o in b"M=XDN")
+    clip = sum(int(n) for n, o in ops if o in b"SH")
+    strand = bool(flag & 0x10)
+    q_end = q_begin + q_aln
+    q_length = clip + q_aln
+    if strand:
+        q_begin, q_end = q_length - q_end, q_length - q_begin
+    t_begin = pos - 1
+    t_end = t_begin + t_aln
+    length = max(q_aln, t_aln)
+    return Overlap(q_name=q_name, t_name=t_name, strand=strand, q_begin=q_begin, q_end=q_end, q_length=q_length,
+                   t_begin=t_begin, t_end=t_end, cigar=cigar.decode(), length=length,
+                   error=1 - min(q_aln, t_aln) / float(length) if length else 1.0)
+
+
+def read_sam(path):
+    out = []
+    with _open(path) as f:
+        for ln in f:
+            if not ln.strip() or ln[:1] == b"@":
+                continue
+            c = ln.rstrip(b"\n").split(b"\t")
+            o = _sam_overlap(c[0].decode(), int(c[1]), c[2].decode(), int(c[3]), c[5])
+            if o is not None:
+                out.append(o)
+    return out
+
+
+def read_paf(path):
+    out = []
+    with _open(path) as f:
+        for ln in f:
+            if not ln.strip():
+                continue
+            c = ln.rstrip(b"\n").split(b"\t")
+            qb, qe, tb, te = int(c[2]), int(c[3]), int(c[7]), int(c[8])
+            cg = [x[5:] for x in c[12:] if x.startswith(b"cg:Z:")]
+            if not cg:
+                raise ValueError(f"{path}: PAF record without a cg:Z: CIGAR -- the overlap would have to be aligned first "
+                                 "(the reference uses edlib there; not part of this library)")
+            length = max(qe - qb, te - tb)
+            out.append(Overlap(q_name=c[0].decode(), t_name=c[5].decode(), strand=c[4] == b"-", q_begin=qb, q_end=qe,
+                               q_length=int(c[1]), t_begin=tb, t_end=te, cigar=cg[0].decode(), length=length,
+                               error=1 - min(qe - qb, te - tb) / float(length) if length else 1.0))
+    return out
+
+
+def read_overlaps(path):
+    p = str(path)
+    if p.endswith((".sam", ".sam.gz")):
+        return read_sam(path)
+    if p.endswith((".paf", ".paf.gz")):
+        return read_paf(path)
+    raise ValueError(f"{path}: unsupported overlap format (valid extensions: .paf, .paf.gz, .sam, .sam.gz)")
+
+
+def load_polisher_input(builder, targets, reads, overlaps, error_threshold=0.3):
+    """Feed a WindowBuilder the way Polisher::initialize fills its tables (fragment-correction mode, -f).
+    Returns (number of overlaps kept, window_type): window_type 0 = NGS (mean read length <= 1000), 1 = TGS."""
+    if not targets:
+        raise ValueError("empty target sequences set")
+    if not reads:
+        raise ValueError("empty sequences set")
+    t_id, q_id = {}, {}
+    for name, data, qual in targets:
+        t_id[name] = builder.add_sequence(name, data, qual)
+    total = 0
+    for name, data, qual in reads:
+        total += len(data)
+        if name in t_id:                       # a read that is also a target shares its record
+            tn, td, tq = targets[t_id[name]]
+            if len(td) != len(data) or len(tq or b"") != len(qual or b""):
+                raise ValueError(f"duplicate sequence {name} with unequal data")
+            q_id[name] = t_id[name]
+        else:
+            q_id[name] = builder.add_sequence(name, data, qual)
+    builder.set_targets(len(targets))
+    kept = 0
+    for o in overlaps:
+        if o.q_name not in q_id or o.t_name not in t_id:
+            continue
+        q, t = q_id[o.q_name], t_id[o.t_name]
+        if o.error > error_threshold or q == t:
+            continue
+        builder.add_overlap(q, t, o.strand, o.q_begin, o.q_end, o.q_length, o.t_begin, o.t_end, o.cigar)
+        kept += 1
+    if kept == 0:
+        raise ValueError("empty overlap set")
+    return kept, 0 if total / float(len(reads)) <= 1000 else 1
