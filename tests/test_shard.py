@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vechat_amd.shard import gather_consensus, shard_range
+from vechat_amd.shard import estimated_cells, gather_consensus, shard_range, shard_range_balanced
 
 
 def test_shard_range_partitions_in_order():
@@ -19,6 +19,25 @@ def test_shard_range_partitions_in_order():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_balanced_split_is_a_partition_with_even_cost(built):
+    from vechat_amd import capi
+    rng = np.random.default_rng(5)
+    for world in (1, 2, 3, 8):
+        cost = rng.integers(1, 100, size=257).astype(float)
+        spans = [shard_range_balanced(cost, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == cost.size
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        per = [cost[a:b].sum() for a, b in spans]
+        assert max(per) - min(per) <= 2 * cost.max()
+    assert shard_range_balanced(np.zeros(5), 1, 2) == shard_range(5, 1, 2)
+    # deep windows weigh more than shallow ones
+    parts = [capi.synth_batch(capi.synth_cfg(3, 120, d), 0, 2) for d in (4, 16)]
+    wins = [p.window(w) for p in parts for w in range(2)]
+    b = capi.Batch.from_windows(wins, [0] * 4, presorted=True)
+    c = estimated_cells(b)
+    assert c[2] > 5 * c[0] and c[3] > 5 * c[1]
 
 
 def _worker(rank, world, port, n, q):

@@ -14,6 +14,36 @@ def shard_range(n_windows: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def estimated_cells(batch):
+    """Per-window DP work estimate of SURVEY 8(e): sum over layers of len * (L + 0.3 * sum of the previous
+    layers' lengths) -- the graph a layer is aligned to has grown by about a third of what came before."""
+    import numpy as np
+    lens = np.diff(batch.seq_off.astype(np.int64))
+    out = np.zeros(batch.n_windows, dtype=np.float64)
+    for w in range(batch.n_windows):
+        s0, s1 = int(batch.win_seq_off[w]), int(batch.win_seq_off[w + 1])
+        ll = lens[s0 + 1:s1].astype(np.float64)
+        prev = np.concatenate([[0.0], np.cumsum(ll)[:-1]]) if ll.size else ll
+        out[w] = float(np.sum(ll * (lens[s0] + 0.3 * prev)))
+    return out
+
+
+def shard_range_balanced(cost, rank: int, world: int):
+    """Contiguous, order-preserving split with (nearly) equal summed cost per rank: rank r takes the windows
+    whose cumulative cost midpoint falls into the r-th of `world` equal slices.  Every window goes to exactly
+    one rank and the ranges stay in rank order, as the stitching needs."""
+    import numpy as np
+    cost = np.asarray(cost, dtype=np.float64)
+    n = cost.size
+    if n == 0 or float(cost.sum()) <= 0.0:
+        return shard_range(n, rank, world)
+    mid = np.cumsum(cost) - 0.5 * cost
+    owner = np.minimum((mid / cost.sum() * world).astype(np.int64), world - 1)     # non-decreasing
+    lo = int(np.searchsorted(owner, rank, side="left"))
+    hi = int(np.searchsorted(owner, rank, side="right"))
+    return lo, hi
+
+
 def gather_consensus(cons: torch.Tensor, lens: torch.Tensor, dst: int = 0, force: bool = False):
     """cons: uint8 [sum(lens)] consensus bytes of this rank's windows, lens: int64 [n_local].
     Returns (cons_all, lens_all) on rank `dst` (window order), (None, None) elsewhere.
