@@ -104,6 +104,15 @@ def test_command_line_from_files(built, tmp_path, capsys, flags, key):
     assert got == fx["expected"][key]["stitched"]
 
 
+def test_thread_per_alignment_backtrack_agrees(built, monkeypatch):
+    """The simple one-thread-per-alignment backtrack (kept as a cross-check of the cooperative k_tracew)."""
+    monkeypatch.setenv("VC_TRACE_THREAD", "1")
+    c = HipContext(device=0)
+    for seed, L, D, n, kw in [(1002, 500, 24, 4, {}), (13, 300, 20, 6, dict(n_haplotypes=2, snp_rate=0.02, frac_partial=0.3))]:
+        _check(c, capi.synth_batch(capi.synth_cfg(seed, L, D, **kw), 0, n), f"thread trace seed{seed}")
+    c.close()
+
+
 def test_tie_resolution_by_exact_dfs(built, monkeypatch):
     """End-cell ties are normally settled by the closure shortcut; force the exact-DFS fallback (which works
     out of an HBM workspace) on every tie and require the same bytes."""

@@ -92,7 +92,6 @@ struct vc_ctx {
     std::vector<uint8_t> h_pre_status;   // per-window status decided at submit (outside the envelope), empty = none
     bool trace_wave = true;
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
-    uint32_t trace_lds_mult = 1;
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
 
@@ -243,8 +242,7 @@ void flush_events(vc_ctx* c) {
 
 template <int CA, int CB>
 void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs) {
-    static const uint32_t pad = getenv("VC_FWD_LDS_PAD") ? (uint32_t)atoi(getenv("VC_FWD_LDS_PAD")) : 0u;   // experiment: cap k_fwd's share of a CU
-    hipLaunchKernelGGL((k_fwd<CA, CB, kRing>), dim3(jobs), dim3(64), pad, st, a);
+    hipLaunchKernelGGL((k_fwd<CA, CB, kRing>), dim3(jobs), dim3(64), 0, st, a);
 }
 
 // One launch when the batch's sequences fall into one width class or two adjacent ones (the usual case:
@@ -357,7 +355,7 @@ struct Plan {
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
         { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = NC; hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(NC, false) * c->trace_lds_mult, wk.stream, ta); }
+          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = NC; hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(NC, false), wk.stream, ta); }
           else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
@@ -421,7 +419,7 @@ struct Plan {
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
             { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = maxn; hipLaunchKernelGGL(k_tracew, dim3((ns * gsz + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(maxn, ta.shared_table != 0) * c->trace_lds_mult, wk.stream, ta); }
+          if (c->trace_wave) { ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = maxn; hipLaunchKernelGGL(k_tracew, dim3((ns * gsz + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(maxn, ta.shared_table != 0), wk.stream, ta); }
           else hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         }
         VcAddwArgs wa{};
@@ -457,7 +455,7 @@ struct Plan {
         ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
         { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = NC; hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(NC, false) * c->trace_lds_mult, wk.stream, ta); }
+          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = NC; hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(NC, false), wk.stream, ta); }
           else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcFinishArgs fn{};
         fn.b = c->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;
@@ -494,7 +492,6 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->prm = *p;
     c->device = p->device;
     c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 2;
-    if (getenv("VC_TRACE_LDS_MULT")) c->trace_lds_mult = (uint32_t)atoi(getenv("VC_TRACE_LDS_MULT"));
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }

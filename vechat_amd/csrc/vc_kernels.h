@@ -1339,9 +1339,6 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
 template <int CA, int CB, int RING>
 __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     __shared__ uint32_t ring_raw[RING * (CB / 2) * 64];
-#ifdef VC_EXP_VGPR_CLOBBER
-    asm volatile("" ::: VC_EXP_VGPR_CLOBBER);
-#endif
     if (CA != CB) {
         // sequence length of this job decides the body (uniform per wave)
         const uint32_t job = blockIdx.x, slot = job / a.group;
