@@ -6,12 +6,12 @@
 // There is no CPU fallback anywhere in this file: without a gfx950 device vc_create fails.
 //
 // Execution plan.  The batch is cut into chunks of CW windows; a chunk owns one workspace (graphs,
-// row records, direction matrices, pair lists) and one HIP stream.  Inside a chunk the build loop of
+// row records, stored DP matrices, pair lists) and one HIP stream.  Inside a chunk the build loop of
 // window.cpp:239-298 runs in lockstep: layer j of every window per iteration
-//     k_rows / k_topo -> k_fwd -> k_resolve -> k_trace -> k_addaln
-// then the prune rounds (k_prune_lcc -> k_topo -> [k_fwd, k_trace]* -> k_addw) and the final local
+//     k_rows / k_rows_sub -> k_fwd -> k_resolve -> k_tracew -> k_addaln
+// then the prune rounds (k_prune_lcc -> k_topo -> [k_fwd, k_tracew]* -> k_addw) and the final local
 // alignment.  Several chunks are in flight on separate streams so that the latency-bound single-lane
-// kernels (k_resolve, k_topo, k_prune_lcc) of one chunk overlap the throughput-bound k_fwd of another.
+// kernels (k_tracew, k_addaln, k_rows, k_topo, k_prune_lcc) of one chunk overlap the k_fwd of another.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -662,7 +662,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     if (CW == 0) CW = 1;
     while (CW > 64 && (per_slot_fixed + per_job) * CW > budget) CW /= 2;
     if ((per_slot_fixed + per_job) * CW > budget) return fail(c, VC_ERR_ARG, "scratch budget %llu too small", (unsigned long long)budget);
-    // extra dir space lets re-alignment rounds run several sequences of a window per launch
+    // spare matrix space lets re-alignment rounds run several sequences of a window per launch
     uint64_t spare = budget - (per_slot_fixed + per_job) * CW;
     uint32_t group_max = 1 + (uint32_t)std::min<uint64_t>(spare / (per_job * CW), 7);
     if (group_max > max_nseq) group_max = max_nseq;

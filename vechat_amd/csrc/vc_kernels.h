@@ -1,18 +1,21 @@
 // Hand-written HIP kernels (gfx950 / CDNA4, wave64) for VeChat's per-window hot path.
 // Written for this target only: DPP wave scans, LDS row ring, 16-byte coalesced HBM traffic.
 //
-// Kernel            parallelism           restates (reference file:line)
-//   k_avg           thread / window       window.cpp:216-236,283,292-309 (average_weight, fp64, in order)
-//   k_init          wave / window         window.cpp:188-201 + graph.cpp:109-130,182-212 (backbone chain)
-//   k_topo          wave / window         graph.cpp:301-371 TopologicalSort, :640-732 Subgraph (as a mask),
-//                                         + builds the row records the DP consumes
-//   k_fwd<CPL>      wave / alignment      sisd_alignment_engine.cpp:118-254 Initialize, :292-360 Linear (NW/SW)
-//   k_trace         thread / alignment    sisd_alignment_engine.cpp:362-459 (backtrack)
-//   k_addaln        wave / window         graph.cpp:182-299 AddAlignment (+ :94-107 AddEdge)
-//   k_prune_lcc     wave / window         graph.cpp:811-982 PruneGraph, :984-1102 DfsUtil/LargestSubgraph
-//   k_addw          wave / window         graph.cpp:1104-1165 AddWeights (+ window.cpp:351-372 weights)
-//   k_finish        wave / window         graph.cpp:1167-1179 GenerateCorrectedSequence
-//   k_consensus     wave / window         graph.cpp:450-638 GenerateConsensus (+ window.cpp:141-171 trim), racon-linear overload
+// Kernel            parallelism            restates (reference file:line)
+//   k_avg           wave / window          window.cpp:216-236,283,292-309 (average_weight, fp64, additions in order)
+//   k_init          wave / window          window.cpp:188-201 + graph.cpp:109-130,182-212 (backbone chain)
+//   k_rows          wave / window          row records from the incrementally kept order (full-span layers)
+//   k_rows_sub      wave / window          graph.cpp:640-732 Subgraph membership + row records (partial-span layers)
+//   k_topo          wave / window          graph.cpp:301-371 TopologicalSort (exact DFS) + row records, after a prune
+//   k_fwd<CA,CB>    wave / alignment       sisd_alignment_engine.cpp:118-254 Initialize, :292-360 Linear (NW/SW)
+//   k_resolve       wave / tied alignment  sisd :353-355 "first sink in rank order" among equal end scores
+//   k_tracew        16 lanes / alignment   sisd_alignment_engine.cpp:362-459 (backtrack), speculative and cooperative
+//   k_trace         thread / alignment     the same backtrack, plain (cross-check, VC_TRACE_THREAD=1)
+//   k_addaln        wave / window          graph.cpp:182-299 AddAlignment (+ :94-107 AddEdge) + order maintenance
+//   k_prune_lcc     wave / window          graph.cpp:811-982 PruneGraph, :984-1102 DfsUtil/LargestSubgraph
+//   k_addw          wave / window          graph.cpp:1104-1165 AddWeights (+ window.cpp:351-372 weights)
+//   k_finish        wave / window          graph.cpp:1167-1179 GenerateCorrectedSequence
+//   k_consensus     wave / window          graph.cpp:450-638 GenerateConsensus (+ window.cpp:141-171 trim), racon-linear overload
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vc_device.h"
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
 // still contiguous), so only the membership is needed: a reverse sweep over ord in 64-position blocks,
 // every lane pulling from its out-neighbours / aligned mates, each block iterated to its fixed point
 // with ballots; repeated until nothing changes (groups straddling a block boundary).
-// LDS carve: member bits 8*nW | rowidx 2*NC | spill NC | node-id bitmap 4*(NC/32+1)
+// LDS carve: member bits 8*nW | rowidx 2*NC | node-id bitmap 4*(NC/32+1)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                                  uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask) {
