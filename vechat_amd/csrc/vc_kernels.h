@@ -997,7 +997,7 @@ __device__ __forceinline__ int vc_packed_cell(const uint32_t* w, uint32_t cc, ui
 //     max_p (H[p][j-1] + P[j]) = (max_p H[p][j-1]) + P[j],   max_p (H[p][j] + g) = (max_p H[p][j]) + g,
 // so each additional in-edge costs one packed max per register instead of a full relaxation, and the
 // order of the in-edges is irrelevant here (it matters only to the backtrack, which follows it).
-template <int CPL, int RING>
+template <int CPL, int RING, bool NWT>
 __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_raw) {
     constexpr int ND = CPL / 2;              // packed int16 dwords per lane per row
     constexpr int NDS = vc_nds(CPL);         // dwords per lane per row in the packed stored form
@@ -1016,9 +1016,15 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k + 1] - so);
     if (vc_cpl_for(len) != (uint32_t)CPL) return;             // another width class handles this sequence
     const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
-    bool nw = true;
-    if (a.mode == 2) nw = false;
-    else if (a.mode == 1) nw = (k == 0) || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L);   // window.cpp:336-349
+    // NW or SW is fixed per instantiation (the caller looked at the layer, window.cpp:336-349): the row loop
+    // then carries no alignment-type branches
+    constexpr bool nw = NWT;
+    {
+        bool want = true;
+        if (a.mode == 2) want = false;
+        else if (a.mode == 1) want = (k == 0) || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L);
+        if (want != nw) return;
+    }
     const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
     const uint32_t nrows = a.dp.nrows[slot];
     const uint64_t nb = (uint64_t)slot * a.NC;
@@ -1337,6 +1343,24 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     if (lane == 0) a.job_end[job] = end;
 }
 
+template <int CPL, int RING>
+__device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_raw) {
+    // alignment type of this job (uniform per wave)
+    bool nw = a.mode == 0;
+    if (a.mode == 1) {
+        const uint32_t job = blockIdx.x, slot = job / a.group;
+        if (slot >= a.nslots) return;
+        const uint32_t w = a.w0 + slot, k = a.k0 + job % a.group;
+        const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
+        if (k < ns) {
+            const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
+            nw = (k == 0) || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L);
+        }
+    }
+    if (nw) vc_fwd_body<CPL, RING, true>(a, ring_raw);
+    else vc_fwd_body<CPL, RING, false>(a, ring_raw);
+}
+
 // CA <= CB: the two adjacent width classes of a batch share one launch (register and LDS budget of the
 // wider one); each alignment takes the narrowest body that holds its sequence.  CA == CB: single class.
 template <int CA, int CB, int RING>
@@ -1350,9 +1374,9 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
         uint32_t cls = CB;
         if (k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + k + 1] - a.b.seq_off[s0 + k]));
-        if (cls == (uint32_t)CA) { vc_fwd_body<CA, RING>(a, ring_raw); return; }
+        if (cls == (uint32_t)CA) { vc_fwd_any<CA, RING>(a, ring_raw); return; }
     }
-    vc_fwd_body<CB, RING>(a, ring_raw);
+    vc_fwd_any<CB, RING>(a, ring_raw);
 }
 
 // ------------------------------------------------------------------------------------------------
