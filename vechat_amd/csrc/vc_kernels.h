@@ -1095,13 +1095,15 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
     uint32_t* hrow = hrow0;                                   // stored form of the current row
     const uint32_t rowdw = packed ? NDS * 64 : ND * 64;
-    for (uint32_t i = 1; i <= nrows; ++i) {
-        const uint32_t ri = (i - 1) & 63;
-        if (ri == 0) {
-            myrec = nextrec;
-            const uint32_t r = i - 1 + 64 + lane;
-            if (r < nrows) nextrec = a.dp.frec[nb + r];
-        }
+    for (uint32_t i0 = 1; i0 <= nrows; i0 += 64) {              // blocks of 64 rows: one record fetch, one column-0 flush
+      myrec = nextrec;
+      {
+          const uint32_t r = i0 - 1 + 64 + lane;
+          if (r < nrows) nextrec = a.dp.frec[nb + r];
+      }
+      const uint32_t cnt = min(64u, nrows - i0 + 1);
+      for (uint32_t ri = 0; ri < cnt; ++ri) {
+        const uint32_t i = i0 + ri;
         const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
         const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
         const uint32_t x = r0 & 0xFF, fl = (r0 >> 8) & 0xFF, nq = (r0 >> 16) & 0xFF, bi = r0 >> 24;
@@ -1291,13 +1293,10 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
             for (int q = 0; q < ND; ++q) hrow[q * 64 + lane] = acc[q];
         }
         hrow += rowdw;
-        bool fence = false;
-        if (ri == 63 || i == nrows) {                         // column 0 of the block just completed
-            if ((uint32_t)lane <= ri) c0p_out[i - 1 - ri + lane] = (int16_t)c0vec;
-            fence = true;
-        }
-        if (fence) __threadfence_block();
         __builtin_amdgcn_wave_barrier();
+      }
+      if ((uint32_t)lane < cnt) c0p_out[i0 - 1 + lane] = (int16_t)c0vec;   // column 0 of the block just completed
+      __threadfence_block();
     }
     if (lane == 0 && far_reads) atomicAdd(a.stat + 3, (unsigned long long)far_reads);
 
