@@ -188,6 +188,25 @@ uint32_t    vc_wb_n_polished(const vc_wb* b);
 const char* vc_wb_polished_name(const vc_wb* b, uint32_t i);
 const char* vc_wb_polished_data(const vc_wb* b, uint32_t i, uint64_t* length);
 
+/* ------------------------------------------------------------------------------------------------
+ * Overlap alignment on the device.  Stands in for the edlib call the reference makes
+ * for overlaps without a CIGAR (src/overlap.cpp:205-220): global unit-cost alignment with path, returned
+ * as an edlib-standard CIGAR (M / I / D).  The path is optimal; which of several optimal paths is returned
+ * is this library's choice (diagonal, then insertion, then deletion, from the end), not edlib's.
+ * q / t hold the pieces to align back to back (the query piece already oriented as it aligns);
+ * query + target length of one overlap must not exceed 30000.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t n;
+    const uint64_t* q_off;   /* [n+1] */
+    const uint8_t*  q;
+    const uint64_t* t_off;   /* [n+1] */
+    const uint8_t*  t;
+} vc_align_batch;
+int         vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_cap, uint64_t* cigar_off,
+                     int32_t* edit_distance);
+const char* vc_align_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,5 +72,9 @@ def test_filters(built, tmp_path):
     with pytest.raises(ValueError):
         seqio.read_overlaps(tmp_path / "x.mhap")
     (tmp_path / "nocg.paf").write_text("r\t40\t0\t40\t+\tt\t120\t4\t44\t40\t40\t60\n")
+    o = seqio.read_overlaps(tmp_path / "nocg.paf")
+    assert o[0].cigar is None                                  # to be aligned on the device (seqio.align_missing)
+    wb = WindowBuilder(50, 10.0)
     with pytest.raises(ValueError):
-        seqio.read_overlaps(tmp_path / "nocg.paf")
+        seqio.load_polisher_input(wb, t, r, o)
+    wb.close()

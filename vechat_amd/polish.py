@@ -3,14 +3,14 @@ vechat_racon: `-f -p -d 0.2 -s 0.2` for round 1, `-f` for round 2; scripts/vecha
 
   python -m vechat_amd.polish reads.fastq overlaps.sam targets.fastq > corrected.fasta
 
-Overlaps need a CIGAR (SAM, or PAF with cg:Z:).  There is no CPU path: without the HIP library and a GPU
+Overlaps may be SAM, PAF with cg:Z:, or plain PAF (then they are aligned on the device first).  There is no CPU path: without the HIP library and a GPU
 this exits with an error."""
 import argparse
 import sys
 
 from . import capi
 from .engine import HipContext
-from .seqio import load_polisher_input, read_overlaps, read_sequences
+from .seqio import align_missing, load_polisher_input, read_overlaps, read_sequences
 from .windows import WindowBuilder
 
 
@@ -33,8 +33,9 @@ def main(argv=None):
     a = ap.parse_args(argv)
 
     wb = WindowBuilder(a.window_length, a.quality_threshold)
-    kept, window_type = load_polisher_input(wb, read_sequences(a.targets), read_sequences(a.sequences),
-                                            read_overlaps(a.overlaps), a.error_threshold)
+    targets, reads, overlaps = read_sequences(a.targets), read_sequences(a.sequences), read_overlaps(a.overlaps)
+    n_aligned = align_missing(targets, reads, overlaps, a.error_threshold, a.device)     # PAF without cg:Z: (overlap.cpp:205-220)
+    kept, window_type = load_polisher_input(wb, targets, reads, overlaps, a.error_threshold)
     batch, ids = wb.build()
     ctx = HipContext(device=a.device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
                      num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
@@ -45,7 +46,7 @@ def main(argv=None):
         sys.exit(f"error: {len(bad)} window(s) outside the device envelope (first: {bad[0]}, status {int(status[bad[0]])})")
     for name, data in wb.stitch(cons, status, drop_unpolished=not a.include_unpolished, fragment_correction=True):
         sys.stdout.write(f">{name}\n{data.decode()}\n")
-    print(f"[vechat_amd] {kept} overlaps, {batch.n_windows} windows, {sum(int(s) == capi.VC_WIN_OK for s in status)} polished",
+    print(f"[vechat_amd] {kept} overlaps ({n_aligned} aligned on the device), {batch.n_windows} windows, {sum(int(s) == capi.VC_WIN_OK for s in status)} polished",
           file=sys.stderr)
     return 0
 

@@ -4,8 +4,9 @@ bioparser and its Sequence / Overlap constructors:
   read_sequences  <- src/sequence.cpp:19-42 (upper-casing; an all-'!' quality string counts as no quality),
                      names cut at the first whitespace as bioparser does
   read_sam        <- src/overlap.cpp:44-110 (SAM constructor: unmapped flag, strand, clips, lengths, error)
-  read_paf        <- src/overlap.cpp:29-42  (PAF constructor); a `cg:Z:` tag supplies the CIGAR -- without it
-                     the reference aligns with edlib (overlap.cpp:205-220), which this library does not do
+  read_paf        <- src/overlap.cpp:29-42  (PAF constructor); a `cg:Z:` tag supplies the CIGAR -- without it the
+                     record keeps cigar=None and align_missing() aligns it on the device (vechat_amd/align.py; the
+                     reference uses edlib there, overlap.cpp:205-220)
   load_polisher_input <- src/polisher.cpp:207-352 (reads that are also targets share one record, self-overlaps
                      and overlaps above the error threshold are dropped, window type from the mean read length)
 Parity unpinned: plain restatements, exercised by tests/test_seqio.py.
@@ -108,12 +109,9 @@ def read_paf(path):
             c = ln.rstrip(b"\n").split(b"\t")
             qb, qe, tb, te = int(c[2]), int(c[3]), int(c[7]), int(c[8])
             cg = [x[5:] for x in c[12:] if x.startswith(b"cg:Z:")]
-            if not cg:
-                raise ValueError(f"{path}: PAF record without a cg:Z: CIGAR -- the overlap would have to be aligned first "
-                                 "(the reference uses edlib there; not part of this library)")
             length = max(qe - qb, te - tb)
             out.append(Overlap(q_name=c[0].decode(), t_name=c[5].decode(), strand=c[4] == b"-", q_begin=qb, q_end=qe,
-                               q_length=int(c[1]), t_begin=tb, t_end=te, cigar=cg[0].decode(), length=length,
+                               q_length=int(c[1]), t_begin=tb, t_end=te, cigar=cg[0].decode() if cg else None, length=length,
                                error=1 - min(qe - qb, te - tb) / float(length) if length else 1.0))
     return out
 
@@ -125,6 +123,27 @@ def read_overlaps(path):
     if p.endswith((".paf", ".paf.gz")):
         return read_paf(path)
     raise ValueError(f"{path}: unsupported overlap format (valid extensions: .paf, .paf.gz, .sam, .sam.gz)")
+
+
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def align_missing(targets, reads, overlaps, error_threshold=0.3, device=0):
+    """Give every overlap without a CIGAR one (overlap.cpp:179-203: the aligned pieces are q[q_begin:q_end], reverse
+    complemented for strand '-', and t[t_begin:t_end]).  Overlaps that load_polisher_input would drop are skipped."""
+    from .align import align_pairs
+    seq = {n: d for n, d, _ in reads}
+    tgt = {n: d for n, d, _ in targets}
+    todo = [o for o in overlaps if o.cigar is None and o.q_name in seq and o.t_name in tgt and o.error <= error_threshold
+            and o.q_name != o.t_name]
+    pairs = []
+    for o in todo:
+        q = seq[o.q_name][o.q_begin:o.q_end]
+        pairs.append((q.translate(_COMP)[::-1] if o.strand else q, tgt[o.t_name][o.t_begin:o.t_end]))
+    cigars, _ = align_pairs(pairs, device=device)
+    for o, cg in zip(todo, cigars):
+        o.cigar = cg
+    return len(todo)
 
 
 def load_polisher_input(builder, targets, reads, overlaps, error_threshold=0.3):
@@ -155,6 +174,8 @@ def load_polisher_input(builder, targets, reads, overlaps, error_threshold=0.3):
         q, t = q_id[o.q_name], t_id[o.t_name]
         if o.error > error_threshold or q == t:
             continue
+        if o.cigar is None:
+            raise ValueError("overlap without a CIGAR: run align_missing() first")
         builder.add_overlap(q, t, o.strand, o.q_begin, o.q_end, o.q_length, o.t_begin, o.t_end, o.cigar)
         kept += 1
     if kept == 0:
