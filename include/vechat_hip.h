@@ -206,6 +206,8 @@ typedef struct {
 int         vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_cap, uint64_t* cigar_off,
                      int32_t* edit_distance);
 const char* vc_align_last_error(void);
+/* the aligner keeps its (large) matrix buffer between calls; this gives it back */
+void        vc_align_release(void);
 
 #ifdef __cplusplus
 }

@@ -215,11 +215,29 @@ bool dalloc(std::vector<void*>& list, T** p, size_t n) {
 thread_local std::string g_err;
 int fail(const char* m) { g_err = m; return VC_ERR_HIP; }
 
+// The stored matrices are tens of GB per call; mapping and unmapping that much takes seconds, so the buffer is
+// kept between calls (grow-only, per device) and released by vc_align_release().
+struct MatCache { int device = -1; uint32_t* p = nullptr; uint64_t dwords = 0; };
+MatCache g_mat;
+uint32_t* mat_buffer(int device, uint64_t dwords) {
+    if (g_mat.p && g_mat.device == device && g_mat.dwords >= dwords) return g_mat.p;
+    if (g_mat.p) { (void)hipFree(g_mat.p); g_mat = MatCache{}; }
+    void* q = nullptr;
+    if (hipMalloc(&q, std::max<uint64_t>(dwords, 1) * 4) != hipSuccess) return nullptr;
+    g_mat.device = device; g_mat.p = (uint32_t*)q; g_mat.dwords = dwords;
+    return g_mat.p;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* vc_align_last_error(void) { return g_err.c_str(); }
+
+void vc_align_release(void) {
+    if (g_mat.p) { (void)hipSetDevice(g_mat.device); (void)hipFree(g_mat.p); }
+    g_mat = MatCache{};
+}
 
 // Aligns every (query piece, target piece) pair globally; writes edlib-standard CIGAR strings (M / I / D) back to
 // back into `cigar` (NUL after each) with offsets in cigar_off[n+1], and the edit distances.
@@ -235,7 +253,7 @@ int vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_ca
     }
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    const uint64_t budget = (uint64_t)(free_b * 0.6);
+    const uint64_t budget = (uint64_t)((free_b + (g_mat.device == device ? g_mat.dwords * 4 : 0)) * 0.5);
     std::vector<void*> fixed;
     uint8_t *d_q = nullptr, *d_t = nullptr;
     uint64_t *d_qo = nullptr, *d_to = nullptr;
@@ -267,7 +285,8 @@ int vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_ca
         std::vector<void*> tmp;
         AlnArgs a{};
         uint64_t *d_mo = nullptr, *d_bo = nullptr, *d_oo = nullptr;
-        if (!dalloc(tmp, &a.mat, mat_dw) || !dalloc(tmp, &a.bnd, bnd_n) || !dalloc(tmp, &a.ops, ops_n) || !dalloc(tmp, &a.n_ops, nj) ||
+        a.mat = mat_buffer(device, mat_dw);
+        if (!a.mat || !dalloc(tmp, &a.bnd, bnd_n) || !dalloc(tmp, &a.ops, ops_n) || !dalloc(tmp, &a.n_ops, nj) ||
             !dalloc(tmp, &a.dist, nj) || !dalloc(tmp, &d_mo, nj) || !dalloc(tmp, &d_bo, nj) || !dalloc(tmp, &d_oo, nj)) {
             cleanup(tmp); cleanup(fixed); return fail("hipMalloc failed (overlap too large for the device memory budget?)");
         }
