@@ -62,6 +62,9 @@ def test_cigars_are_optimal_global_alignments(built):
         pairs.append((t, _mut(rng, t, 0.1) or b"A"))
     pairs.append((bytes(rng.choice(b"ACGT") for _ in range(300)), bytes(rng.choice(b"ACGT") for _ in range(2500))))   # unrelated
     pairs.append((b"ACGTNNACGT" * 30, b"ACGTACGT" * 40))
+    big = (b"ACGT" * 4000, b"ACGT" * 4000)                     # 32 000 bases: outside the int16 envelope, reported not aligned
+    cg_big, d_big = align_pairs([pairs[0], big, pairs[1]])
+    assert d_big == [0, -1, 1] and cg_big[1] == "" and cg_big[0] == "1M"
     cigars, dist = align_pairs(pairs)
     for (q, t), cg, d in zip(pairs, cigars, dist):
         assert d == edit_distance(q, t), (len(q), len(t))

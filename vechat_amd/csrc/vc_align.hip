@@ -48,6 +48,7 @@ struct AlnArgs {
     uint32_t n_jobs;
     const uint64_t* q_off; const uint8_t* q;      // query pieces, oriented as they align
     const uint64_t* t_off; const uint8_t* t;      // target pieces
+    const uint8_t* skip;                          // [n_jobs] 1: outside the envelope, treated as an empty pair
     const uint64_t* mat_off;                      // [n_jobs] dword offset of a job's stored matrix
     uint32_t* mat;                                // rows x tiles x 64 lanes x 3 dwords
     const uint64_t* bnd_off; int16_t* bnd;        // [n_jobs] offsets; n+1 boundary-column scores per job
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(64) void k_aln_fwd(AlnArgs a) {
     const int lane = threadIdx.x & 63;
     const uint8_t* q = a.q + a.q_off[job];
     const uint8_t* t = a.t + a.t_off[job];
-    const uint32_t n = (uint32_t)(a.q_off[job + 1] - a.q_off[job]), m = (uint32_t)(a.t_off[job + 1] - a.t_off[job]);
+    const bool skip = a.skip[job] != 0;
+    const uint32_t n = skip ? 0u : (uint32_t)(a.q_off[job + 1] - a.q_off[job]), m = skip ? 0u : (uint32_t)(a.t_off[job + 1] - a.t_off[job]);
     const uint32_t ntiles = (m + kTile - 1) / kTile;
     uint32_t* mat = a.mat + a.mat_off[job];
     int16_t* bnd = a.bnd + a.bnd_off[job];
@@ -177,7 +179,8 @@ __global__ void k_aln_trace(AlnArgs a) {
     if (job >= a.n_jobs) return;
     const uint8_t* q = a.q + a.q_off[job];
     const uint8_t* t = a.t + a.t_off[job];
-    const uint32_t n = (uint32_t)(a.q_off[job + 1] - a.q_off[job]), m = (uint32_t)(a.t_off[job + 1] - a.t_off[job]);
+    const bool skip = a.skip[job] != 0;
+    const uint32_t n = skip ? 0u : (uint32_t)(a.q_off[job + 1] - a.q_off[job]), m = skip ? 0u : (uint32_t)(a.t_off[job + 1] - a.t_off[job]);
     const uint32_t ntiles = (m + kTile - 1) / kTile;
     const uint32_t* mat = a.mat + a.mat_off[job];
     uint8_t* ops = a.ops + a.ops_off[job];
@@ -247,9 +250,11 @@ int vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_ca
     const uint32_t n = b->n;
     cigar_off[0] = 0;
     if (n == 0) return VC_OK;
+    // overlaps beyond the int16 score range are reported (distance -1, empty CIGAR), the rest is aligned
+    std::vector<uint8_t> skip(n, 0);
     for (uint32_t k = 0; k < n; ++k) {
         const uint64_t ql = b->q_off[k + 1] - b->q_off[k], tl = b->t_off[k + 1] - b->t_off[k];
-        if (ql + tl > 30000) return fail("overlap longer than the int16 score range (query + target > 30000)");
+        if (ql + tl > 30000) skip[k] = 1;
     }
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -257,15 +262,17 @@ int vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_ca
     std::vector<void*> fixed;
     uint8_t *d_q = nullptr, *d_t = nullptr;
     uint64_t *d_qo = nullptr, *d_to = nullptr;
+    uint8_t* d_skip = nullptr;
     const uint64_t qbytes = b->q_off[n], tbytes = b->t_off[n];
     auto cleanup = [&](std::vector<void*>& l) { for (void* p : l) (void)hipFree(p); l.clear(); };
-    if (!dalloc(fixed, &d_q, qbytes) || !dalloc(fixed, &d_t, tbytes) || !dalloc(fixed, &d_qo, (size_t)n + 1) || !dalloc(fixed, &d_to, (size_t)n + 1)) {
+    if (!dalloc(fixed, &d_q, qbytes) || !dalloc(fixed, &d_t, tbytes) || !dalloc(fixed, &d_qo, (size_t)n + 1) || !dalloc(fixed, &d_to, (size_t)n + 1) || !dalloc(fixed, &d_skip, (size_t)n)) {
         cleanup(fixed); return fail("hipMalloc failed");
     }
     (void)hipMemcpy(d_q, b->q, qbytes, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_t, b->t, tbytes, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_qo, b->q_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_to, b->t_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_skip, skip.data(), n, hipMemcpyHostToDevice);
     uint64_t out = 0;
     std::string cg;
     for (uint32_t k0 = 0; k0 < n;) {
@@ -274,7 +281,7 @@ int vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_ca
         uint64_t mat_dw = 0, bnd_n = 0, ops_n = 0;
         uint32_t k1 = k0;
         while (k1 < n) {
-            const uint64_t ql = b->q_off[k1 + 1] - b->q_off[k1], tl = b->t_off[k1 + 1] - b->t_off[k1];
+            const uint64_t ql = skip[k1] ? 0 : b->q_off[k1 + 1] - b->q_off[k1], tl = skip[k1] ? 0 : b->t_off[k1 + 1] - b->t_off[k1];
             const uint64_t need = ql * ((tl + kTile - 1) / kTile) * kRowDw;
             if (k1 > k0 && (mat_dw + need) * 4 > budget) break;
             mat_off.push_back(mat_dw); bnd_off.push_back(bnd_n); ops_off.push_back(ops_n);
@@ -293,7 +300,7 @@ int vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_ca
         (void)hipMemcpy(d_mo, mat_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice);
         (void)hipMemcpy(d_bo, bnd_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice);
         (void)hipMemcpy(d_oo, ops_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice);
-        a.n_jobs = nj; a.q_off = d_qo + k0; a.q = d_q; a.t_off = d_to + k0; a.t = d_t;
+        a.n_jobs = nj; a.q_off = d_qo + k0; a.q = d_q; a.t_off = d_to + k0; a.t = d_t; a.skip = d_skip + k0;
         a.mat_off = d_mo; a.bnd_off = d_bo; a.ops_off = d_oo;
         hipLaunchKernelGGL(k_aln_fwd, dim3(nj), dim3(64), 0, 0, a);
         hipLaunchKernelGGL(k_aln_trace, dim3((nj + 63) / 64), dim3(64), 0, 0, a);
@@ -306,6 +313,7 @@ int vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_ca
         cleanup(tmp);
         for (uint32_t k = 0; k < nj; ++k) {
             cg.clear();
+            if (skip[k0 + k]) edit_distance[k0 + k] = -1;
             const uint8_t* o = ops.data() + ops_off[k];
             for (uint32_t p = nops[k]; p > 0;) {                    // stored end first
                 const uint8_t op = o[p - 1];

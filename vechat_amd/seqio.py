@@ -140,10 +140,14 @@ def align_missing(targets, reads, overlaps, error_threshold=0.3, device=0):
     for o in todo:
         q = seq[o.q_name][o.q_begin:o.q_end]
         pairs.append((q.translate(_COMP)[::-1] if o.strand else q, tgt[o.t_name][o.t_begin:o.t_end]))
-    cigars, _ = align_pairs(pairs, device=device)
-    for o, cg in zip(todo, cigars):
-        o.cigar = cg
-    return len(todo)
+    cigars, dist = align_pairs(pairs, device=device)
+    for o, cg, d in zip(todo, cigars, dist):
+        if d < 0:                         # beyond the aligner's envelope: drop the overlap rather than guess
+            o.error = 2.0
+            o.cigar = ""
+        else:
+            o.cigar = cg
+    return sum(1 for d in dist if d >= 0)
 
 
 def load_polisher_input(builder, targets, reads, overlaps, error_threshold=0.3):
