@@ -194,8 +194,8 @@ const char* vc_wb_polished_data(const vc_wb* b, uint32_t i, uint64_t* length);
  * as an edlib-standard CIGAR (M / I / D).  The path is optimal; which of several optimal paths is returned
  * is this library's choice (diagonal, then insertion, then deletion, from the end), not edlib's.
  * q / t hold the pieces to align back to back (the query piece already oriented as it aligns);
- * An overlap whose query + target length exceeds 30000 (int16 score range) is not aligned: its distance
- * comes back as -1 and its CIGAR empty; the others are unaffected.
+ * Any length: scores are kept relative per 2048-column tile.  An overlap whose stored matrix would not fit the
+ * device memory is not aligned: its distance comes back as -1 and its CIGAR empty; the others are unaffected.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
     uint32_t n;

@@ -62,9 +62,12 @@ def test_cigars_are_optimal_global_alignments(built):
         pairs.append((t, _mut(rng, t, 0.1) or b"A"))
     pairs.append((bytes(rng.choice(b"ACGT") for _ in range(300)), bytes(rng.choice(b"ACGT") for _ in range(2500))))   # unrelated
     pairs.append((b"ACGTNNACGT" * 30, b"ACGTACGT" * 40))
-    big = (b"ACGT" * 4000, b"ACGT" * 4000)                     # 32 000 bases: outside the int16 envelope, reported not aligned
-    cg_big, d_big = align_pairs([pairs[0], big, pairs[1]])
-    assert d_big == [0, -1, 1] and cg_big[1] == "" and cg_big[0] == "1M"
+    rng2 = random.Random(5)
+    long_t = bytes(rng2.choice(b"ACGT") for _ in range(21000))                # beyond int16 as an absolute score: relative scores
+    long_q = _mut(rng2, long_t, 0.2)
+    cg_big, d_big = align_pairs([pairs[0], (long_q, long_t), pairs[1]])
+    assert d_big[0] == 0 and d_big[2] == 1 and cg_big[0] == "1M"
+    assert d_big[1] == edit_distance(long_q, long_t) and cigar_cost(cg_big[1], long_q, long_t) == d_big[1]
     cigars, dist = align_pairs(pairs)
     for (q, t), cg, d in zip(pairs, cigars, dist):
         assert d == edit_distance(q, t), (len(q), len(t))

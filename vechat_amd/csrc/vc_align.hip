@@ -11,8 +11,9 @@
 // Kernels (gfx950, wave64):
 //   k_aln_fwd    one wave per overlap.  Rows = query bases, columns = target bases in tiles of 2048 (64 lanes x
 //                32 cells as packed int16 pairs).  Same arithmetic as the POA forward kernel: tilted scores
-//                T = H + jj (unit gap), so the horizontal pass is a prefix maximum; the row above stays in
-//                registers (a sequence is a chain: one predecessor).  No band: the full n x m matrix costs
+//                (H + jj, unit gap), so the horizontal pass is a prefix maximum; the row above stays in
+//                registers (a sequence is a chain: one predecessor).  Scores are relative to the row's value at
+//                the tile boundary, so int16 suffices for any length; boundary columns are int32 in HBM.  No band: the full n x m matrix costs
 //                ~1e8 cells for a 10 kb overlap, 40 us of this chip.  Stored per row, tile and lane: the first
 //                cell as int16 and the 31 steps to its right neighbours (each 0, 1 or 2) as 2-bit fields --
 //                12 bytes per 32 cells, 0.375 B/cell, otherwise the stores would exceed HBM bandwidth.
@@ -51,7 +52,7 @@ struct AlnArgs {
     const uint8_t* skip;                          // [n_jobs] 1: outside the envelope, treated as an empty pair
     const uint64_t* mat_off;                      // [n_jobs] dword offset of a job's stored matrix
     uint32_t* mat;                                // rows x tiles x 64 lanes x 3 dwords
-    const uint64_t* bnd_off; int16_t* bnd;        // [n_jobs] offsets; n+1 boundary-column scores per job
+    const uint64_t* bnd_off; int32_t* bnd;        // [n_jobs] offsets; per job [tiles][n+1]: H at each tile's left boundary column
     int32_t* dist;                                // [n_jobs] edit distance
     const uint64_t* ops_off; uint8_t* ops;        // [n_jobs] offsets; n+m op bytes per job (0 M, 1 I, 2 D), end first
     uint32_t* n_ops;                              // [n_jobs]
@@ -67,11 +68,18 @@ __global__ __launch_bounds__(64) void k_aln_fwd(AlnArgs a) {
     const uint32_t n = skip ? 0u : (uint32_t)(a.q_off[job + 1] - a.q_off[job]), m = skip ? 0u : (uint32_t)(a.t_off[job + 1] - a.t_off[job]);
     const uint32_t ntiles = (m + kTile - 1) / kTile;
     uint32_t* mat = a.mat + a.mat_off[job];
-    int16_t* bnd = a.bnd + a.bnd_off[job];
+    int32_t* bnd = a.bnd + a.bnd_off[job];
     const uint32_t ones = 0x00010001u;
     int last = 0;
+    // Scores are kept RELATIVE to the row's value at the tile's left boundary column ts:
+    //     R[i][jj] = H[i][ts + jj] - H[i][ts] + jj   in [0, 2 * 2048],
+    // so int16 holds them whatever the overlap's length; the boundary columns themselves (B[ct][i] = H[i][ts]) are
+    // int32 in HBM.  With d = B[i-1] - B[i] (-1, 0 or +1): diagonal R' + 1 + s + d, vertical R' - 1 + d, horizontal = prefix
+    // maximum starting from R[i][0] = 0.
     for (uint32_t ct = 0; ct < ntiles; ++ct) {
-        const int base = -(int)(ct * kTile);              // H[0][first column of the tile - 1] ... T of row 0 everywhere
+        const int ts = (int)(ct * kTile);
+        const int32_t* bin = bnd + (uint64_t)ct * (n + 1);                  // this tile's boundary column (ct > 0)
+        int32_t* bout = bnd + (uint64_t)(ct + 1) * (n + 1);                 // the next tile's
         uint32_t sbp[kND];
 #pragma unroll
         for (int k = 0; k < kND; ++k) {
@@ -81,27 +89,29 @@ __global__ __launch_bounds__(64) void k_aln_fwd(AlnArgs a) {
         }
         uint32_t acc[kND];
 #pragma unroll
-        for (int k = 0; k < kND; ++k) acc[k] = pdup(base);
-        int c0prev = base;                                 // H[0][tile start]
+        for (int k = 0; k < kND; ++k) acc[k] = 0;                          // row 0: R = 0 everywhere
+        int bprev = -ts;                                                    // B[ct][0] = H[0][ts]
         for (uint32_t i0 = 1; i0 <= n; i0 += 64) {
             const uint32_t cnt = min(64u, n - i0 + 1);
-            // this block's query bases and incoming boundary scores: lane r holds row i0 + r
+            // this block's query bases and boundary scores: lane r holds row i0 + r
             const uint32_t myq = (uint32_t)lane < cnt ? q[i0 - 1 + lane] : 0u;
-            int mybnd = -(int)(i0 + lane);                 // first tile: H[i][0] = -i
-            if (ct != 0 && (uint32_t)lane < cnt) mybnd = bnd[i0 + lane];
-            int outv = 0;                                  // lane r: boundary score this tile hands on for row i0 + r
+            int mybnd = -(int)(i0 + lane);                                  // first tile: H[i][0] = -i
+            if (ct != 0 && (uint32_t)lane < cnt) mybnd = bin[i0 + lane];
+            int outv = 0;                                                   // lane r: H[i0 + r][ts + 2048]
             for (uint32_t ri = 0; ri < cnt; ++ri) {
                 const uint32_t i = i0 + ri;
                 const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)myq, ri);
-                const int c0cur = __builtin_amdgcn_readlane(mybnd, ri);
+                const int bcur = __builtin_amdgcn_readlane(mybnd, ri);
+                const int d = bprev - bcur;
+                const uint32_t cd = pdup(1 + d), cv = pdup(d - 1);
                 const uint32_t xx = x * 0x10001u;
-                const uint32_t left = (uint32_t)ALN_DPP((int)acc[kND - 1], (int)((uint32_t)c0prev << 16), 0x138, 0xF);
+                const uint32_t left = (uint32_t)ALN_DPP((int)acc[kND - 1], 0, 0x138, 0xF);      // lane 0: R[i-1][0] = 0
                 uint32_t P[kND];
 #pragma unroll
                 for (int k = 0; k < kND; ++k) {
                     const uint32_t sh = __builtin_amdgcn_alignbit(acc[k], k == 0 ? left : acc[k - 1], 16);
-                    const uint32_t dg = psub(padd(sh, ones), pminu(sbp[k] ^ xx, ones));      // +1 on a match, +0 on a mismatch (tilted)
-                    P[k] = pmax(dg, psub(acc[k], ones));                                      // vertical: -1 (tilted)
+                    const uint32_t dg = psub(padd(sh, cd), pminu(sbp[k] ^ xx, ones));           // match: + 1 + d, mismatch: + d
+                    P[k] = pmax(dg, padd(acc[k], cv));                                           // vertical: - 1 + d
                 }
                 P[0] = hi_with_lo(P[0]);
 #pragma unroll
@@ -114,12 +124,12 @@ __global__ __launch_bounds__(64) void k_aln_fwd(AlnArgs a) {
                 sc = max(sc, ALN_DPP(sc, ALN_INT_MIN, 0x142, 0xA));
                 sc = max(sc, ALN_DPP(sc, ALN_INT_MIN, 0x143, 0xC));
                 int carry = ALN_DPP(sc, ALN_INT_MIN, 0x138, 0xF);
-                carry = max(carry, c0cur);
+                carry = max(carry, 0);                                       // R[i][0] = 0
                 const uint32_t cc = pdup(carry);
 #pragma unroll
                 for (int k = 0; k < kND; ++k) acc[k] = pmax(P[k], cc);
-                // score at the tile's last column, as H (T - 2048), for the next tile / the result
-                const int endv = __builtin_amdgcn_readlane((int)acc[kND - 1] >> 16, 63) - kTile;
+                // H at the tile's last column: the next tile's boundary value
+                const int endv = __builtin_amdgcn_readlane((int)acc[kND - 1] >> 16, 63) - kTile + bcur;
                 outv = ((uint32_t)lane == ri) ? endv : outv;
                 if (i == n && ct == ntiles - 1) {
                     // the cell (n, m): lane and slot of column m in this tile
@@ -128,8 +138,9 @@ __global__ __launch_bounds__(64) void k_aln_fwd(AlnArgs a) {
 #pragma unroll
                     for (int k = 1; k < kND; ++k) hv = (c / 2 == (uint32_t)k) ? acc[k] : hv;
                     const int v = (c & 1) ? ((int)hv >> 16) : (int)(short)(hv & 0xFFFF);
-                    last = __builtin_amdgcn_readlane(v, l) - (int)jj;
+                    last = __builtin_amdgcn_readlane(v, l) - (int)jj + bcur;
                 }
+                bprev = bcur;
                 // stored form: anchor | pairs 1..4, pairs 5..12, pairs 13..15 | step 1
                 uint32_t w0, w1 = 0, w2 = 0;
                 {
@@ -147,16 +158,15 @@ __global__ __launch_bounds__(64) void k_aln_fwd(AlnArgs a) {
                 }
                 uint32_t* dst = mat + ((uint64_t)(i - 1) * ntiles + ct) * kRowDw + lane * 3;
                 dst[0] = w0; dst[1] = w1; dst[2] = w2;
-                c0prev = c0cur;
             }
-            if ((uint32_t)lane < cnt) bnd[i0 + lane] = (int16_t)outv;          // in place: this block's old values were read above
+            if (ct + 1 < ntiles && (uint32_t)lane < cnt) bout[i0 + lane] = outv;
         }
     }
     if (lane == 0) a.dist[job] = n == 0 ? (int32_t)m : (m == 0 ? (int32_t)n : -last);
 }
 
-// H[i][j] from the stored tiles (i >= 1, j >= 1)
-__device__ __forceinline__ int aln_cell(const uint32_t* mat, uint32_t ntiles, uint32_t i, uint32_t j) {
+// H[i][j] from the stored tiles (i >= 1, j >= 1): the relative score plus the row's boundary value of that tile
+__device__ __forceinline__ int aln_cell(const uint32_t* mat, const int32_t* bnd, uint32_t n, uint32_t ntiles, uint32_t i, uint32_t j) {
     const uint32_t ct = (j - 1) / kTile, jj = j - ct * kTile, l = (jj - 1) / kCPL, c = (jj - 1) % kCPL;
     const uint32_t* w = mat + ((uint64_t)(i - 1) * ntiles + ct) * kRowDw + l * 3;
     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
@@ -171,7 +181,7 @@ __device__ __forceinline__ int aln_cell(const uint32_t* mat, uint32_t ntiles, ui
         s = (s & 0x0F0F0F0F0F0F0F0Full) + ((s >> 4) & 0x0F0F0F0F0F0F0F0Full);
         v += (int)((s * 0x0101010101010101ull) >> 56);
     }
-    return v - (int)jj;
+    return v - (int)jj + (ct == 0 ? -(int)i : bnd[(uint64_t)ct * (n + 1) + i]);
 }
 
 __global__ void k_aln_trace(AlnArgs a) {
@@ -183,11 +193,12 @@ __global__ void k_aln_trace(AlnArgs a) {
     const uint32_t n = skip ? 0u : (uint32_t)(a.q_off[job + 1] - a.q_off[job]), m = skip ? 0u : (uint32_t)(a.t_off[job + 1] - a.t_off[job]);
     const uint32_t ntiles = (m + kTile - 1) / kTile;
     const uint32_t* mat = a.mat + a.mat_off[job];
+    const int32_t* bnd = a.bnd + a.bnd_off[job];
     uint8_t* ops = a.ops + a.ops_off[job];
     auto H = [&](uint32_t i, uint32_t j) -> int {
         if (i == 0) return -(int)j;
         if (j == 0) return -(int)i;
-        return aln_cell(mat, ntiles, i, j);
+        return aln_cell(mat, bnd, n, ntiles, i, j);
     };
     uint32_t i = n, j = m, k = 0;
     int h = H(i, j);
@@ -250,11 +261,13 @@ int vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_ca
     const uint32_t n = b->n;
     cigar_off[0] = 0;
     if (n == 0) return VC_OK;
-    // overlaps beyond the int16 score range are reported (distance -1, empty CIGAR), the rest is aligned
+    size_t free_b0 = 0, total_b0 = 0;
+    (void)hipMemGetInfo(&free_b0, &total_b0);
+    // an overlap whose stored matrix alone would not fit the device is reported (distance -1, empty CIGAR)
     std::vector<uint8_t> skip(n, 0);
     for (uint32_t k = 0; k < n; ++k) {
         const uint64_t ql = b->q_off[k + 1] - b->q_off[k], tl = b->t_off[k + 1] - b->t_off[k];
-        if (ql + tl > 30000) skip[k] = 1;
+        if (ql >= (1ull << 31) || tl >= (1ull << 31) || ql * ((tl + kTile - 1) / kTile) * kRowDw * 4 > total_b0 / 3) skip[k] = 1;
     }
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -285,7 +298,7 @@ int vc_align(int device, const vc_align_batch* b, char* cigar, uint64_t cigar_ca
             const uint64_t need = ql * ((tl + kTile - 1) / kTile) * kRowDw;
             if (k1 > k0 && (mat_dw + need) * 4 > budget) break;
             mat_off.push_back(mat_dw); bnd_off.push_back(bnd_n); ops_off.push_back(ops_n);
-            mat_dw += need; bnd_n += ql + 1; ops_n += ql + tl;
+            mat_dw += need; bnd_n += (ql + 1) * ((tl + kTile - 1) / kTile + 1); ops_n += ql + tl;
             ++k1;
         }
         const uint32_t nj = k1 - k0;
