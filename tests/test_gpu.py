@@ -104,6 +104,21 @@ def test_command_line_from_files(built, tmp_path, capsys, flags, key):
     assert got == fx["expected"][key]["stitched"]
 
 
+def test_command_line_distributed_path(built, tmp_path, capsys, monkeypatch):
+    """The one-process-per-GPU path of the command line (cost-balanced window range, RCCL gather, rank 0 stitches),
+    exercised with a single rank."""
+    from test_seqio import write_inputs
+    from vechat_amd import polish
+    monkeypatch.setenv("VC_FORCE_DIST", "1")
+    monkeypatch.setenv("MASTER_PORT", "29547")
+    fx, wb = fixtures.load_plumbing()
+    wb.close()
+    rp, op, tp = write_inputs(fx, tmp_path, sam=True)
+    assert polish.main([str(rp), str(op), str(tp), "-p"]) == 0
+    out = capsys.readouterr().out.strip().split("\n")
+    assert [[out[i][1:], out[i + 1]] for i in range(0, len(out), 2)] == fx["expected"]["hap"]["stitched"]
+
+
 def test_thread_per_alignment_backtrack_agrees(built, monkeypatch):
     """The simple one-thread-per-alignment backtrack (kept as a cross-check of the cooperative k_tracew)."""
     monkeypatch.setenv("VC_TRACE_THREAD", "1")

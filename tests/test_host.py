@@ -79,3 +79,13 @@ def test_window_mirror_validates_like_the_reference(built):
         w.add_layer(b"ACGT", None, 6, 5)
     with pytest.raises(ValueError):
         engine.create_window(0, 0, 1, b"", b"")
+
+
+def test_batch_slice_equals_select(built):
+    b = capi.synth_batch(capi.synth_cfg(9, 80, 5, frac_partial=0.3), 0, 7)
+    for lo, hi in ((0, 7), (2, 5), (6, 7), (3, 3)):
+        x, y = b.slice(lo, hi), b.select(list(range(lo, hi))) if hi > lo else None
+        assert x.n_windows == hi - lo
+        if y is not None:
+            for k in ("win_seq_off", "seq_off", "seq_begin", "seq_end", "seq_has_qual", "bases", "quals", "win_fasta"):
+                assert np.array_equal(getattr(x, k), getattr(y, k)), k

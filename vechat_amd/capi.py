@@ -136,6 +136,14 @@ class Batch:
             e.append(int(self.seq_end[s]))
         return seqs, quals, b, e
 
+    def slice(self, lo, hi):
+        """Windows [lo, hi) as a new Batch (contiguous range: offsets rebased, no per-window work)."""
+        s0, s1 = int(self.win_seq_off[lo]), int(self.win_seq_off[hi])
+        b0, b1 = int(self.seq_off[s0]), int(self.seq_off[s1])
+        return Batch(self.win_seq_off[lo:hi + 1] - np.uint32(s0), self.seq_off[s0:s1 + 1] - np.uint64(b0),
+                     self.seq_begin[s0:s1], self.seq_end[s0:s1], self.seq_has_qual[s0:s1], self.bases[b0:b1],
+                     self.quals[b0:b1], self.win_fasta[lo:hi], None if self.seq_orig is None else self.seq_orig[s0:s1])
+
     def select(self, idx):
         """A new Batch holding windows idx (in that order)."""
         return Batch.from_windows([self.window(w) for w in idx], [int(self.win_fasta[w]) for w in idx],

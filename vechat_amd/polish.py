@@ -6,6 +6,7 @@ vechat_racon: `-f -p -d 0.2 -s 0.2` for round 1, `-f` for round 2; scripts/vecha
 Overlaps may be SAM, PAF with cg:Z:, or plain PAF (then they are aligned on the device first).  There is no CPU path: without the HIP library and a GPU
 this exits with an error."""
 import argparse
+import os
 import sys
 
 from . import capi
@@ -37,10 +38,39 @@ def main(argv=None):
     n_aligned = align_missing(targets, reads, overlaps, a.error_threshold, a.device)     # PAF without cg:Z: (overlap.cpp:205-220)
     kept, window_type = load_polisher_input(wb, targets, reads, overlaps, a.error_threshold)
     batch, ids = wb.build()
-    ctx = HipContext(device=a.device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
+    # one process per GPU when launched through torch.distributed.run: every rank reads the inputs, takes a contiguous
+    # cost-balanced range of windows and rank 0 gathers the results over RCCL and writes the output
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    distributed = world > 1 or os.environ.get("VC_FORCE_DIST") == "1"
+    device = int(os.environ.get("LOCAL_RANK", a.device)) if distributed else a.device
+    ctx = HipContext(device=device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
                      num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
                      window_type=window_type)
-    cons, status = ctx.consensus(batch)
+    if not distributed:
+        cons, status = ctx.consensus(batch)
+    else:
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        from .shard import estimated_cells, gather_consensus, shard_range_balanced
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        dev = torch.device("cuda", device)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        lo, hi = shard_range_balanced(estimated_cells(batch), rank, world)
+        lc, ls = ctx.consensus(batch.slice(lo, hi)) if hi > lo else ([], np.zeros(0, np.uint8))
+        payload = torch.from_numpy(np.frombuffer(b"".join(lc), dtype=np.uint8).copy()).to(dev)
+        # length and status of a window travel together: status in the bits above 40
+        lens = torch.tensor([len(x) | (int(s) << 40) for x, s in zip(lc, ls)], dtype=torch.int64, device=dev)
+        call, lall = gather_consensus(payload, lens, dst=0, force=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return 0
+        lall = lall.cpu().numpy()
+        blob = call.cpu().numpy().tobytes()
+        off = np.concatenate([[0], np.cumsum(lall & ((1 << 40) - 1))])
+        cons = [blob[int(off[w]):int(off[w + 1])] for w in range(batch.n_windows)]
+        status = (lall >> 40).astype(np.uint8)
     bad = [w for w in range(batch.n_windows) if int(status[w]) > capi.VC_WIN_UNPOLISHED]
     if bad:
         sys.exit(f"error: {len(bad)} window(s) outside the device envelope (first: {bad[0]}, status {int(status[bad[0]])})")
