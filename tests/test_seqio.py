@@ -70,7 +70,12 @@ def test_filters(built, tmp_path):
     assert kept == 1 and wtype == 0                       # self overlap, high error and unknown read are dropped
     wb.close()
     with pytest.raises(ValueError):
-        seqio.read_overlaps(tmp_path / "x.mhap")
+        seqio.read_overlaps(tmp_path / "x.txt")
+    (tmp_path / "x.mhap").write_text("2 1 0.1 10 0 0 40 40 1 4 44 120\n")
+    mh = seqio.read_overlaps(tmp_path / "x.mhap")
+    assert (mh[0].q_name, mh[0].t_name, mh[0].strand, mh[0].cigar) == ("#1", "#0", True, None)
+    seqio._resolve_indices(t, r, mh)
+    assert (mh[0].q_name, mh[0].t_name) == ("r", "t")
     (tmp_path / "nocg.paf").write_text("r\t40\t0\t40\t+\tt\t120\t4\t44\t40\t40\t60\n")
     o = seqio.read_overlaps(tmp_path / "nocg.paf")
     assert o[0].cigar is None                                  # to be aligned on the device (seqio.align_missing)

@@ -7,6 +7,7 @@ bioparser and its Sequence / Overlap constructors:
   read_paf        <- src/overlap.cpp:29-42  (PAF constructor); a `cg:Z:` tag supplies the CIGAR -- without it the
                      record keeps cigar=None and align_missing() aligns it on the device (vechat_amd/align.py; the
                      reference uses edlib there, overlap.cpp:205-220)
+  read_mhap       <- src/overlap.cpp:14-27  (MHAP constructor: 1-based file positions, strand = a_rc ^ b_rc); no CIGAR
   load_polisher_input <- src/polisher.cpp:207-352 (reads that are also targets share one record, self-overlaps
                      and overlaps above the error threshold are dropped, window type from the mean read length)
 Parity unpinned: plain restatements, exercised by tests/test_seqio.py.
@@ -116,16 +117,44 @@ def read_paf(path):
     return out
 
 
+def read_mhap(path):
+    """MHAP: `a_id b_id error minmers a_rc a_begin a_end a_length b_rc b_begin b_end b_length`; ids are 1-based positions in
+    the reads / targets files (overlap.cpp:14-27), kept here as "#<index>" names that load_polisher_input resolves."""
+    out = []
+    with _open(path) as f:
+        for ln in f:
+            c = ln.split()
+            if not c:
+                continue
+            a_rc, ab, ae, al, b_rc, bb, be = int(c[4]), int(c[5]), int(c[6]), int(c[7]), int(c[8]), int(c[9]), int(c[10])
+            length = max(ae - ab, be - bb)
+            out.append(Overlap(q_name=f"#{int(c[0]) - 1}", t_name=f"#{int(c[1]) - 1}", strand=bool(a_rc ^ b_rc), q_begin=ab, q_end=ae,
+                               q_length=al, t_begin=bb, t_end=be, cigar=None, length=length,
+                               error=1 - min(ae - ab, be - bb) / float(length) if length else 1.0))
+    return out
+
+
 def read_overlaps(path):
     p = str(path)
+    if p.endswith((".mhap", ".mhap.gz")):
+        return read_mhap(path)
     if p.endswith((".sam", ".sam.gz")):
         return read_sam(path)
     if p.endswith((".paf", ".paf.gz")):
         return read_paf(path)
-    raise ValueError(f"{path}: unsupported overlap format (valid extensions: .paf, .paf.gz, .sam, .sam.gz)")
+    raise ValueError(f"{path}: unsupported overlap format (valid extensions: .mhap, .mhap.gz, .paf, .paf.gz, .sam, .sam.gz)")
 
 
 _COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _resolve_indices(targets, reads, overlaps):
+    """MHAP records name sequences by file position ("#k"): turn them into names (overlap.cpp:129-166, id_to_id)."""
+    for o in overlaps:
+        if o.q_name.startswith("#") and o.q_name[1:].isdigit() and int(o.q_name[1:]) < len(reads):
+            o.q_name = reads[int(o.q_name[1:])][0]
+        if o.t_name.startswith("#") and o.t_name[1:].isdigit() and int(o.t_name[1:]) < len(targets):
+            o.t_name = targets[int(o.t_name[1:])][0]
 
 
 def align_missing(targets, reads, overlaps, error_threshold=0.3, device=0):
@@ -134,6 +163,7 @@ def align_missing(targets, reads, overlaps, error_threshold=0.3, device=0):
     from .align import align_pairs
     seq = {n: d for n, d, _ in reads}
     tgt = {n: d for n, d, _ in targets}
+    _resolve_indices(targets, reads, overlaps)
     todo = [o for o in overlaps if o.cigar is None and o.q_name in seq and o.t_name in tgt and o.error <= error_threshold
             and o.q_name != o.t_name]
     pairs = []
@@ -157,6 +187,7 @@ def load_polisher_input(builder, targets, reads, overlaps, error_threshold=0.3):
         raise ValueError("empty target sequences set")
     if not reads:
         raise ValueError("empty sequences set")
+    _resolve_indices(targets, reads, overlaps)
     t_id, q_id = {}, {}
     for name, data, qual in targets:
         t_id[name] = builder.add_sequence(name, data, qual)
