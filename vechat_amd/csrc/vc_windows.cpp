@@ -76,55 +76,52 @@ void make_reverse(Seq& s) {
     s.rq.assign(s.qual.rbegin(), s.qual.rend());
 }
 
-// overlap.cpp:222-292.  atoi(&cigar[j]) reads the run length that precedes operation i.
+// Breaking points of an overlap from its CIGAR (what src/overlap.cpp:222-292 computes base by base): for every
+// window of the target the overlap touches, the first aligned (target, query) position inside it and the position
+// one past the last aligned pair.  Done run by run here: a run of matches or deletions is cut at the window ends
+// it crosses.  Window ends are the last target position of each window, and the overlap's own end.
 void breaking_points_from_cigar(Ovl& o, const char* cigar, uint32_t window_length) {
-    std::vector<int32_t> window_ends;
-    for (uint32_t i = 0; i < o.t_end; i += window_length)
-        if (i > o.t_begin) window_ends.emplace_back((int32_t)i - 1);
-    window_ends.emplace_back((int32_t)o.t_end - 1);
+    std::vector<int64_t> ends;
+    for (uint64_t e = window_length; e < o.t_end; e += window_length)
+        if (e > o.t_begin) ends.push_back((int64_t)e - 1);
+    ends.push_back((int64_t)o.t_end - 1);
 
-    uint32_t w = 0;
-    bool found_first_match = false;
-    std::pair<uint32_t, uint32_t> first_match(0, 0), last_match(0, 0);
-    int32_t q_ptr = (int32_t)(o.strand ? (o.q_length - o.q_end) : o.q_begin) - 1;
-    int32_t t_ptr = (int32_t)o.t_begin - 1;
-    const size_t n = std::strlen(cigar);
-    auto at_end = [&]() { return w < window_ends.size() && t_ptr == window_ends[w]; };
-    for (size_t i = 0, j = 0; i < n; ++i) {
-        const char c = cigar[i];
-        if (c == 'M' || c == '=' || c == 'X') {
-            const uint32_t num_bases = (uint32_t)std::atoi(&cigar[j]);
-            j = i + 1;
-            for (uint32_t k = 0; k < num_bases; ++k) {
-                ++q_ptr; ++t_ptr;
-                if (!found_first_match) {
-                    found_first_match = true;
-                    first_match = {(uint32_t)t_ptr, (uint32_t)q_ptr};
-                }
-                last_match = {(uint32_t)t_ptr + 1, (uint32_t)q_ptr + 1};
-                if (at_end()) {
-                    if (found_first_match) { o.bp.emplace_back(first_match); o.bp.emplace_back(last_match); }
-                    found_first_match = false;
-                    ++w;
-                }
+    size_t w = 0;
+    bool open = false;                                   // a first aligned pair of the current window has been seen
+    std::pair<uint32_t, uint32_t> first(0, 0), last(0, 0);
+    int64_t tpos = (int64_t)o.t_begin - 1;               // last consumed target / query position
+    int64_t qpos = (int64_t)(o.strand ? o.q_length - o.q_end : o.q_begin) - 1;
+    auto close_window = [&]() {
+        if (open) { o.bp.push_back(first); o.bp.push_back(last); }
+        open = false;
+        ++w;
+    };
+    // consume `len` target positions (aligned to query positions or not), stopping at every window end on the way
+    auto advance = [&](uint64_t len, bool aligned) {
+        while (len) {
+            uint64_t k = len;
+            if (w < ends.size() && ends[w] >= tpos) k = std::min<uint64_t>(len, (uint64_t)std::max<int64_t>(ends[w] - tpos, 1));
+            if (aligned) {
+                if (!open) { open = true; first = {(uint32_t)(tpos + 1), (uint32_t)(qpos + 1)}; }
+                qpos += (int64_t)k;
             }
-        } else if (c == 'I') {
-            q_ptr += std::atoi(&cigar[j]);
-            j = i + 1;
-        } else if (c == 'D' || c == 'N') {
-            const uint32_t num_bases = (uint32_t)std::atoi(&cigar[j]);
-            j = i + 1;
-            for (uint32_t k = 0; k < num_bases; ++k) {
-                ++t_ptr;
-                if (at_end()) {
-                    if (found_first_match) { o.bp.emplace_back(first_match); o.bp.emplace_back(last_match); }
-                    found_first_match = false;
-                    ++w;
-                }
-            }
-        } else if (c == 'S' || c == 'H' || c == 'P') {
-            j = i + 1;
+            tpos += (int64_t)k;
+            if (aligned) last = {(uint32_t)(tpos + 1), (uint32_t)(qpos + 1)};
+            len -= k;
+            if (w < ends.size() && tpos == ends[w]) close_window();
         }
+    };
+    for (const char* p = cigar; *p;) {
+        char* e = nullptr;
+        const uint64_t len = std::strtoull(p, &e, 10);
+        if (e == p || !*e) break;                        // no run length / no operation: stop like atoi-driven parsing would
+        switch (*e) {
+            case 'M': case '=': case 'X': advance(len, true); break;
+            case 'D': case 'N': advance(len, false); break;
+            case 'I': qpos += (int64_t)len; break;
+            default: break;                              // S, H, P consume nothing here (clips are in q_begin / q_end)
+        }
+        p = e + 1;
     }
 }
 
