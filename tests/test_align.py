@@ -55,7 +55,8 @@ def _mut(rng, s, rate):
 def test_cigars_are_optimal_global_alignments(built):
     from vechat_amd.align import align_pairs
     rng = random.Random(11)
-    pairs = [(b"A", b"A"), (b"A", b"C"), (b"ACGT", b"A"), (b"A", b"ACGTACGT"), (b"ACGTTGCA", b"ACGTTGCA")]
+    pairs = [(b"A", b"A"), (b"A", b"C"), (b"ACGT", b"A"), (b"A", b"ACGTACGT"), (b"ACGTTGCA", b"ACGTTGCA"),
+             (b"", b"ACG"), (b"ACG", b""), (b"", b"")]
     for L in (7, 33, 64, 65, 500, 2047, 2048, 2049, 3000, 4500):
         t = bytes(rng.choice(b"ACGT") for _ in range(L))
         pairs.append((_mut(rng, t, 0.25) or b"A", t))
