@@ -73,7 +73,12 @@ struct vc_ctx {
     std::string err;
     std::vector<void*> allocs;          // lifetime of the context
     std::vector<void*> batch_allocs;    // per batch
+    // batch and collect buffers are kept between calls (grow-only): hipMalloc / hipFree synchronise the whole device and
+    // would serialise two contexts that a caller runs side by side to hide one batch's H2D behind the other's kernels
+    struct Slot { void* p = nullptr; size_t cap = 0; };
+    Slot slots[16];
     std::vector<void*> chunk_allocs;    // workspaces (re-created when capacities change)
+    uint64_t chunk_bytes = 0;           // what they hold: counts as available when the next batch is planned
 
     bool have_batch = false, ran = false;
     VcBatchDev b{};
@@ -131,6 +136,28 @@ int dalloc(vc_ctx* c, std::vector<void*>& list, T** out, size_t n) {
     if (e != hipSuccess) return fail(c, VC_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     list.push_back(p);
     *out = static_cast<T*>(p);
+    return VC_OK;
+}
+
+void sync_ctx(vc_ctx* c) {
+    (void)hipStreamSynchronize(c->stream);
+    for (uint32_t k = 0; k < c->n_streams; ++k) if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
+}
+
+template <typename T>
+int salloc(vc_ctx* c, int slot, T** out, size_t n) {
+    vc_ctx::Slot& s = c->slots[slot];
+    const size_t bytes = std::max<size_t>(n * sizeof(T), 256);
+    if (s.cap < bytes) {
+        sync_ctx(c);
+        if (s.p) (void)hipFree(s.p);
+        s.p = nullptr; s.cap = 0;
+        const size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&s.p, want);
+        if (e != hipSuccess) return fail(c, VC_ERR_HIP, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        s.cap = want;
+    }
+    *out = static_cast<T*>(s.p);
     return VC_OK;
 }
 
@@ -531,9 +558,10 @@ int vc_create(vc_ctx** out, const vc_params* p) {
 void vc_destroy(vc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
+    sync_ctx(c);
     free_list(c->chunk_allocs);
     free_list(c->batch_allocs);
+    for (auto& sl : c->slots) if (sl.p) (void)hipFree(sl.p);
     free_list(c->allocs);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) { if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); }
@@ -597,20 +625,19 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         const double est = depth > 0 ? 0.33 * ((double)sum / depth) * std::pow(depth, 0.55) : 0.0;
         need_nodes = std::max<uint64_t>(need_nodes, L + (uint64_t)std::ceil(est) + 64);
     }
-    (void)hipDeviceSynchronize();
-    free_list(c->batch_allocs);
+    sync_ctx(c);                                          // only this context's streams: another context may be running
     c->have_batch = false; c->ran = false;
     VcBatchDev& b = c->b;
     b = VcBatchDev{};
     b.n_windows = nw;
     uint32_t* d_wso; uint64_t* d_so; uint32_t *d_sb, *d_se; uint8_t *d_hq, *d_ba, *d_qu, *d_wf;
     int rc;
-    if ((rc = dalloc(c, c->batch_allocs, &d_wso, nw + 1)) || (rc = dalloc(c, c->batch_allocs, &d_so, nseq + 1)) ||
-        (rc = dalloc(c, c->batch_allocs, &d_sb, nseq)) || (rc = dalloc(c, c->batch_allocs, &d_se, nseq)) ||
-        (rc = dalloc(c, c->batch_allocs, &d_hq, nseq)) || (rc = dalloc(c, c->batch_allocs, &d_ba, nbytes + 16)) ||
-        (rc = dalloc(c, c->batch_allocs, &d_qu, nbytes + 16)) || (rc = dalloc(c, c->batch_allocs, &d_wf, nw)) ||
-        (rc = dalloc(c, c->batch_allocs, &b.win_avg, nw)) || (rc = dalloc(c, c->batch_allocs, &b.status, nw)) ||
-        (rc = dalloc(c, c->batch_allocs, &b.cons_len, nw)) || (rc = dalloc(c, c->batch_allocs, &b.errinfo, nw)))
+    if ((rc = salloc(c, 0, &d_wso, nw + 1)) || (rc = salloc(c, 1, &d_so, nseq + 1)) ||
+        (rc = salloc(c, 2, &d_sb, nseq)) || (rc = salloc(c, 3, &d_se, nseq)) ||
+        (rc = salloc(c, 4, &d_hq, nseq)) || (rc = salloc(c, 5, &d_ba, nbytes + 16)) ||
+        (rc = salloc(c, 6, &d_qu, nbytes + 16)) || (rc = salloc(c, 7, &d_wf, nw)) ||
+        (rc = salloc(c, 8, &b.win_avg, nw)) || (rc = salloc(c, 9, &b.status, nw)) ||
+        (rc = salloc(c, 10, &b.cons_len, nw)) || (rc = salloc(c, 11, &b.errinfo, nw)))
         return rc;
     HIPCHK(c, hipMemcpyAsync(d_wso, hb->win_seq_off, (nw + 1) * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_so, hb->seq_off, (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
@@ -651,6 +678,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     // chunk size from the scratch budget (split over the streams)
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+    free_b += c->chunk_bytes;            // our own workspaces are reusable: the plan must not depend on whether they exist yet
     const uint32_t S = c->n_streams;
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6)) / S;
     const uint64_t rowd = 64ull * (cpl / 2);
@@ -671,15 +699,20 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
                       c->group_max == group_max && c->max_nseq == max_nseq && !c->chunk_allocs.empty();
     if (!same) {
         free_list(c->chunk_allocs);
+        c->chunk_bytes = 0;
         c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
         c->big_ws_stride = big;
         c->jobs_cap = CW * group_max;
         c->hmat_dwords = (uint64_t)c->jobs_cap * NC * rowd;
+        size_t f0 = 0, f1 = 0, tt = 0;
+        (void)hipMemGetInfo(&f0, &tt);
         for (uint32_t s = 0; s < S; ++s)
             if ((rc = alloc_work(c, &c->works[s]))) return rc;
+        (void)hipMemGetInfo(&f1, &tt);
+        c->chunk_bytes = f0 > f1 ? f0 - f1 : 0;
     }
     b.cons_cap = NC;
-    if ((rc = dalloc(c, c->batch_allocs, &b.cons, (size_t)nw * b.cons_cap))) return rc;
+    if ((rc = salloc(c, 12, &b.cons, (size_t)nw * b.cons_cap))) return rc;
     HIPCHK(c, hipMemsetAsync(b.status, 0, nw, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, nw * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -819,14 +852,12 @@ int vc_collect(vc_ctx* c, vc_result* r) {
                     (unsigned long long)c->total_cons, (unsigned long long)r->cons_cap);
     const uint32_t nw = c->b.n_windows;
     uint8_t* d_out = nullptr; uint64_t* d_off = nullptr;
-    std::vector<void*> tmp;
-    if ((rc = dalloc(c, tmp, &d_out, c->total_cons + 16)) || (rc = dalloc(c, tmp, &d_off, nw + 1))) { free_list(tmp); return rc; }
+    if ((rc = salloc(c, 13, &d_out, c->total_cons + 16)) || (rc = salloc(c, 14, &d_off, (size_t)nw + 1))) return rc;
     rc = vc_collect_device(c, d_out, c->total_cons + 16, d_off, nullptr);
     if (rc == VC_OK) {
         hipError_t e = hipMemcpy(r->cons, d_out, c->total_cons, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(c, VC_ERR_HIP, "D2H of consensus failed: %s", hipGetErrorString(e));
     }
-    free_list(tmp);
     if (rc) return rc;
     r->cons_off[0] = 0;
     for (uint32_t w = 0; w < nw; ++w) {
