@@ -75,12 +75,16 @@ def test_cigars_are_optimal_global_alignments(built):
         assert cigar_cost(cg, q, t) == d, (len(q), len(t), cg[:60])
 
 
-def test_paf_without_cigar_end_to_end(built, tmp_path, capsys):
+@pytest.mark.parametrize("dist_path", [False, True])
+def test_paf_without_cigar_end_to_end(built, tmp_path, capsys, monkeypatch, dist_path):
     """The VeChat driver's own input shape: PAF from minimap2 without cg tags.  The command line aligns the
     overlaps on the device first; the corrected reads must come out polished and close to the truth."""
     import fixtures
     from test_seqio import write_inputs
     from vechat_amd import polish
+    if dist_path:                                   # one-process-per-GPU path (sharded alignment, RCCL exchange), single rank
+        monkeypatch.setenv("VC_FORCE_DIST", "1")
+        monkeypatch.setenv("MASTER_PORT", "29549")
     fx, wb = fixtures.load_plumbing()
     wb.close()
     rp, op, tp = write_inputs(fx, tmp_path, sam=False)

@@ -55,6 +55,9 @@ def _worker(rank, world, port, n, q):
         q.put((c.numpy().tobytes() == blob.tobytes(), l.numpy().tolist() == lens_all.tolist()))
     else:
         assert c is None and l is None
+    # dst=None: every rank ends up with everything (used to share device-aligned CIGAR strings)
+    c2, l2 = gather_consensus(cons, lens, dst=None)
+    assert c2.numpy().tobytes() == blob.tobytes() and l2.numpy().tolist() == lens_all.tolist()
     dist.barrier()
     dist.destroy_process_group()
 

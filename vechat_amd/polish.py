@@ -34,21 +34,14 @@ def main(argv=None):
     a = ap.parse_args(argv)
 
     wb = WindowBuilder(a.window_length, a.quality_threshold)
-    targets, reads, overlaps = read_sequences(a.targets), read_sequences(a.sequences), read_overlaps(a.overlaps)
-    n_aligned = align_missing(targets, reads, overlaps, a.error_threshold, a.device)     # PAF without cg:Z: (overlap.cpp:205-220)
-    kept, window_type = load_polisher_input(wb, targets, reads, overlaps, a.error_threshold)
-    batch, ids = wb.build()
-    # one process per GPU when launched through torch.distributed.run: every rank reads the inputs, takes a contiguous
-    # cost-balanced range of windows and rank 0 gathers the results over RCCL and writes the output
+    # one process per GPU when launched through torch.distributed.run: every rank reads the inputs, aligns its share of
+    # the CIGAR-less overlaps, takes a contiguous cost-balanced range of windows; rank 0 gathers the results
+    # over RCCL and writes the output
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     distributed = world > 1 or os.environ.get("VC_FORCE_DIST") == "1"
     device = int(os.environ.get("LOCAL_RANK", a.device)) if distributed else a.device
-    ctx = HipContext(device=device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
-                     num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
-                     window_type=window_type)
-    if not distributed:
-        cons, status = ctx.consensus(batch)
-    else:
+    shard = None
+    if distributed:
         import numpy as np
         import torch
         import torch.distributed as dist
@@ -56,9 +49,29 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
         dev = torch.device("cuda", device)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+        def exchange(items):              # list of bytes per rank -> everybody's, in rank order
+            payload = torch.from_numpy(np.frombuffer(b"".join(items) + b"\0", dtype=np.uint8).copy()[:-1]).to(dev)
+            lens = torch.tensor([len(x) for x in items], dtype=torch.int64, device=dev)
+            call, lall = gather_consensus(payload, lens, dst=None, force=True)
+            blob, lall = call.cpu().numpy().tobytes(), lall.cpu().numpy()
+            off = np.concatenate([[0], np.cumsum(lall)])
+            return [blob[int(off[k]):int(off[k + 1])] for k in range(len(lall))]
+        shard = (rank, world, exchange)
+
+    targets, reads, overlaps = read_sequences(a.targets), read_sequences(a.sequences), read_overlaps(a.overlaps)
+    n_aligned = align_missing(targets, reads, overlaps, a.error_threshold, device, shard)     # PAF / MHAP without a CIGAR (overlap.cpp:205-220)
+    kept, window_type = load_polisher_input(wb, targets, reads, overlaps, a.error_threshold)
+    batch, ids = wb.build()
+    ctx = HipContext(device=device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
+                     num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
+                     window_type=window_type)
+    if not distributed:
+        cons, status = ctx.consensus(batch)
+    else:
         lo, hi = shard_range_balanced(estimated_cells(batch), rank, world)
         lc, ls = ctx.consensus(batch.slice(lo, hi)) if hi > lo else ([], np.zeros(0, np.uint8))
-        payload = torch.from_numpy(np.frombuffer(b"".join(lc), dtype=np.uint8).copy()).to(dev)
+        payload = torch.from_numpy(np.frombuffer(b"".join(lc) + b"\0", dtype=np.uint8).copy()[:-1]).to(dev)
         # length and status of a window travel together: status in the bits above 40
         lens = torch.tensor([len(x) | (int(s) << 40) for x, s in zip(lc, ls)], dtype=torch.int64, device=dev)
         call, lall = gather_consensus(payload, lens, dst=0, force=True)

@@ -157,27 +157,38 @@ def _resolve_indices(targets, reads, overlaps):
             o.t_name = targets[int(o.t_name[1:])][0]
 
 
-def align_missing(targets, reads, overlaps, error_threshold=0.3, device=0):
+def align_missing(targets, reads, overlaps, error_threshold=0.3, device=0, shard=None):
     """Give every overlap without a CIGAR one (overlap.cpp:179-203: the aligned pieces are q[q_begin:q_end], reverse
-    complemented for strand '-', and t[t_begin:t_end]).  Overlaps that load_polisher_input would drop are skipped."""
+    complemented for strand '-', and t[t_begin:t_end]).  Overlaps that load_polisher_input would drop are skipped.
+    shard=(rank, world, exchange): this rank aligns its contiguous share and `exchange(list of bytes)` returns
+    everybody's results in order (one process per GPU)."""
     from .align import align_pairs
+    _resolve_indices(targets, reads, overlaps)
     seq = {n: d for n, d, _ in reads}
     tgt = {n: d for n, d, _ in targets}
-    _resolve_indices(targets, reads, overlaps)
     todo = [o for o in overlaps if o.cigar is None and o.q_name in seq and o.t_name in tgt and o.error <= error_threshold
             and o.q_name != o.t_name]
+    lo, hi = 0, len(todo)
+    if shard is not None:
+        base, rem = divmod(len(todo), shard[1])
+        lo = shard[0] * base + min(shard[0], rem)
+        hi = lo + base + (1 if shard[0] < rem else 0)
     pairs = []
-    for o in todo:
+    for o in todo[lo:hi]:
         q = seq[o.q_name][o.q_begin:o.q_end]
         pairs.append((q.translate(_COMP)[::-1] if o.strand else q, tgt[o.t_name][o.t_begin:o.t_end]))
     cigars, dist = align_pairs(pairs, device=device)
-    for o, cg, d in zip(todo, cigars, dist):
-        if d < 0:                         # beyond the aligner's envelope: drop the overlap rather than guess
+    mine = [(cg if d >= 0 else "!").encode() for cg, d in zip(cigars, dist)]            # "!": beyond the aligner's envelope
+    everyone = mine if shard is None else shard[2](mine)
+    n_ok = 0
+    for o, cg in zip(todo, everyone):
+        if cg == b"!":                    # drop the overlap rather than guess
             o.error = 2.0
             o.cigar = ""
         else:
-            o.cigar = cg
-    return sum(1 for d in dist if d >= 0)
+            o.cigar = cg.decode()
+            n_ok += 1
+    return n_ok
 
 
 def load_polisher_input(builder, targets, reads, overlaps, error_threshold=0.3):

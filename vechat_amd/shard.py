@@ -46,7 +46,7 @@ def shard_range_balanced(cost, rank: int, world: int):
 
 def gather_consensus(cons: torch.Tensor, lens: torch.Tensor, dst: int = 0, force: bool = False):
     """cons: uint8 [sum(lens)] consensus bytes of this rank's windows, lens: int64 [n_local].
-    Returns (cons_all, lens_all) on rank `dst` (window order), (None, None) elsewhere.
+    Returns (cons_all, lens_all) on rank `dst` (window order), (None, None) elsewhere; dst=None: on every rank.
     Two collectives: all_gather of (n_windows, n_bytes), then an all_gather of payloads padded to
     the largest shard (one large message per peer link; no ring dependency on payload size)."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
@@ -66,7 +66,7 @@ def gather_consensus(cons: torch.Tensor, lens: torch.Tensor, dst: int = 0, force
     all_c = [torch.empty_like(pc) for _ in range(world)]
     dist.all_gather(all_l, pl)
     dist.all_gather(all_c, pc)
-    if rank != dst:
+    if dst is not None and rank != dst:
         return None, None
     lens_all = torch.cat([all_l[r][:int(metas[r, 0])] for r in range(world)])
     cons_all = torch.cat([all_c[r][:int(metas[r, 1])] for r in range(world)])
