@@ -168,3 +168,45 @@ def spoa_align_probe(lib, prefix, seqs, quals, build_type, m, n_, g, query, quer
     if rc != 0:
         raise RuntimeError(f"{prefix}_spoa_align_probe rc={rc}")
     return list(pairs[:2 * npairs.value]), list(rank[:nnodes.value])
+
+
+def have_adapter():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libvcadapter.so"))
+
+
+def adapter_run(batch: Batch, params: VcParams):
+    """oracle/ref_adapter.cpp: the reference's own racon::Window objects, once through Window::generate_consensus on the CPU
+    and once through a racon::CUDABatchProcessor-named batch class backed by libvechat_hip.so.  -> number of differing windows."""
+    lib = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libvcadapter.so"))
+    lib.vcadapter_run.restype = C.c_int
+    nw = batch.n_windows
+    bbs, bqs, bls, off, seqs, lens, quals, begins, ends = [], [], [], [0], [], [], [], [], []
+    for w in range(nw):
+        s, q, b, e = batch.window(w)
+        s0 = int(batch.win_seq_off[w])
+        n = len(s)
+        orig = [int(x) for x in batch.seq_orig[s0:s0 + n]] if batch.seq_orig is not None else list(range(n))
+        inv = [0] * n
+        for k, o in enumerate(orig):
+            inv[o] = k
+        L = len(s[0])
+        bq = q[0]
+        if not batch.win_fasta[w] and bq == b"!" * L:
+            bq = bq + b"!" * 8                       # short last window of a FASTA target: the shared dummy string is longer than L
+        bbs.append(s[0]); bqs.append(bq); bls.append(L)
+        for i in range(1, n):
+            k = inv[i]
+            seqs.append(s[k]); lens.append(len(s[k])); quals.append(q[k]); begins.append(b[k]); ends.append(e[k])
+        off.append(len(seqs))
+    nl = max(len(seqs), 1)
+    CP = C.c_char_p
+    err = C.create_string_buffer(512)
+    rc = lib.vcadapter_run(C.c_uint32(nw), (CP * nw)(*bbs), (C.c_uint32 * nw)(*bls), (CP * nw)(*bqs),
+                           (C.c_uint32 * (nw + 1))(*off), (CP * nl)(*seqs), (C.c_uint32 * nl)(*lens), (CP * nl)(*quals),
+                           (C.c_uint32 * nl)(*begins), (C.c_uint32 * nl)(*ends), C.c_int(params.mode), C.c_int(params.trim),
+                           C.c_int(params.match), C.c_int(params.mismatch), C.c_int(params.gap),
+                           C.c_double(params.min_confidence), C.c_double(params.min_support), C.c_uint32(params.num_prune),
+                           err, C.c_uint32(512))
+    if rc < 0:
+        raise RuntimeError(f"vcadapter_run: {err.value.decode()}")
+    return rc

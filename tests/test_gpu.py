@@ -119,6 +119,24 @@ def test_command_line_distributed_path(built, tmp_path, capsys, monkeypatch):
     assert [[out[i][1:], out[i + 1]] for i in range(0, len(out), 2)] == fx["expected"]["hap"]["stitched"]
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_reference_windows_through_the_compiled_adapter(built, mode):
+    """The drop-in boundary compiled against the reference's own headers (oracle/ref_adapter.cpp): real racon::Window
+    objects filled by createWindow / add_layer, Window::generate_consensus on the CPU vs a racon::CUDABatchProcessor-named
+    batch class over libvechat_hip.so.  Built only where /root/reference exists; travels to the GPU box prebuilt."""
+    if not oa.have_adapter():
+        pytest.skip("oracle/_ref/libvcadapter.so not built (no reference tree at build time)")
+    p = capi.default_params(mode=mode)
+    gold = fixtures.fixture_batch(fixtures.load_windows()["windows"])
+    assert oa.adapter_run(gold, p) == 0
+    synth = capi.synth_batch(capi.synth_cfg(77, 400, 24, n_haplotypes=2, snp_rate=0.02, frac_partial=0.25), 0, 12)
+    assert oa.adapter_run(synth, p) == 0
+    fx, wb = fixtures.load_plumbing()
+    batch, _ = wb.build()
+    wb.close()
+    assert oa.adapter_run(batch, p) == 0
+
+
 def test_thread_per_alignment_backtrack_agrees(built, monkeypatch):
     """The simple one-thread-per-alignment backtrack (kept as a cross-check of the cooperative k_tracew)."""
     monkeypatch.setenv("VC_TRACE_THREAD", "1")
