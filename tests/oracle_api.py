@@ -210,3 +210,27 @@ def adapter_run(batch: Batch, params: VcParams):
     if rc < 0:
         raise RuntimeError(f"vcadapter_run: {err.value.decode()}")
     return rc
+
+
+def have_seqparse():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libvcseq.so"))
+
+
+def ref_parse_sequences(path, fastq):
+    """oracle/ref_seqparse.cpp: the reference's bioparser + racon::Sequence on a file
+    -> [(name, data, quality|None, reverse complement, reverse quality|None)]"""
+    lib = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libvcseq.so"))
+    lib.vcref_parse_sequences.restype = C.c_long
+    lib.vcref_parse_sequences.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_long]
+    need = lib.vcref_parse_sequences(str(path).encode(), int(fastq), None, 0)
+    if need < 0:
+        raise RuntimeError("reference parser threw")
+    buf = C.create_string_buffer(need + 1)
+    lib.vcref_parse_sequences(str(path).encode(), int(fastq), buf, need)
+    out = []
+    for ln in buf.raw[:need].split(b"\n"):
+        if not ln:
+            continue
+        name, data, q, rc, rq = ln.split(b"\t")
+        out.append((name.decode(), data, None if q == b"*" else q, rc, None if rq == b"*" else rq))
+    return out

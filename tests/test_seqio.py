@@ -83,3 +83,49 @@ def test_filters(built, tmp_path):
     with pytest.raises(ValueError):
         seqio.load_polisher_input(wb, t, r, o)
     wb.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_sequence_ingest_matches_the_reference_parser(tmp_path, seed):
+    """read_sequences against the reference's own ingest (its vendored bioparser feeding racon::Sequence, compiled in
+    place by oracle/Makefile `seqparse`): names, upper-casing, dropped all-'!' quality, multi-line FASTA, .gz, IUPAC and
+    other symbols; and the reverse complement / reverse quality rule (src/sequence.cpp:50-83) the window builder restates."""
+    import random
+
+    import oracle_api as oa
+    import windows_ref
+
+    if not oa.have_seqparse():
+        pytest.skip("oracle/_ref/libvcseq.so not built (needs /root/reference)")
+    rng = random.Random(seed)
+
+    def rs(n, alpha="ACGTacgtNnRYKMSWBDHVUu-*."):
+        return "".join(rng.choice(alpha) for _ in range(n))
+
+    fa = ""
+    for i in range(12):
+        body = rs(rng.choice([1, 5, 70, 71, 500, 3000]))
+        width = rng.choice([len(body), 60, 70])
+        fa += f">t{i}" + rng.choice(["", " some description", "\ttabbed text"]) + "\n"
+        fa += "".join(body[k:k + width] + "\n" for k in range(0, len(body), width))
+    fq = ""
+    for i in range(12):
+        n = rng.choice([1, 2, 150, 2000])
+        q = "!" * n if i % 4 == 2 else "".join(chr(33 + rng.randint(0, 60)) for _ in range(n))
+        fq += f"@q{i}" + rng.choice(["", " len=%d" % n]) + f"\n{rs(n)}\n+\n{q}\n"
+    files = []
+    for name, text, is_fq in (("a.fasta", fa, 0), ("a.fastq", fq, 1)):
+        p = tmp_path / name
+        p.write_text(text)
+        pz = tmp_path / (name + ".gz")
+        with gzip.open(pz, "wt") as f:
+            f.write(text)
+        files += [(p, is_fq), (pz, is_fq)]
+    for p, is_fq in files:
+        ref = oa.ref_parse_sequences(p, is_fq)
+        mine = seqio.read_sequences(p)
+        assert len(ref) == len(mine) == 12
+        for (rn, rd, rq, rrc, rrq), (n, d, q) in zip(ref, mine):
+            assert (rn, rd, rq) == (n, d, q)
+            assert rrc == windows_ref.revcomp(d)
+            assert rrq == (q[::-1] if q is not None else None)

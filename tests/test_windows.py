@@ -22,7 +22,7 @@ def _rank(host):
     return f
 
 
-def _mutate(rng, s, rate):
+def _mutate(rng, s, rate, alpha=b"ACGT"):
     """-> (read bytes, cigar of read vs s)"""
     out, ops = bytearray(), []
     for c in s:
@@ -30,9 +30,9 @@ def _mutate(rng, s, rate):
         if r < rate * 0.3:
             ops.append("D")
         elif r < rate * 0.7:
-            out.append(rng.choice(b"ACGT")); out.append(c); ops.append("I"); ops.append("M")
+            out.append(rng.choice(alpha)); out.append(c); ops.append("I"); ops.append("M")
         else:
-            out.append(rng.choice(b"ACGT") if r < rate else c); ops.append("M")
+            out.append(rng.choice(alpha) if r < rate else c); ops.append("M")
     cig, run = "", 1
     for a, b in zip(ops, ops[1:] + ["$"]):
         if a == b:
@@ -44,6 +44,7 @@ def _mutate(rng, s, rate):
 
 def _case(seed, W, fastq_targets, fastq_reads):
     rng = random.Random(seed)
+    flank = b"ACGTNRYKMSW" if seed % 3 == 1 else b"ACGT"      # symbols the reverse complement leaves as they are
     seqs, ovl = [], []
     nt = rng.randint(1, 3)
     for t in range(nt):
@@ -57,13 +58,13 @@ def _case(seed, W, fastq_targets, fastq_reads):
         t = rng.randrange(nt)
         td = seqs[t][1]
         tb = rng.randrange(0, max(1, len(td) - 5)); te = rng.randint(tb + 1, len(td))
-        piece, cig = _mutate(rng, td[tb:te], 0.15)
+        piece, cig = _mutate(rng, td[tb:te], 0.15, flank)
         while cig and cig[-1] == "D" or (cig and cig.split("M")[0].endswith("D")):   # keep the record simple: start/end on M or I
             break
         if not piece:
             continue
         pre, post = rng.randint(0, 20), rng.randint(0, 20)
-        fwd = bytes(rng.choice(b"ACGT") for _ in range(pre)) + piece + bytes(rng.choice(b"ACGT") for _ in range(post))
+        fwd = bytes(rng.choice(flank) for _ in range(pre)) + piece + bytes(rng.choice(flank) for _ in range(post))
         strand = rng.random() < 0.5
         data = wr.revcomp(fwd) if strand else fwd
         ql = len(data)

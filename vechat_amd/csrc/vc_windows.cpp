@@ -2,9 +2,10 @@
 // overlaps of a racon-style polisher and the batch of windows the device path consumes, and between the
 // per-window results and the corrected sequences.  No device code; built into libvechat_hip.so and
 // libvechat_host.so.  The reference's own implementation of this layer (src/polisher.cpp, src/overlap.cpp)
-// cannot be compiled here (thread_pool / edlib / bioparser are fetched at configure time), so parity of this
+// cannot be compiled here (thread_pool / edlib are fetched at configure time), so parity of this
 // file is UNPINNED: it is a restatement, cross-checked against an independent Python restatement in
-// tests/test_windows.py.
+// tests/test_windows.py (whose reverse complement rule is itself checked against the reference's
+// racon::Sequence, tests/test_seqio.py).
 //
 //   vc_wb_add_overlap + breaking points  <- src/overlap.cpp:222-292  (find_breaking_points_from_cigar)
 //   vc_wb_build                          <- src/polisher.cpp:389-462 (windows, layer filters, add_layer)

@@ -10,7 +10,9 @@ bioparser and its Sequence / Overlap constructors:
   read_mhap       <- src/overlap.cpp:14-27  (MHAP constructor: 1-based file positions, strand = a_rc ^ b_rc); no CIGAR
   load_polisher_input <- src/polisher.cpp:207-352 (reads that are also targets share one record, self-overlaps
                      and overlaps above the error threshold are dropped, window type from the mean read length)
-Parity unpinned: plain restatements, exercised by tests/test_seqio.py.
+read_sequences is pinned against the reference's own bioparser + racon::Sequence (oracle/ref_seqparse.cpp, built in
+place; tests/test_seqio.py).  The overlap readers are unpinned restatements (src/overlap.cpp needs edlib.h, which is
+not in the tree).
 """
 import gzip
 import re
