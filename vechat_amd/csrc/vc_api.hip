@@ -34,6 +34,7 @@ const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace"
 
 constexpr int kRing = 8;      // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
 constexpr int kMaxStreams = 4;
+constexpr uint32_t kTraceTabRows = 8188;           // rows covered by k_tracew's first-in-edge table (4 tables x 2 B x 8192 = 64 KB); later rows are walked without speculation
 constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may ask for (160 KB per CU minus room for static __shared__)
 constexpr uint64_t kMaxColumns = 2048;     // longest sequence k_fwd takes (64 lanes x 32 columns)
 constexpr uint32_t kResolveGrid = 128;   // workgroups of k_resolve (each owns one DFS workspace in HBM)
@@ -89,7 +90,7 @@ struct vc_ctx {
     std::vector<uint32_t> h_cons_len;
     std::vector<uint8_t> h_status;
     uint32_t* d_lut_w = nullptr; double* d_lut_d = nullptr;
-    unsigned long long* d_stat = nullptr;   // [8] cells, rows, -, far-row reads, trace steps, speculated steps, rounds, -
+    unsigned long long* d_stat = nullptr;   // [VC_STAT_SLOTS][8] cells, rows, -, far-row reads, trace steps, speculated steps, rounds, -
 
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
@@ -382,7 +383,7 @@ struct Plan {
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
         { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = NC; hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(NC, false), wk.stream, ta); }
+          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = std::min(NC, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(ta.tab_rows, false), wk.stream, ta); }
           else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
@@ -446,7 +447,7 @@ struct Plan {
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
             { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = maxn; hipLaunchKernelGGL(k_tracew, dim3((ns * gsz + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(maxn, ta.shared_table != 0), wk.stream, ta); }
+          if (c->trace_wave) { ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = std::min(maxn, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns * gsz + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0), wk.stream, ta); }
           else hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         }
         VcAddwArgs wa{};
@@ -482,7 +483,7 @@ struct Plan {
         ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
         { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = NC; hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(NC, false), wk.stream, ta); }
+          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = std::min(NC, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(ta.tab_rows, false), wk.stream, ta); }
           else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcFinishArgs fn{};
         fn.b = c->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;
@@ -544,7 +545,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     uint32_t lw[256]; double ld[256];
     vc_weight_lut(lw);
     for (int ch = 0; ch < 256; ++ch) ld[ch] = 1 - pow(10, (33 - (int)(signed char)ch) / 10.0);
-    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, 8)) {
+    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, 8 * VC_STAT_SLOTS)) {
         g_create_error = c->err; vc_destroy(c); return VC_ERR_HIP;
     }
     (void)hipMemcpy(c->d_lut_w, lw, sizeof(lw), hipMemcpyHostToDevice);
@@ -739,7 +740,7 @@ int vc_run(vc_ctx* c) {
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
     if (c->prm.mode == 1)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.cons_lds, kLdsCap)));
-    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64 * VC_STAT_SLOTS, c->stream));
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
     if (!c->h_pre_status.empty()) HIPCHK(c, hipMemcpyAsync(b.status, c->h_pre_status.data(), b.n_windows, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
@@ -877,8 +878,9 @@ int vc_debug_errinfo(vc_ctx* c, uint32_t* out) {
 int vc_get_stats(vc_ctx* c, vc_stats* s) {
     if (!c || !s) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIPCHK(c, hipMemcpy(st, c->d_stat, 64, hipMemcpyDeviceToHost));
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, raw[8 * VC_STAT_SLOTS];
+    HIPCHK(c, hipMemcpy(raw, c->d_stat, sizeof(raw), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8 * VC_STAT_SLOTS; ++i) st[i % 8] += raw[i];
     c->stats.cells = st[0]; c->stats.dp_rows = st[1];
     c->stats.far_row_reads = st[3];
     c->stats.trace_steps = st[4]; c->stats.trace_spec = st[5]; c->stats.trace_rounds = st[6];

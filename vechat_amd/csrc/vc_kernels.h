@@ -959,6 +959,10 @@ __device__ __forceinline__ int pk_hi(uint32_t a) { return (int)a >> 16; }
 // T_c = anchor + ((byte_c - anchor) & 0xFF).  That is CPL+2 bytes per lane per row instead of 2*CPL, and
 // packing costs one v_perm_b32 per four cells.  Other score sets keep raw packed int16 pairs.
 __host__ __device__ constexpr int vc_nds(int cpl) { return (cpl + 2 + 3) / 4; }
+// work counters: VC_STAT_SLOTS sets of 8, picked by block, summed by vc_get_stats
+#define VC_STAT_SLOTS 64
+__device__ __forceinline__ unsigned long long* vc_stat_slot(unsigned long long* stat) { return stat + (blockIdx.x % VC_STAT_SLOTS) * 8; }
+
 __host__ __device__ inline bool vc_row_packed(int m, int n, int g, int cpl) {
     return g < 0 && (cpl - 1) * ((m > n ? m : n) - 2 * g) <= 255;
 }
@@ -1047,8 +1051,9 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     }
     if (lane == 0) {
         a.job_type[job] = nw ? 1 : 0;
-        atomicAdd(a.stat + 0, (unsigned long long)nrows * len);
-        atomicAdd(a.stat + 1, (unsigned long long)nrows);
+        unsigned long long* st = vc_stat_slot(a.stat);
+        atomicAdd(st + 0, (unsigned long long)nrows * len);
+        atomicAdd(st + 1, (unsigned long long)nrows);
     }
 
     // tilted match/mismatch profile (score - g) of my columns for the four usual bases (packed pairs);
@@ -1298,7 +1303,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
       if ((uint32_t)lane < cnt) c0p_out[i0 - 1 + lane] = (int16_t)c0vec;   // column 0 of the block just completed
       __threadfence_block();
     }
-    if (lane == 0 && far_reads) atomicAdd(a.stat + 3, (unsigned long long)far_reads);
+    if (lane == 0 && far_reads) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
 
     // publish the end cell
     uint32_t end = 0;
@@ -1398,7 +1403,7 @@ struct VcTraceArgs {
     uint32_t PC;
     uint32_t pair_group, pair_k0;   // pairs index = slot*pair_group + (k - pair_k0)
     uint32_t k0;
-    unsigned long long* stat;   // [8], see vc_ctx::d_stat
+    unsigned long long* stat;   // [VC_STAT_SLOTS][8], see vc_ctx::d_stat
     int shared_table;           // k_tracew: the VC_TG alignments of a wave share a window (group % VC_TG == 0)
     uint32_t tab_rows;          // k_tracew: rows the LDS table is sized for (>= every graph's height in this launch)
 };
@@ -1522,7 +1527,8 @@ __global__ void k_trace(VcTraceArgs a) {
 // ------------------------------------------------------------------------------------------------
 #define VC_TG 4
 #define VC_TL 16
-__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table) { return (shared_table ? 1u : (uint32_t)VC_TG) * ((max_rows + 2 + 3) & ~3u); }
+__host__ __device__ inline uint32_t vc_tracew_tab_len(uint32_t max_rows) { return (max_rows + 2 + 3) & ~3u; }     // entries per table
+__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table) { return (shared_table ? 1u : (uint32_t)VC_TG) * vc_tracew_tab_len(max_rows) * 2u; }
 __device__ __forceinline__ int vc_row_shr1(int v, int first) {          // value of the lane to the left inside a 16-lane row
     return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false);
 }
@@ -1535,7 +1541,10 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     // first in-edge distance of row r (0: do not speculate).  In the re-alignment rounds the alignments of a
     // wave belong to one window (group % VC_TG == 0) and share one table: a quarter of the LDS, more waves
     const bool shared_tab = a.shared_table != 0;
-    uint8_t* tab = smem + (shared_tab ? 0u : grp) * ((a.tab_rows + 2 + 3) & ~3u);
+    // entry of row r: low byte = distance to the first in-edge's row, high byte = that row's own distance -- two links
+    // of the chain per LDS access (0: stop)
+    uint16_t* tab = reinterpret_cast<uint16_t*>(smem) + (shared_tab ? 0u : grp) * vc_tracew_tab_len(a.tab_rows);
+    uint8_t* tab8 = reinterpret_cast<uint8_t*>(tab);
     const uint32_t njobs = a.nslots * a.group;
     const uint32_t job = blockIdx.x * VC_TG + grp;
     bool valid = job < njobs;
@@ -1586,13 +1595,23 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         for (uint32_t r = lane; r < nr; r += 64) {
             const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nbs + r]);
             const uint32_t d0 = q.y & 0xFFFF;
-            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint8_t)0 : (uint8_t)d0;
+            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint16_t)0 : (uint16_t)d0;
+        }
+        __syncthreads();
+        for (uint32_t r = 1 + lane; r <= nr; r += 64) {                 // second link: byte reads, byte writes, no overlap
+            const uint32_t d1 = tab8[2 * r];
+            tab8[2 * r + 1] = (d1 && r > d1) ? tab8[2 * (r - d1)] : (uint8_t)0;
         }
     } else {
         for (uint32_t r = gl; walking && r < nrows; r += VC_TL) {
             const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + r]);
             const uint32_t d0 = q.y & 0xFFFF;
-            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint8_t)0 : (uint8_t)d0;
+            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint16_t)0 : (uint16_t)d0;
+        }
+        __syncthreads();
+        for (uint32_t r = 1 + gl; walking && r <= nrows; r += VC_TL) {
+            const uint32_t d1 = tab8[2 * r];
+            tab8[2 * r + 1] = (d1 && r > d1) ? tab8[2 * (r - d1)] : (uint8_t)0;
         }
     }
     __syncthreads();
@@ -1612,17 +1631,24 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         {
             uint32_t ci = gi;
             bool can = walking && gi != 0 && gj != 0;
-#pragma unroll 1
-            for (uint32_t t = 0; t < VC_TL; ++t) {
+#pragma unroll
+            for (uint32_t t = 0; t < VC_TL; t += 2) {                    // two links of the chain per LDS access
                 can = can && ci != 0 && gj > t;
-                const uint32_t d = (can && ci <= a.tab_rows) ? (uint32_t)tab[ci] : 0u;
-                can = can && d != 0;
-                if (!__any(can)) break;
+                const uint32_t e = (can && ci <= a.tab_rows) ? (uint32_t)tab[ci] : 0u;
+                const uint32_t d1 = e & 0xFFu, d2 = e >> 8;
+                can = can && d1 != 0;
+                const uint32_t c1 = ci - d1;
+                const bool can2 = can && c1 != 0 && gj > t + 1 && d2 != 0;
                 if (can) {
-                    if (gl == t) { my_i = ci; my_in = ci - d; }
-                    ci -= d;
+                    if (gl == t) { my_i = ci; my_in = c1; }
                     nspec = t + 1;
                 }
+                if (can2) {
+                    if (gl == t + 1) { my_i = c1; my_in = c1 - d2; }
+                    nspec = t + 2;
+                }
+                ci = c1 - d2;
+                can = can2;
             }
         }
         // ---- B: one round trip for all speculated diagonal cells and the records behind them
@@ -1659,12 +1685,12 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
             if (f) {
                 gnout += f; nspec_ok += f;
                 gi = ni; gT = nT; grec = ni ? nr : zero4; gj -= f;
-                cont = f == VC_TL;                                        // everything confirmed: speculate again
+                cont = f == VC_TL;                                       // everything confirmed: speculate again
                 if (!cont && (nw ? (gi == 0 && gj == 0) : (gT == -(int)gj * g))) walking = false;
             }
         }
-        // ---- D: one general step at (gi, gj) for the groups that stopped short
         const bool need = walking && !cont;
+        // ---- D: one general step at (gi, gj) for the groups that stopped short
         if (__any(need)) {
             uint32_t pi_ = 0, pj_ = 0;
             int hv = 0;
@@ -1727,9 +1753,15 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         if (gbroken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, gi); gnout = 0; }
         if (govf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, gnout); gnout = 0; }
         a.npairs[pj] = gnout;
-        atomicAdd(a.stat + 4, (unsigned long long)gnout);
-        atomicAdd(a.stat + 5, (unsigned long long)nspec_ok);
-        atomicAdd(a.stat + 6, (unsigned long long)nrounds);
+    }
+    {   // statistics: summed over the wave first, then one of VC_STAT_SLOTS counter sets (a single set serialises in the L2)
+        uint32_t s0 = (valid && gl == 0) ? gnout : 0u, s1 = (valid && gl == 0) ? nspec_ok : 0u, s2 = (valid && gl == 0) ? nrounds : 0u;
+#pragma unroll
+        for (int o = VC_TL; o < 64; o <<= 1) { s0 += (uint32_t)__shfl_xor((int)s0, o, 64); s1 += (uint32_t)__shfl_xor((int)s1, o, 64); s2 += (uint32_t)__shfl_xor((int)s2, o, 64); }
+        if (lane == 0) {
+            unsigned long long* st = vc_stat_slot(a.stat);
+            atomicAdd(st + 4, (unsigned long long)s0); atomicAdd(st + 5, (unsigned long long)s1); atomicAdd(st + 6, (unsigned long long)s2);
+        }
     }
 }
 
