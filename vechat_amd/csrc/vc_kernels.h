@@ -472,6 +472,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
 // "first sink in rank order" among equal end scores (sisd :353-355) -- is settled by k_resolve,
 // which runs the exact DFS only for the ~1-2 % of alignments that actually tie.
 // ------------------------------------------------------------------------------------------------
+#define VC_ROWS_U 4
 __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                              uint32_t NC, uint32_t EC, int next_layer, uint32_t ring) {
     VC_LATENCY_KERNEL_PRIO();
@@ -491,60 +492,86 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
     int bad = 0, broken = 0;
     uint32_t ovf_base = 0;
-    for (uint32_t r0 = 0; r0 < N; r0 += 64) {
-        const uint32_t r = r0 + lane;
-        const bool act = r < N;
-        const uint32_t v = act ? g.ord[nb + r] : 0;
-        uint32_t np = 0;
-        bool hasprev = false;
-        uint16_t dl[VC_INLINE_PRED];
+    // VC_ROWS_U blocks of 64 rows per iteration: the in-edge lists are chains of dependent loads, and the wave's only
+    // way to have more of them in flight is to walk several rows per lane at once
+    for (uint32_t r0 = 0; r0 < N; r0 += 64 * VC_ROWS_U) {
+        uint32_t rr[VC_ROWS_U], vv[VC_ROWS_U], np_[VC_ROWS_U], ee[VC_ROWS_U], of_[VC_ROWS_U], cd_[VC_ROWS_U];
+        bool act_[VC_ROWS_U], hp_[VC_ROWS_U];
+        uint16_t dl_[VC_ROWS_U][VC_INLINE_PRED];
 #pragma unroll
-        for (int k = 0; k < VC_INLINE_PRED; ++k) dl[k] = 0;
-        if (act) {
-            for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
-                const uint32_t tn = g.e_tn[eb + e];
-                e = tn >> 16;
-                const uint32_t pt = g.pos[nb + (tn & 0xFFFF)];
-                if (pt >= r) broken = 1;                         // the kept order must stay topological
-                const uint32_t delta = r - pt;
+        for (int u = 0; u < VC_ROWS_U; ++u) {
+            rr[u] = r0 + 64 * u + lane;
+            act_[u] = rr[u] < N;
+            vv[u] = act_[u] ? g.ord[nb + rr[u]] : 0;
+            np_[u] = 0; hp_[u] = false;
 #pragma unroll
-                for (int k = 0; k < VC_INLINE_PRED; ++k) if (np == (uint32_t)k) dl[k] = (uint16_t)delta;
-                np++;
-                hasprev |= delta == 1;
-            }
+            for (int k = 0; k < VC_INLINE_PRED; ++k) dl_[u][k] = 0;
         }
-        const bool is_ovf = np > VC_INLINE_PRED;
-        uint32_t tot_ovf;
-        const uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
-        if (act) {
-            if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }
-            if (np > 255) bad = 1;
-            if (is_ovf) {
-                if (my_ovf + np > EC) bad = 1;
-                else {
-                    uint32_t k = 0;
-                    for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
-                        const uint32_t tn = g.e_tn[eb + e];
-                        e = tn >> 16;
-                        const uint32_t delta = r - g.pos[nb + (tn & 0xFFFF)];
-                        dp.ovf[eb + my_ovf + k] = (uint16_t)delta;
-                        k++;
-                    }
+#pragma unroll
+        for (int u = 0; u < VC_ROWS_U; ++u) {
+            ee[u] = act_[u] ? (uint32_t)g.in_first[nb + vv[u]] : (uint32_t)VC_NONE16;
+            of_[u] = act_[u] ? (uint32_t)g.out_first[nb + vv[u]] : 0u;
+            cd_[u] = act_[u] ? (uint32_t)g.code[nb + vv[u]] : 0u;
+        }
+        for (;;) {
+            bool any_ = false;
+#pragma unroll
+            for (int u = 0; u < VC_ROWS_U; ++u) any_ |= ee[u] != VC_NONE16;
+            if (!any_) break;
+            uint32_t tn[VC_ROWS_U], pt[VC_ROWS_U];
+#pragma unroll
+            for (int u = 0; u < VC_ROWS_U; ++u) tn[u] = ee[u] != VC_NONE16 ? g.e_tn[eb + ee[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < VC_ROWS_U; ++u) pt[u] = ee[u] != VC_NONE16 ? (uint32_t)g.pos[nb + (tn[u] & 0xFFFF)] : 0u;
+#pragma unroll
+            for (int u = 0; u < VC_ROWS_U; ++u) {
+                if (ee[u] != VC_NONE16) {
+                    if (pt[u] >= rr[u]) broken = 1;                  // the kept order must stay topological
+                    const uint32_t delta = rr[u] - pt[u];
+#pragma unroll
+                    for (int k = 0; k < VC_INLINE_PRED; ++k) if (np_[u] == (uint32_t)k) dl_[u][k] = (uint16_t)delta;
+                    np_[u]++;
+                    hp_[u] |= delta == 1;
+                    ee[u] = tn[u] >> 16;
                 }
-                dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
             }
-            const uint32_t fl = (g.out_first[nb + v] == VC_NONE16 ? VC_RF_SINK : 0u) |
-                                (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
-            uint4 rec;
-            rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
-            rec.y = dl[0] | ((uint32_t)dl[1] << 16);
-            rec.z = dl[2] | ((uint32_t)dl[3] << 16);
-            rec.w = dl[4] | ((uint32_t)dl[5] << 16);
-            dp.rec[nb + r] = rec;
-            dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl, is_ovf, hasprev, r, ring);
-            dp.rank2node[nb + r] = (uint16_t)v;
         }
-        ovf_base += tot_ovf;
+#pragma unroll
+        for (int u = 0; u < VC_ROWS_U; ++u) {
+            const uint32_t r = rr[u], v = vv[u];
+            uint32_t np = np_[u];
+            const bool is_ovf = np > VC_INLINE_PRED;
+            uint32_t tot_ovf;
+            const uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
+            if (act_[u]) {
+                if (np == 0) { np = 1; dl_[u][0] = (uint16_t)(r + 1); }
+                if (np > 255) bad = 1;
+                if (is_ovf) {
+                    if (my_ovf + np > EC) bad = 1;
+                    else {
+                        uint32_t k = 0;
+                        for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
+                            const uint32_t tn = g.e_tn[eb + e];
+                            e = tn >> 16;
+                            const uint32_t delta = r - g.pos[nb + (tn & 0xFFFF)];
+                            dp.ovf[eb + my_ovf + k] = (uint16_t)delta;
+                            k++;
+                        }
+                    }
+                    dl_[u][0] = (uint16_t)(my_ovf & 0xFFFF); dl_[u][1] = (uint16_t)(my_ovf >> 16);
+                }
+                const uint32_t fl = (of_[u] == VC_NONE16 ? VC_RF_SINK : 0u) | (is_ovf ? VC_RF_OVF : 0u) | (hp_[u] ? VC_RF_PREV : 0u);
+                uint4 rec;
+                rec.x = cd_[u] | (fl << 8) | (np << 16);
+                rec.y = dl_[u][0] | ((uint32_t)dl_[u][1] << 16);
+                rec.z = dl_[u][2] | ((uint32_t)dl_[u][3] << 16);
+                rec.w = dl_[u][4] | ((uint32_t)dl_[u][5] << 16);
+                dp.rec[nb + r] = rec;
+                dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl_[u], is_ovf, hp_[u], r, ring);
+                dp.rank2node[nb + r] = (uint16_t)v;
+            }
+            ovf_base += tot_ovf;
+        }
     }
     bad = __any(bad);
     broken = __any(broken);
