@@ -1541,7 +1541,8 @@ __global__ void k_trace(VcTraceArgs a) {
 // k_tracew: the same backtrack, cooperative: VC_TG alignments per wave, VC_TL = 16 lanes each.  The walk
 // is a chain of dependent HBM round trips, and ~85 % of its moves are "diagonal through the first
 // in-edge".  Each round therefore
-//   A. follows first in-edges for up to 16 positions using a per-graph table in LDS (no HBM),
+//   A. follows first in-edges for up to VC_SPECW positions using a per-graph table in LDS (no HBM; one entry holds two
+//      links of the chain, so the chase is VC_SPECW/2 dependent LDS reads -- it was 40 % of the kernel at one link each),
 //   B. lets lane k of the group fetch the diagonal cell (and the row record) of speculated position k --
 //      one round trip for all of them,
 //   C. accepts the longest prefix whose cells confirm the move (exactly the reference's first test at
@@ -1549,10 +1550,13 @@ __global__ void k_trace(VcTraceArgs a) {
 //   D. takes one fully general step at the first position that did not confirm: lanes 0..6 of the group
 //      test the diagonal through in-edge p, lanes 8..14 the vertical one, lane 15 the horizontal move,
 //      all in one round trip; ballots pick the first match in the reference's order (sisd :392-448).
-// Four alignments share every instruction of the round; the kernel is instruction-issue bound when the
-// chip is full, so this is what sets its throughput.
+// Four alignments share every instruction of the round.  Measured with the cycle counter: B's loads (HBM misses, one
+// 128-B line per cell) are ~75 % of a round, D's mostly hit the lines B brought in (~7 %).  A step taken locally for
+// single-in-edge rows (vertical / horizontal cells fetched in B) was tried and is slower: a wave still runs D when any of
+// its four groups needs it, and the extra scattered loads lengthen B.
 // ------------------------------------------------------------------------------------------------
 #define VC_TG 4
+#define VC_SPECW 8         // positions speculated per round: 6..10 measured equal and 5 % better than 16 (fewer lines fetched for moves that get rejected)
 #define VC_TL 16
 __host__ __device__ inline uint32_t vc_tracew_tab_len(uint32_t max_rows) { return (max_rows + 2 + 3) & ~3u; }     // entries per table
 __host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table) { return (shared_table ? 1u : (uint32_t)VC_TG) * vc_tracew_tab_len(max_rows) * 2u; }
@@ -1660,7 +1664,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
             bool can = walking && gi != 0 && gj != 0;
 #pragma unroll
             for (uint32_t t = 0; t < VC_TL; t += 2) {                    // two links of the chain per LDS access
-                can = can && ci != 0 && gj > t;
+                can = can && ci != 0 && gj > t && t < VC_SPECW;
                 const uint32_t e = (can && ci <= a.tab_rows) ? (uint32_t)tab[ci] : 0u;
                 const uint32_t d1 = e & 0xFFu, d2 = e >> 8;
                 can = can && d1 != 0;
@@ -1712,7 +1716,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
             if (f) {
                 gnout += f; nspec_ok += f;
                 gi = ni; gT = nT; grec = ni ? nr : zero4; gj -= f;
-                cont = f == VC_TL;                                       // everything confirmed: speculate again
+                cont = f == VC_SPECW;                                       // everything confirmed: speculate again
                 if (!cont && (nw ? (gi == 0 && gj == 0) : (gT == -(int)gj * g))) walking = false;
             }
         }
