@@ -383,7 +383,7 @@ struct Plan {
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
         { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = std::min(NC, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(ta.tab_rows, false), wk.stream, ta); }
+          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = std::min(NC, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, false), wk.stream, ta); }
           else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
@@ -447,7 +447,7 @@ struct Plan {
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
             { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = std::min(maxn, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns * gsz + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0), wk.stream, ta); }
+          if (c->trace_wave) { ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = std::min(maxn, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns * gsz + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0), wk.stream, ta); }
           else hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         }
         VcAddwArgs wa{};
@@ -483,7 +483,7 @@ struct Plan {
         ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
         { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = std::min(NC, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(64), vc_tracew_lds_bytes(ta.tab_rows, false), wk.stream, ta); }
+          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = std::min(NC, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, false), wk.stream, ta); }
           else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
         VcFinishArgs fn{};
         fn.b = c->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;

@@ -1623,13 +1623,13 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         const uint32_t nr = (uint32_t)__shfl((int)nrows, src, 64);
         const uint32_t nb_lo = (uint32_t)__shfl((int)(uint32_t)nb, src, 64), nb_hi = (uint32_t)__shfl((int)(uint32_t)(nb >> 32), src, 64);
         const uint64_t nbs = ((uint64_t)nb_hi << 32) | nb_lo;
-        for (uint32_t r = lane; r < nr; r += 64) {
+        for (uint32_t r = lane; r < nr; r += VC_TG * VC_TL) {
             const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nbs + r]);
             const uint32_t d0 = q.y & 0xFFFF;
             tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint16_t)0 : (uint16_t)d0;
         }
         __syncthreads();
-        for (uint32_t r = 1 + lane; r <= nr; r += 64) {                 // second link: byte reads, byte writes, no overlap
+        for (uint32_t r = 1 + lane; r <= nr; r += VC_TG * VC_TL) {                 // second link: byte reads, byte writes, no overlap
             const uint32_t d1 = tab8[2 * r];
             tab8[2 * r + 1] = (d1 && r > d1) ? tab8[2 * (r - d1)] : (uint8_t)0;
         }
@@ -1788,7 +1788,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     {   // statistics: summed over the wave first, then one of VC_STAT_SLOTS counter sets (a single set serialises in the L2)
         uint32_t s0 = (valid && gl == 0) ? gnout : 0u, s1 = (valid && gl == 0) ? nspec_ok : 0u, s2 = (valid && gl == 0) ? nrounds : 0u;
 #pragma unroll
-        for (int o = VC_TL; o < 64; o <<= 1) { s0 += (uint32_t)__shfl_xor((int)s0, o, 64); s1 += (uint32_t)__shfl_xor((int)s1, o, 64); s2 += (uint32_t)__shfl_xor((int)s2, o, 64); }
+        for (int o = VC_TL; o < VC_TG * VC_TL; o <<= 1) { s0 += (uint32_t)__shfl_xor((int)s0, o, 64); s1 += (uint32_t)__shfl_xor((int)s1, o, 64); s2 += (uint32_t)__shfl_xor((int)s2, o, 64); }
         if (lane == 0) {
             unsigned long long* st = vc_stat_slot(a.stat);
             atomicAdd(st + 4, (unsigned long long)s0); atomicAdd(st + 5, (unsigned long long)s1); atomicAdd(st + 6, (unsigned long long)s2);
