@@ -153,11 +153,21 @@ def main():
         achieved = BYTES_PER_CELL * cells / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
         # measured HBM bytes per cell of k_fwd (rocprofv3 PMC passes, see profiles/r1_hbm_traffic.json)
         traffic = None
+        valu = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
             traffic = tj["bytes_per_cell"] * cells / max(fwd_launches, 1)
-        except Exception:
-            pass
+            # the kernel moves less than the 4 B/cell model, so the VALU issue bound is stated beside it:
+            # VALU instructions per DP row (PMC) x 4 cycles per wave64 instruction, against SIMD-cycles of the k_fwd launches
+            prop = torch.cuda.get_device_properties(local)
+            simds = prop.multi_processor_count * 4
+            mhz = getattr(prop, "clock_rate", 0) / 1e3 or 2400.0          # MI355X peak engine clock (MI355X_MICROARCH.md)
+            ipr = tj["instructions_per_dp_row"]["VALU"]
+            rows = s["dp_rows"] * a.steps
+            valu = {"valu_insts_per_dp_row": ipr, "dp_rows_per_step": rows / a.steps, "simds": simds, "clock_mhz": mhz,
+                    "frac_of_valu_issue_peak": (rows * ipr * 4.0) / (fwd_ms * 1e-3 * simds * mhz * 1e6) if fwd_ms > 0 else None}
+        except Exception as e:
+            valu = valu or {"error": repr(e)}
         line = {
             "metric": "POA windows/sec (500 bp x 64-read)", "value": total_windows / dt, "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -175,7 +185,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells / max(fwd_launches, 1),
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL, "cells_per_step": cells / a.steps,
-                         "avg_launch_ms": fwd_ms / max(fwd_launches, 1), "launches_per_step": fwd_launches / a.steps},
+                         "avg_launch_ms": fwd_ms / max(fwd_launches, 1), "launches_per_step": fwd_launches / a.steps,
+                         "valu_issue": valu},
             "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
         }
         if world == 1 and not a.no_cpu:
