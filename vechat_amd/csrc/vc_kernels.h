@@ -1556,10 +1556,18 @@ __global__ void k_trace(VcTraceArgs a) {
 // its four groups needs it, and the extra scattered loads lengthen B.
 // ------------------------------------------------------------------------------------------------
 #define VC_TG 4
+#ifndef VC_SPECW
 #define VC_SPECW 8         // positions speculated per round: 6..10 measured equal and 5 % better than 16 (fewer lines fetched for moves that get rejected)
+#endif
 #define VC_TL 16
 __host__ __device__ inline uint32_t vc_tracew_tab_len(uint32_t max_rows) { return (max_rows + 2 + 3) & ~3u; }     // entries per table
-__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table) { return (shared_table ? 1u : (uint32_t)VC_TG) * vc_tracew_tab_len(max_rows) * 2u; }
+// links of the first-in-edge chain per table entry.  2 halves the dependent LDS reads of step A (backtrack alone: 390 ->
+// 370 ms per 32 768 windows) but doubles the table, and 8 waves x 18 KB leave no LDS to the other chunk's k_fwd: with two
+// chunk streams 1 link gives 22.3 k windows/s, 2 links 21.2 k
+#ifndef VC_TAB_LINKS
+#define VC_TAB_LINKS 1
+#endif
+__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table) { return (shared_table ? 1u : (uint32_t)VC_TG) * vc_tracew_tab_len(max_rows) * (uint32_t)VC_TAB_LINKS; }
 __device__ __forceinline__ int vc_row_shr1(int v, int first) {          // value of the lane to the left inside a 16-lane row
     return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false);
 }
@@ -1574,8 +1582,12 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     const bool shared_tab = a.shared_table != 0;
     // entry of row r: low byte = distance to the first in-edge's row, high byte = that row's own distance -- two links
     // of the chain per LDS access (0: stop)
+#if VC_TAB_LINKS == 2
     uint16_t* tab = reinterpret_cast<uint16_t*>(smem) + (shared_tab ? 0u : grp) * vc_tracew_tab_len(a.tab_rows);
     uint8_t* tab8 = reinterpret_cast<uint8_t*>(tab);
+#else
+    uint8_t* tab = smem + (shared_tab ? 0u : grp) * vc_tracew_tab_len(a.tab_rows);
+#endif
     const uint32_t njobs = a.nslots * a.group;
     const uint32_t job = blockIdx.x * VC_TG + grp;
     bool valid = job < njobs;
@@ -1626,24 +1638,28 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         for (uint32_t r = lane; r < nr; r += VC_TG * VC_TL) {
             const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nbs + r]);
             const uint32_t d0 = q.y & 0xFFFF;
-            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint16_t)0 : (uint16_t)d0;
+            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? 0 : d0;
         }
         __syncthreads();
+#if VC_TAB_LINKS == 2
         for (uint32_t r = 1 + lane; r <= nr; r += VC_TG * VC_TL) {                 // second link: byte reads, byte writes, no overlap
             const uint32_t d1 = tab8[2 * r];
             tab8[2 * r + 1] = (d1 && r > d1) ? tab8[2 * (r - d1)] : (uint8_t)0;
         }
+#endif
     } else {
         for (uint32_t r = gl; walking && r < nrows; r += VC_TL) {
             const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + r]);
             const uint32_t d0 = q.y & 0xFFFF;
-            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? (uint16_t)0 : (uint16_t)d0;
+            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? 0 : d0;
         }
         __syncthreads();
+#if VC_TAB_LINKS == 2
         for (uint32_t r = 1 + gl; walking && r <= nrows; r += VC_TL) {
             const uint32_t d1 = tab8[2 * r];
             tab8[2 * r + 1] = (d1 && r > d1) ? tab8[2 * (r - d1)] : (uint8_t)0;
         }
+#endif
     }
     __syncthreads();
     uint32_t gi = end >> 16, gj = end & 0xFFFF, gnout = 0, nspec_ok = 0, nrounds = 0;
@@ -1666,7 +1682,11 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
             for (uint32_t t = 0; t < VC_TL; t += 2) {                    // two links of the chain per LDS access
                 can = can && ci != 0 && gj > t && t < VC_SPECW;
                 const uint32_t e = (can && ci <= a.tab_rows) ? (uint32_t)tab[ci] : 0u;
+#if VC_TAB_LINKS == 2
                 const uint32_t d1 = e & 0xFFu, d2 = e >> 8;
+#else
+                const uint32_t d1 = e, d2 = (can && d1 != 0 && ci - d1 != 0 && ci - d1 <= a.tab_rows) ? (uint32_t)tab[ci - d1] : 0u;
+#endif
                 can = can && d1 != 0;
                 const uint32_t c1 = ci - d1;
                 const bool can2 = can && c1 != 0 && gj > t + 1 && d2 != 0;
