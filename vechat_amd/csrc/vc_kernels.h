@@ -1541,8 +1541,8 @@ __global__ void k_trace(VcTraceArgs a) {
 // k_tracew: the same backtrack, cooperative: VC_TG alignments per wave, VC_TL = 16 lanes each.  The walk
 // is a chain of dependent HBM round trips, and ~85 % of its moves are "diagonal through the first
 // in-edge".  Each round therefore
-//   A. follows first in-edges for up to VC_SPECW positions using a per-graph table in LDS (no HBM; one entry holds two
-//      links of the chain, so the chase is VC_SPECW/2 dependent LDS reads -- it was 40 % of the kernel at one link each),
+//   A. follows first in-edges for up to VC_SPECW positions using a per-graph table in LDS (no HBM; VC_TAB_LINKS links
+//      of the chain per entry -- see there for why it is 1 although 2 makes this kernel faster on its own),
 //   B. lets lane k of the group fetch the diagonal cell (and the row record) of speculated position k --
 //      one round trip for all of them,
 //   C. accepts the longest prefix whose cells confirm the move (exactly the reference's first test at
@@ -1580,8 +1580,8 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     // first in-edge distance of row r (0: do not speculate).  In the re-alignment rounds the alignments of a
     // wave belong to one window (group % VC_TG == 0) and share one table: a quarter of the LDS, more waves
     const bool shared_tab = a.shared_table != 0;
-    // entry of row r: low byte = distance to the first in-edge's row, high byte = that row's own distance -- two links
-    // of the chain per LDS access (0: stop)
+    // entry of row r: distance to the first in-edge's row (0: stop); with VC_TAB_LINKS == 2 the high byte holds that row's
+    // own distance as well, two links of the chain per LDS access
 #if VC_TAB_LINKS == 2
     uint16_t* tab = reinterpret_cast<uint16_t*>(smem) + (shared_tab ? 0u : grp) * vc_tracew_tab_len(a.tab_rows);
     uint8_t* tab8 = reinterpret_cast<uint8_t*>(tab);
@@ -1679,7 +1679,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
             uint32_t ci = gi;
             bool can = walking && gi != 0 && gj != 0;
 #pragma unroll
-            for (uint32_t t = 0; t < VC_TL; t += 2) {                    // two links of the chain per LDS access
+            for (uint32_t t = 0; t < VC_TL; t += 2) {                    // two links per iteration (one LDS access with VC_TAB_LINKS == 2)
                 can = can && ci != 0 && gj > t && t < VC_SPECW;
                 const uint32_t e = (can && ci <= a.tab_rows) ? (uint32_t)tab[ci] : 0u;
 #if VC_TAB_LINKS == 2
