@@ -72,6 +72,33 @@ def cpu_baseline(batch, params, budget_s):
                 sample=f"first {done} windows of the bench batch, one window per task on {cores} threads, {dt:.1f} s"), out
 
 
+def stub_main(a, world):
+    """Launch-plumbing check for boxes without a GPU (tests/test_shard.py): the same rank fan-out, barrier, MAX-over-ranks
+    timing and gather, over gloo, with the kernels replaced by "consensus = backbone".  Never a measurement: the line says
+    metric "stub"."""
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = capi.synth_cfg(1002, a.length, min(a.layers, 4), profile=capi.PACBIO)
+    batch = capi.synth_batch(cfg, rank * a.windows, a.windows)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        backs = [batch.window(w)[0][0] for w in range(batch.n_windows)]
+        cons = torch.from_numpy(np.frombuffer(b"".join(backs), dtype=np.uint8).copy())
+        lens = torch.tensor([len(x) for x in backs], dtype=torch.int64)
+        cons_all, lens_all = gather_consensus(cons, lens, dst=0)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": a.windows * world * a.steps / float(t.item()), "unit": "windows/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "data": "stub", "windows_gathered": int(lens_all.numel())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,7 +113,19 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # one process per GPU: start N ranks of this same command line (rank r on device r), as the reference fans one
+        # invocation out over its devices (src/cuda/cudapolisher.cpp:229-241)
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29533")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("VC_BENCH_STUB") == "1":
+        return stub_main(a, world)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("VC_FORCE_DIST") == "1"      # exercise the RCCL path on a single GPU

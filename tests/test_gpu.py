@@ -277,3 +277,84 @@ def test_full_size_config_b_properties(built):
     for w in rng.choice(n, size=12, replace=False):
         ref, pol, _ = oa.oracle_run(batch, capi.default_params(), int(w), int(w) + 1)
         assert cons[int(w)] == ref[0] and pol[0]
+
+
+def test_config_e_full_depth_parity(built):
+    """BASELINE config E at its real shape (ONT-profile 1 kb windows x 128 reads, d=0.2, 3 prune rounds): every
+    window byte-identical to the oracle in both overloads, same DP work counted on both sides."""
+    batch = capi.synth_batch(capi.synth_cfg(1005, 1000, 128, profile=capi.ONT), 0, 3)
+    for mode in (0, 1):
+        c = HipContext(device=0, mode=mode, min_confidence=0.2, num_prune=3)
+        st = _check(c, batch, f"config E mode{mode}")
+        assert c.stats()["cells"] == st.cells
+        c.close()
+
+
+def test_config_e_properties_at_2048_windows(built):
+    """Config E's shape over 2 048 windows: all windows polished, a checksum of checksums that does not depend on
+    chunking or stream count, 8 sampled windows re-checked against the oracle."""
+    n = 2048
+    batch = capi.synth_batch(capi.synth_cfg(1005, 1000, 128, profile=capi.ONT), 0, n)
+    c1 = HipContext(device=0)
+    cons, status = c1.consensus(batch)
+    c1.close()
+    assert (status == capi.VC_WIN_OK).all(), [int(s) for s in status if s != capi.VC_WIN_OK][:8]
+    lens = np.array([len(x) for x in cons])
+    assert 950 < np.median(lens) < 1020
+    h1 = hashlib.sha256(b"".join(hashlib.sha256(x).digest() for x in cons)).hexdigest()
+    c2 = HipContext(device=0, chunk_windows=600, n_streams=3)
+    cons2, status2 = c2.consensus(batch)
+    c2.close()
+    assert (status2 == capi.VC_WIN_OK).all()
+    assert hashlib.sha256(b"".join(hashlib.sha256(x).digest() for x in cons2)).hexdigest() == h1
+    rng = np.random.default_rng(11)
+    for w in rng.choice(n, size=8, replace=False):
+        ref, pol, _ = oa.oracle_run(batch, capi.default_params(), int(w), int(w) + 1)
+        assert cons[int(w)] == ref[0] and pol[0], int(w)
+
+
+def test_randomised_sweep_fixed_seed(built):
+    """48 random shapes / parameter sets (fixed seed), small batches, both overloads, packed and raw rows, partial spans,
+    several haplotypes: consensus bytes, polished flags and DP cell counts equal to the oracle's."""
+    import random
+    rng = random.Random(20260929)
+    ctxs = {}
+    bad = []
+    for case in range(48):
+        L = rng.choice([60, 120, 250, 400, 500, 500, 640, 800, 1000])
+        D = rng.choice([3, 5, 8, 12, 20, 32, 48])
+        n = rng.choice([4, 8])
+        kw = dict(frac_partial=rng.choice([0, 0, 0.2, 0.5]), n_haplotypes=rng.choice([1, 1, 2, 3]), snp_rate=rng.choice([0.005, 0.02]),
+                  fastq=rng.choice([0, 1, 1]), backbone_fastq=rng.choice([0, 1, 1]), profile=rng.choice([capi.PACBIO, capi.ONT]))
+        pk = dict(mode=rng.choice([0, 0, 0, 1]), num_prune=rng.choice([1, 2, 3, 3, 4]), min_confidence=rng.choice([0.2, 0.2, 0.1, 0.3]),
+                  min_support=rng.choice([0.2, 0.2, 0.15]), trim=rng.choice([0, 1]))
+        if rng.random() < 0.15:
+            pk.update(match=5, mismatch=-4, gap=-8)            # raw (unpacked) rows
+        key = tuple(sorted(pk.items()))
+        if key not in ctxs:
+            ctxs[key] = HipContext(device=0, **pk)
+        c = ctxs[key]
+        seed = rng.randrange(1, 1 << 30)
+        batch = capi.synth_batch(capi.synth_cfg(seed, L, D, **kw), 0, n)
+        cons, status = c.consensus(batch)
+        ref, pol, st = oa.oracle_run(batch, c.params)
+        mism = [w for w in range(n) if cons[w] != ref[w] or int(status[w]) != (capi.VC_WIN_OK if pol[w] else capi.VC_WIN_UNPOLISHED)]
+        retried = any(e != (0, 0) for e in c.errinfo())         # an overflow retry reruns part of the batch: counters differ
+        if mism or (not retried and c.stats()["cells"] != st.cells):
+            bad.append((case, seed, L, D, n, kw, pk, mism, [int(x) for x in status]))
+    for c in ctxs.values():
+        c.close()
+    assert not bad, bad[:3]
+
+
+def test_bench_single_rank_through_rccl(built):
+    """bench.py's distributed path (RCCL process group, barrier, gather to rank 0) with one rank on one GPU."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VC_FORCE_DIST="1", MASTER_PORT="29573")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--windows", "512",
+                          "--layers", "16", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["windows_not_ok"] == 0

@@ -1,12 +1,15 @@
 """CPU suite, part 3: the N>1 path (window sharding + final gather) over gloo, world_size 2."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from vechat_amd.shard import estimated_cells, gather_consensus, shard_range, shard_range_balanced
 
@@ -75,3 +78,22 @@ def test_gather_over_gloo_world_size_2():
         p.join(30)
         assert p.exitcode == 0
     assert ok == (True, True)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks(built):
+    """`python bench.py --gpus 2` itself starts two ranks (one per GPU on a GPU box).  Here: gloo, kernels stubbed off
+    (VC_BENCH_STUB=1) -- the fan-out, the rendezvous, the gather to rank 0 and the one JSON line are what is checked."""
+    import json, subprocess
+    env = dict(os.environ, VC_BENCH_STUB="1", MASTER_PORT="29571")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--windows", "6",
+                          "--length", "80"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["windows_gathered"] == 12
+    # a mismatch between --gpus and the launcher's world size is an error, not a silent 1-GPU run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
