@@ -1,0 +1,104 @@
+// Calibration microbenchmark for the VALU roofline of k_fwd (bench.py reads profiles/r2_valu_peak.json made from its output):
+// issue rate of the packed-int16 instructions the forward DP is made of (v_pk_max_i16 / v_pk_add_i16, plus the DPP and
+// v_perm forms it uses), the dependent-issue latency of the same, and the engine clock the chip sustains under that load.
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_peak.hip -o tools/valu_peak.bin && tools/valu_peak.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// MODE 0: 8 independent chains of v_pk_max_i16 / v_pk_add_i16 (issue-bound)
+// MODE 1: one dependent chain of the same (latency-bound)
+// MODE 2: dependent chain of DPP row_shr max (the cross-lane scan step)
+// MODE 3: 8 independent v_perm_b32
+// MODE 4: 8 independent v_max_i32 (32-bit reference)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, unsigned long long* cyc) {
+    uint32_t r0 = threadIdx.x, r1 = r0 * 3 + 1, r2 = r0 * 5 + 2, r3 = r0 * 7 + 3, r4 = r0 ^ 0x55, r5 = r0 + 77, r6 = r0 * 11, r7 = r0 + 9;
+    const uint32_t c = 0x00010001u * (blockIdx.x & 3) + 0x00020001u;
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {
+            asm volatile(
+                "v_pk_max_i16 %0, %0, %8\n v_pk_add_i16 %1, %1, %8\n v_pk_max_i16 %2, %2, %8\n v_pk_add_i16 %3, %3, %8\n"
+                "v_pk_max_i16 %4, %4, %8\n v_pk_add_i16 %5, %5, %8\n v_pk_max_i16 %6, %6, %8\n v_pk_add_i16 %7, %7, %8\n"
+                "v_pk_max_i16 %0, %0, %8\n v_pk_add_i16 %1, %1, %8\n v_pk_max_i16 %2, %2, %8\n v_pk_add_i16 %3, %3, %8\n"
+                "v_pk_max_i16 %4, %4, %8\n v_pk_add_i16 %5, %5, %8\n v_pk_max_i16 %6, %6, %8\n v_pk_add_i16 %7, %7, %8\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c));
+        } else if (MODE == 1) {
+            asm volatile(
+                "v_pk_max_i16 %0, %0, %1\n v_pk_add_i16 %0, %0, %1\n v_pk_max_i16 %0, %0, %1\n v_pk_add_i16 %0, %0, %1\n"
+                "v_pk_max_i16 %0, %0, %1\n v_pk_add_i16 %0, %0, %1\n v_pk_max_i16 %0, %0, %1\n v_pk_add_i16 %0, %0, %1\n"
+                "v_pk_max_i16 %0, %0, %1\n v_pk_add_i16 %0, %0, %1\n v_pk_max_i16 %0, %0, %1\n v_pk_add_i16 %0, %0, %1\n"
+                "v_pk_max_i16 %0, %0, %1\n v_pk_add_i16 %0, %0, %1\n v_pk_max_i16 %0, %0, %1\n v_pk_add_i16 %0, %0, %1\n"
+                : "+v"(r0) : "v"(c));
+        } else if (MODE == 2) {
+            asm volatile(
+                "s_nop 1\n"
+                "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+                : "+v"(r0));
+        } else if (MODE == 3) {
+            asm volatile(
+                "v_perm_b32 %0, %0, %8, %9\n v_perm_b32 %1, %1, %8, %9\n v_perm_b32 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n"
+                "v_perm_b32 %4, %4, %8, %9\n v_perm_b32 %5, %5, %8, %9\n v_perm_b32 %6, %6, %8, %9\n v_perm_b32 %7, %7, %8, %9\n"
+                "v_perm_b32 %0, %0, %8, %9\n v_perm_b32 %1, %1, %8, %9\n v_perm_b32 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n"
+                "v_perm_b32 %4, %4, %8, %9\n v_perm_b32 %5, %5, %8, %9\n v_perm_b32 %6, %6, %8, %9\n v_perm_b32 %7, %7, %8, %9\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c), "v"(0x06040200u));
+        } else {
+            asm volatile(
+                "v_max_i32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_max_i32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                "v_max_i32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_max_i32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                "v_max_i32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_max_i32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                "v_max_i32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_max_i32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c));
+        }
+    }
+    const unsigned long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int MODE>
+int run(const char* name, int waves_per_simd, int n_cu, int per_iter) {
+    const int iters = 200000;
+    const int blocks = n_cu * waves_per_simd;          // 256-thread blocks: one wave per SIMD each
+    uint32_t* d_out; unsigned long long* d_cyc;
+    CHK(hipMalloc(&d_out, (size_t)blocks * 256 * 4)); CHK(hipMalloc(&d_cyc, (size_t)blocks * 4 * 8));
+    hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+    hipLaunchKernelGGL(k_valu<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, 1000, d_cyc);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL(k_valu<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, iters, d_cyc);
+    CHK(hipEventRecord(b, 0));
+    CHK(hipEventSynchronize(b));
+    float ms = 0; CHK(hipEventElapsedTime(&ms, a, b));
+    std::vector<unsigned long long> cyc((size_t)blocks * 4);
+    CHK(hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost));
+    std::sort(cyc.begin(), cyc.end());
+    const double med = (double)cyc[cyc.size() / 2];
+    const double insts = (double)iters * per_iter;
+    // clock64() ticks at a constant 100 MHz on gfx9; the engine clock follows from the instruction count when the issue
+    // rate per cycle is known -- report both views: instructions per microsecond per SIMD and ticks
+    const double inst_per_us_per_simd = insts * waves_per_simd / (ms * 1e3);
+    printf("{\"test\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"wave_insts\": %.0f, \"inst_per_us_per_simd\": %.1f, \"ns_per_wave_inst\": %.3f, \"clock64_ticks_median\": %.0f}\n",
+           name, waves_per_simd, ms, insts, inst_per_us_per_simd, ms * 1e6 / insts, med);
+    (void)hipFree(d_out); (void)hipFree(d_cyc);
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
+    const int n_cu = p.multiProcessorCount;
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_rate_khz\": %d}\n", p.gcnArchName, n_cu, p.clockRate);
+    for (int w : {1, 2, 4, 8}) if (run<0>("pk_i16_independent", w, n_cu, 16)) return 1;
+    for (int w : {1, 4}) if (run<4>("i32_independent", w, n_cu, 16)) return 1;
+    for (int w : {1, 4}) if (run<3>("v_perm_independent", w, n_cu, 16)) return 1;
+    for (int w : {1, 2, 4}) if (run<1>("pk_i16_dependent", w, n_cu, 16)) return 1;
+    for (int w : {1, 4}) if (run<2>("dpp_max_dependent", w, n_cu, 8)) return 1;
+    return 0;
+}

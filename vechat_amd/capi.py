@@ -234,7 +234,7 @@ def load_hip():
     """The product library.  Raises if it has not been built; never falls back to CPU code."""
     global _hip
     if _hip is None:
-        path = os.path.join(LIB_DIR, "libvechat_hip.so")
+        path = os.environ.get("VECHAT_HIP_LIB") or os.path.join(LIB_DIR, "libvechat_hip.so")   # override: development A/B builds
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: the HIP extension is required (no CPU fallback); "
                                "run `python -c 'import __graft_entry__ as g; g.build()'`")

@@ -875,6 +875,58 @@ int vc_debug_errinfo(vc_ctx* c, uint32_t* out) {
     return VC_OK;
 }
 
+#ifdef VC_LAB
+// development (tools/gpu_fwd_lab.py): build the first chunk up to `layer`, prepare that layer's rows, then time `reps`
+// launches of k_fwd alone with parts of its row loop switched off (VcFwdArgs::dbg).  Nothing downstream runs.
+int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, float* ms_out, unsigned long long* cells_out) {
+    if (!c || !c->have_batch) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    Plan pl{};
+    pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
+    pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK);
+    pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
+    pl.add_lds = 2 * c->PC + 2 * (c->PC - c->NC) + 64;
+    pl.rows_lds = 0; pl.cons_lds = 0;
+    pl.rowd = 64ull * (c->cpl / 2);
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
+    HIPCHK(c, hipMemsetAsync(c->b.status, 0, c->b.n_windows, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Work& wk = c->works[0];
+    static uint32_t built_to = 0;
+    int rc;
+    if (built_to != layer) {
+        pl.begin(wk, 0, std::min(c->CW, c->b.n_windows));
+        for (uint32_t j = 1; j < layer; ++j) if ((rc = pl.build_layer(wk, j))) return rc;
+        hipLaunchKernelGGL(k_rows, dim3(wk.ns), dim3(64), 0, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, wk.ns, pl.NC, pl.EC, (int)layer, (uint32_t)kRing);
+        built_to = layer;
+    }
+    VcFwdArgs fa = pl.fwd_args(wk);
+    fa.group = 1; fa.k0 = layer; fa.mode = 0; fa.hstride = (uint64_t)pl.NC * pl.rowd; fa.dbg = flags;
+    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64 * VC_STAT_SLOTS, wk.stream));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
+    if ((rc = launch_fwd(c, wk.stream, fa, wk.ns))) return rc;            // warm-up
+    HIPCHK(c, hipEventRecord(e0, wk.stream));
+    for (uint32_t r = 0; r < reps; ++r) {
+        HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
+        if ((rc = launch_fwd(c, wk.stream, fa, wk.ns))) return rc;
+    }
+    HIPCHK(c, hipEventRecord(e1, wk.stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / reps;
+    unsigned long long raw[8 * VC_STAT_SLOTS], cells = 0, rows = 0;
+    HIPCHK(c, hipMemcpy(raw, c->d_stat, sizeof(raw), hipMemcpyDeviceToHost));
+    for (int i = 0; i < VC_STAT_SLOTS; ++i) { cells += raw[i * 8]; rows += raw[i * 8 + 1]; }
+    cells_out[0] = cells / (reps + 1); cells_out[1] = rows / (reps + 1);
+
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return VC_OK;
+}
+#endif
+
 int vc_get_stats(vc_ctx* c, vc_stats* s) {
     if (!c || !s) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));

@@ -948,7 +948,15 @@ struct VcFwdArgs {
     uint32_t* tie_list;            // [jobs] windows whose alignment ended in a tie (build phase)
     uint32_t* tie_n;               // [1]
     unsigned long long* stat;      // [4] cells, rows, -, far-row reads
+#ifdef VC_LAB
+    uint32_t dbg;                  // development (tools/gpu_fwd_lab.py): parts of the row loop switched off, timing only
+#endif
 };
+#ifdef VC_LAB
+#define VC_LABF(f) ((a.dbg & (f)) != 0)
+#else
+#define VC_LABF(f) false
+#endif
 
 #define VC_DPP_SHR(v, old, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xF, false)
 
@@ -1149,7 +1157,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
 #pragma unroll
             for (int q = 0; q < ND; ++q) acc[q] = 0x80008000u;
         }
-        if (nq) {
+        if (nq && !VC_LABF(4)) {
             // a row of the LDS ring; column 0 of the last 64 rows lives in c0vec
             auto ringrow = [&](uint32_t delta, uint32_t (&hp)[ND], int& c0p) __attribute__((always_inline)) {
                 const uint32_t pr = i - delta, rs = pr % RING;
@@ -1164,7 +1172,8 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
             };
             uint32_t hA[ND], hB[ND];
             int cA = 0, cB = 0;
-            if (!(fl & VC_RF_SLOW)) {
+            if (VC_LABF(256) && (fl & VC_RF_SLOW)) {
+            } else if (!(fl & VC_RF_SLOW)) {
                 // usual case: every listed predecessor sits in the LDS ring
                 ringrow(r1 & 0xFFFF, hA, cA);
                 if (nq > 1) ringrow(r1 >> 16, hB, cB);
@@ -1275,7 +1284,8 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         for (int q = 0; q < ND; ++q) acc[q] = pk_max(P[q], cc);
 
         // ---- end cell
-        if (nw) {
+        if (VC_LABF(16)) {
+        } else if (nw) {
             if (fl & VC_RF_SINK) {                           // sisd :353-355 (same column: tilted compare is exact)
                 uint32_t hv = acc[0];
 #pragma unroll
@@ -1305,9 +1315,12 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         // one wave per workgroup: LDS operations of a wave retire in order, so no s_barrier (and no
         // vmcnt(0) drain of the H stores) is needed -- only keep the compiler from reordering
         __builtin_amdgcn_wave_barrier();
+        if (!VC_LABF(2)) {
 #pragma unroll
         for (int q = 0; q < ND; ++q) ring[ws][q][lane] = acc[q];
-        if (packed) {
+        }
+        if (VC_LABF(1)) {
+        } else if (packed) {
             uint32_t wv[NDS];
             vc_pack_row<ND, NDS>(acc, wv);
             uint32_t* hr = hrow + lane * NDS;
