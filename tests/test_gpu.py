@@ -358,3 +358,36 @@ def test_bench_single_rank_through_rccl(built):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["windows_not_ok"] == 0
+
+
+def _recode(batch, alphabet, rate, seed):
+    """Windows of `batch` with a fraction of the layer bases replaced by letters of `alphabet` (columns then hold many
+    distinct bytes: aligned groups larger than A/C/G/T/N)."""
+    rng = np.random.default_rng(seed)
+    wins = []
+    for w in range(batch.n_windows):
+        seqs, quals, b, e = batch.window(w)
+        out = []
+        for k, sq in enumerate(seqs):
+            a = np.frombuffer(sq, dtype=np.uint8).copy()
+            if k > 0:
+                hit = rng.random(a.size) < rate
+                a[hit] = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=int(hit.sum()))
+            out.append(a.tobytes())
+        wins.append((out, quals, b, e))
+    return capi.Batch.from_windows(wins, [int(x) for x in batch.win_fasta], presorted=True)
+
+
+def test_wide_alphabet_aligned_groups_beyond_five(built):
+    """IUPAC-style reads: a column can hold far more than five distinct bytes, i.e. aligned groups (Node::aligned_nodes,
+    graph.cpp:258-277) beyond A/C/G/T/N.  The aligned lists are sized from the batch's alphabet; same bytes as the oracle."""
+    base = capi.synth_batch(capi.synth_cfg(301, 160, 40, frac_partial=0.2), 0, 6)
+    batch = _recode(base, b"ACGTURYSWKMBDHVN", 0.35, 5)
+    for mode in (0, 1):
+        c = HipContext(device=0, mode=mode)
+        _check(c, batch, f"iupac mode{mode}")
+        c.close()
+    lower = _recode(base, bytes(range(97, 123)), 0.5, 6)                     # 26 more symbols
+    c = HipContext(device=0)
+    _check(c, lower, "26-letter alphabet")
+    c.close()

@@ -39,8 +39,8 @@ constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may as
 constexpr uint64_t kMaxColumns = 2048;     // longest sequence k_fwd takes (64 lanes x 32 columns)
 constexpr uint32_t kResolveGrid = 128;   // workgroups of k_resolve (each owns one DFS workspace in HBM)
 
-uint32_t topo_lds_bytes(uint32_t NC, uint32_t EC, uint32_t STK) {
-    return ((2 * NC + 15) & ~15u) + 4 * EC + 8 * NC + ((NC + 15) & ~15u) + 2 * STK + 2 * NC + 64;
+uint32_t topo_lds_bytes(uint32_t NC, uint32_t EC, uint32_t STK, uint32_t MA) {
+    return ((2 * NC + 15) & ~15u) + 4 * EC + 2 * MA * NC + 2 * ((NC + 15) & ~15u) + 2 * STK + 2 * NC + 64;
 }
 
 // one chunk's device workspace + stream
@@ -51,7 +51,7 @@ struct Work {
     uint32_t* d_hmat = nullptr; int16_t* d_c0 = nullptr; uint8_t* d_resolve_ws = nullptr;
     uint8_t* d_big_ws = nullptr;        // [CW * big_ws_stride] graph images that do not fit the LDS (k_topo / k_prune_lcc / k_consensus)
     uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
-    uint16_t* d_tie_rows = nullptr; uint8_t* d_tie_cnt = nullptr; uint32_t* d_tie_list = nullptr; uint32_t* d_tie_n = nullptr;
+    uint16_t* d_tie_rows = nullptr; uint32_t* d_tie_cnt = nullptr; uint32_t* d_tie_list = nullptr; uint32_t* d_tie_n = nullptr;
     uint32_t* d_pairs = nullptr; uint32_t* d_npairs = nullptr;       // build / final: [CW*PC]
     uint32_t* d_rpairs = nullptr; uint32_t* d_rnpairs = nullptr;     // realign: [CW*max_nseq*PC]
     uint32_t* d_maxn = nullptr;
@@ -92,6 +92,7 @@ struct vc_ctx {
     uint32_t* d_lut_w = nullptr; double* d_lut_d = nullptr;
     unsigned long long* d_stat = nullptr;   // [VC_STAT_SLOTS][8] cells, rows, -, far-row reads, trace steps, speculated steps, rounds, -
 
+    uint32_t MA = 4;                     // entries per aligned list: max(4, distinct bytes in the batch - 1), even
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
     uint32_t big_ws_stride = 0;          // bytes per window of the HBM workspace for oversized graph images (0: all fit the LDS)
@@ -178,7 +179,8 @@ int alloc_graph(vc_ctx* c, VcGraph* g) {
     if ((rc = dalloc(c, c->chunk_allocs, &g->out_first, CW * NC))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &g->out_last, CW * NC))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &g->al_cnt, CW * NC))) return rc;
-    if ((rc = dalloc(c, c->chunk_allocs, &g->al, CW * NC * VC_MAXALN))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->al, CW * NC * c->MA))) return rc;
+    g->ma = c->MA;
     if ((rc = dalloc(c, c->chunk_allocs, &g->e_tn, CW * EC))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &g->e_hn, CW * EC))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &g->e_w, CW * EC))) return rc;
@@ -198,7 +200,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_resolve_ws, (size_t)kResolveGrid * ((topo_lds_bytes(NC, c->EC, c->STK) + 15u) & ~15u))) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_resolve_ws, (size_t)kResolveGrid * ((topo_lds_bytes(NC, c->EC, c->STK, c->MA) + 15u) & ~15u))) ||
         (c->big_ws_stride && (rc = dalloc(c, c->chunk_allocs, &wk->d_big_ws, (size_t)CW * c->big_ws_stride))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_c0, (size_t)c->jobs_cap * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_end, c->jobs_cap)) ||
@@ -370,13 +372,14 @@ struct Plan {
         }
         VcFwdArgs fa = fwd_args(wk);
         fa.group = 1; fa.k0 = j; fa.mode = 0; fa.hstride = (uint64_t)NC * rowd;
+        fa.tie_over = wk.d_pairs; fa.tie_over_stride = PC;      // the pair list of the job is written only after k_resolve
         HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
         int rc = launch_fwd(c, wk.stream, fa, ns);
         if (rc) return rc;
         { Timer t(c, KC_RESOLVE, wk.stream);
           const uint32_t rs_lds = 4 * ((NC + 31) / 32 + 1) + 2 * 256 + 16;
           hipLaunchKernelGGL(k_resolve, dim3(kResolveGrid), dim3(64), rs_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
-                             (const uint16_t*)wk.d_tie_rows, (const uint8_t*)wk.d_tie_cnt, wk.d_job_end,
+                             (const uint16_t*)wk.d_tie_rows, (const uint32_t*)wk.d_tie_cnt, (const uint32_t*)wk.d_pairs, PC, wk.d_job_end,
                              (const uint32_t*)wk.d_tie_list, (const uint32_t*)wk.d_tie_n, (const uint32_t*)wk.d_submask, (int)j,
                              wk.d_resolve_ws, (topo_lds + 15u) & ~15u, c->force_dfs ? 1 : 0); }
         VcTraceArgs ta = trace_args(wk);
@@ -408,13 +411,13 @@ struct Plan {
         VcPruneArgs pa{};
         pa.b = c->b; pa.src = wk.gr[wk.cur]; pa.dst = wk.gr[wk.cur ^ 1]; pa.w0 = wk.w0; pa.nslots = ns; pa.NC = NC; pa.EC = EC;
         pa.NCl = NCl; pa.ECl = ECl;
-        const bool pws = vc_prune_lds_bytes(NCl, ECl) > kLdsCap, tws = topo_lds_bytes(NCl, ECl, c->STK) > kLdsCap;
+        const bool pws = vc_prune_lds_bytes(NCl, ECl) > kLdsCap, tws = topo_lds_bytes(NCl, ECl, c->STK, c->MA) > kLdsCap;
         pa.ws = pws ? wk.d_big_ws : nullptr; pa.ws_stride = c->big_ws_stride;
         pa.min_conf = c->prm.min_confidence; pa.min_supp = c->prm.min_support;
         { Timer t(c, KC_PRUNE, wk.stream); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), pws ? 0 : vc_prune_lds_bytes(NCl, ECl), wk.stream, pa); }
         wk.cur ^= 1;
         { Timer t(c, KC_TOPO, wk.stream);
-          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tws ? 0 : topo_lds_bytes(NCl, ECl, c->STK), wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NCl, ECl,
+          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tws ? 0 : topo_lds_bytes(NCl, ECl, c->STK, c->MA), wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NCl, ECl,
                              tws ? wk.d_big_ws : nullptr, c->big_ws_stride); }
         if (more) {
             HIPCHK(c, hipMemsetAsync(wk.d_maxn, 0, 8, wk.stream));
@@ -657,6 +660,21 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     c->h_pre_status = any_pre ? pre : std::vector<uint8_t>();
     if (max_len == 0) { max_len = 1; min_len = 1; }              // every window was outside the envelope
 
+    // alphabet of the batch -> entries per aligned list (an aligned group holds distinct bytes, graph.cpp:258-277)
+    uint32_t MA = 4;
+    {
+        uint32_t* d_mask = nullptr;
+        if ((rc = salloc(c, 15, &d_mask, 8))) return rc;
+        HIPCHK(c, hipMemsetAsync(d_mask, 0, 32, c->stream));
+        hipLaunchKernelGGL(k_byte_presence, dim3(1024), dim3(256), 0, c->stream, (const uint8_t*)d_ba, nbytes, d_mask);
+        uint32_t hm[8];
+        HIPCHK(c, hipMemcpyAsync(hm, d_mask, 32, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        uint32_t distinct = 0;
+        for (int k = 0; k < 8; ++k) distinct += (uint32_t)__builtin_popcount(hm[k]);
+        if (distinct > 5) MA = (distinct - 1 + 1) & ~1u;
+    }
+
     // capacities
     uint32_t NC = c->prm.max_nodes ? c->prm.max_nodes : (uint32_t)std::min<uint64_t>(need_nodes, 60000);
     NC = (NC + 63) & ~63u;
@@ -670,7 +688,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint32_t lds_cap = kLdsCap;
     // graph images that do not fit the LDS are worked on in an HBM workspace (slower, not refused)
     uint32_t big = 0;
-    if (topo_lds_bytes(NC, EC, c->STK) > lds_cap) big = std::max(big, topo_lds_bytes(NC, EC, c->STK));
+    if (topo_lds_bytes(NC, EC, c->STK, MA) > lds_cap) big = std::max(big, topo_lds_bytes(NC, EC, c->STK, MA));
     if (vc_prune_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_prune_lds_bytes(NC, EC));
     if (c->prm.mode == 1 && vc_cons_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_cons_lds_bytes(NC, EC));
     big = (big + 255u) & ~255u;
@@ -683,7 +701,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint32_t S = c->n_streams;
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6)) / S;
     const uint64_t rowd = 64ull * (cpl / 2);
-    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2 * VC_MAXALN + 6) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
+    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
     const uint64_t per_job = NC * rowd * 4 + NC * 2 + 8 + 2 * VC_MAXTIE + 8;
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
@@ -696,12 +714,12 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint32_t group_max = 1 + (uint32_t)std::min<uint64_t>(spare / (per_job * CW), 7);
     if (group_max > max_nseq) group_max = max_nseq;
 
-    const bool same = c->NC == NC && c->EC == EC && c->CW == CW && c->cpl == cpl && c->PC == PC && c->big_ws_stride == big &&
+    const bool same = c->MA == MA && c->NC == NC && c->EC == EC && c->CW == CW && c->cpl == cpl && c->PC == PC && c->big_ws_stride == big &&
                       c->group_max == group_max && c->max_nseq == max_nseq && !c->chunk_allocs.empty();
     if (!same) {
         free_list(c->chunk_allocs);
         c->chunk_bytes = 0;
-        c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
+        c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
         c->big_ws_stride = big;
         c->jobs_cap = CW * group_max;
         c->hmat_dwords = (uint64_t)c->jobs_cap * NC * rowd;
@@ -729,7 +747,7 @@ int vc_run(vc_ctx* c) {
     const VcBatchDev& b = c->b;
     Plan pl{};
     pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
-    pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK);
+    pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK, c->MA);
     pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
     pl.add_lds = 2 * c->PC + 2 * (c->PC - c->NC) + 64;
     pl.rows_lds = 0;
@@ -883,7 +901,7 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
     HIPCHK(c, hipSetDevice(c->device));
     Plan pl{};
     pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
-    pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK);
+    pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK, c->MA);
     pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
     pl.add_lds = 2 * c->PC + 2 * (c->PC - c->NC) + 64;
     pl.rows_lds = 0; pl.cons_lds = 0;

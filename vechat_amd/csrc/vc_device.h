@@ -7,13 +7,13 @@
 //   in-list / out-list of v     singly linked through the edges, append order == edge id order
 //                               (Graph::AddEdge appends to edges_, tail->outedges, head->inedges at once,
 //                               graph.cpp:94-107), so "list order" is reproduced by following next links
-//   al[v][0..al_cnt)            Node::aligned_nodes in append order (<= VC_MAXALN entries)
+//   al[v][0..al_cnt)            Node::aligned_nodes in append order; ma entries per node, ma = max(4, distinct bytes in the
+//                               batch - 1): the members of an aligned group carry distinct bytes (graph.cpp:258-277)
 //   e_tn[e] = tail | next_in<<16,  e_hn[e] = head | next_out<<16,  e_w[e] = Edge::weight
 #pragma once
 #include <stdint.h>
 
 #define VC_NONE16   0xFFFFu
-#define VC_MAXALN   4          // aligned group <= 5 members (A,C,G,T,N)
 #define VC_INLINE_PRED 6       // predecessors stored inline in a row record
 #define VC_MAXTIE   16         // NW end-cell ties remembered for the exact-rank resolver
 
@@ -32,7 +32,8 @@ struct VcGraph {
     uint16_t* out_first;
     uint16_t* out_last;
     uint8_t*  al_cnt;     // [CW*NC]
-    uint16_t* al;         // [CW*NC*VC_MAXALN]
+    uint16_t* al;         // [CW*NC*ma]
+    uint32_t  ma;         // entries per aligned list (even)
     uint32_t* e_tn;       // [CW*EC]
     uint32_t* e_hn;       // [CW*EC]
     uint32_t* e_w;        // [CW*EC]

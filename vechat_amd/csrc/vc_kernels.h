@@ -91,7 +91,8 @@ __device__ __forceinline__ uint4 vc_make_frec(uint32_t code, uint32_t fl, uint32
     if (hasprev) f |= VC_RF_PREV;
     if (is_ovf) {
         out[0] = dl[0]; out[1] = dl[1];                      // offset into VcDp::ovf
-        nq = np;
+        out[2] = dl[2]; out[3] = dl[3];                      // number of entries there
+        nq = min(np, 255u);
     } else {
 #pragma unroll
         for (int k = 0; k < VC_INLINE_PRED; ++k) {
@@ -205,19 +206,21 @@ __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, uint32_t w
 #define TF_MARK  0x03
 #define TF_IGN   0x04
 #define TF_SUB   0x08
-#define TF_CNTSH 4
 
 struct VcTopoLds {
-    uint16_t* in_first; uint32_t* etn; uint16_t* al; uint8_t* flag; uint16_t* stack; uint16_t* rank;
+    uint16_t* in_first; uint32_t* etn; uint16_t* al; uint8_t* flag; uint8_t* alc; uint16_t* stack; uint16_t* rank;
+    uint32_t ma;                  // entries per aligned list (VcGraph::ma)
 };
 
-__device__ __forceinline__ VcTopoLds vc_topo_carve(uint8_t* smem, uint32_t NC, uint32_t EC, uint32_t STK) {
+__device__ __forceinline__ VcTopoLds vc_topo_carve(uint8_t* smem, uint32_t NC, uint32_t EC, uint32_t STK, uint32_t MA) {
     VcTopoLds t;
+    t.ma = MA;
     t.in_first = (uint16_t*)smem;
     t.etn = (uint32_t*)(smem + ((2 * NC + 15) & ~15u));
     t.al = (uint16_t*)((uint8_t*)t.etn + 4 * EC);
-    t.flag = (uint8_t*)t.al + 8 * NC;
-    t.stack = (uint16_t*)(t.flag + ((NC + 15) & ~15u));
+    t.flag = (uint8_t*)t.al + 2 * MA * NC;
+    t.alc = t.flag + ((NC + 15) & ~15u);
+    t.stack = (uint16_t*)(t.alc + ((NC + 15) & ~15u));
     t.rank = t.stack + STK;
     return t;
 }
@@ -227,12 +230,13 @@ __device__ __forceinline__ void vc_topo_load(const VcGraph& g, uint64_t nb, uint
                                              const VcTopoLds& t, int lane) {
     for (uint32_t i = lane; i < N; i += 64) {
         t.in_first[i] = g.in_first[nb + i];
-        t.flag[i] = (uint8_t)(g.al_cnt[nb + i] << TF_CNTSH);
+        t.flag[i] = 0;
+        t.alc[i] = g.al_cnt[nb + i];
     }
     for (uint32_t i = lane; i < E; i += 64) t.etn[i] = g.e_tn[eb + i];
-    const uint2* src = (const uint2*)(g.al + nb * VC_MAXALN);
-    uint2* dst = (uint2*)t.al;
-    for (uint32_t i = lane; i < N; i += 64) dst[i] = src[i];
+    const uint32_t* src = (const uint32_t*)(g.al + nb * g.ma);            // ma is even: whole dwords
+    uint32_t* dst = (uint32_t*)t.al;
+    for (uint32_t i = lane; i < N * (g.ma / 2); i += 64) dst[i] = src[i];
 }
 
 // The serial, order-defining part: ExtractSubgraph flood (when masked) + TopologicalSort DFS.
@@ -256,10 +260,10 @@ __device__ int vc_topo_dfs(const VcTopoLds& ls, uint32_t N, uint32_t STK, bool m
                         ls.stack[sp++] = (uint16_t)(tn & 0xFFFF);
                         e = tn >> 16;
                     }
-                    uint32_t cnt = ls.flag[c] >> TF_CNTSH;
+                    uint32_t cnt = ls.alc[c];
                     for (uint32_t k = 0; k < cnt; ++k) {
                         if (sp >= STK) { err = VC_WIN_OVERFLOW; break; }
-                        ls.stack[sp++] = ls.al[c * VC_MAXALN + k];
+                        ls.stack[sp++] = ls.al[c * ls.ma + k];
                     }
                     ls.flag[c] |= TF_SUB;
                 }
@@ -291,10 +295,10 @@ __device__ int vc_topo_dfs(const VcTopoLds& ls, uint32_t N, uint32_t STK, bool m
                     }
                 }
                 if (err) break;
-                uint32_t cnt = fc >> TF_CNTSH;
+                uint32_t cnt = ls.alc[c];
                 if (!(fc & TF_IGN)) {
                     for (uint32_t k = 0; k < cnt; ++k) {
-                        uint32_t a = ls.al[c * VC_MAXALN + k];
+                        uint32_t a = ls.al[c * ls.ma + k];
                         uint8_t fa = ls.flag[a];
                         if ((fa & need) != need) continue;
                         if ((fa & TF_MARK) != 2) {
@@ -312,7 +316,7 @@ __device__ int vc_topo_dfs(const VcTopoLds& ls, uint32_t N, uint32_t STK, bool m
                     if (!(fc & TF_IGN)) {
                         ls.rank[nr++] = (uint16_t)c;
                         for (uint32_t k = 0; k < cnt; ++k) {
-                            uint32_t a = ls.al[c * VC_MAXALN + k];
+                            uint32_t a = ls.al[c * ls.ma + k];
                             if ((ls.flag[a] & need) != need) continue;
                             ls.rank[nr++] = (uint16_t)a;
                         }
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
 
     if (N > NCl || E > ECl) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 24, N); return; }
-    const VcTopoLds t = vc_topo_carve(ws ? ws + (size_t)blockIdx.x * ws_stride : smem, NCl, ECl, STK);
+    const VcTopoLds t = vc_topo_carve(ws ? ws + (size_t)blockIdx.x * ws_stride : smem, NCl, ECl, STK, g.ma);
     uint16_t* s_in_first = t.in_first; uint32_t* s_etn = t.etn; uint16_t* s_al = t.al;
     uint8_t* s_flag = t.flag; uint16_t* s_rank = t.rank;
     vc_topo_load(g, nb, eb, N, E, t, lane);
@@ -428,7 +432,6 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
         if (act) {
             if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }   // virtual row 0 is `row` rows above
-            if (np > 255) bad = 1;
             if (is_ovf) {
                 if (my_ovf + np > EC) bad = 1;
                 else {
@@ -444,10 +447,11 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
                     }
                 }
                 dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
+                dl[2] = (uint16_t)(np & 0xFFFF); dl[3] = (uint16_t)(np >> 16);      // the full count (the header field saturates at 255)
             }
             uint32_t fl = (s_hasout[v] ? 0u : VC_RF_SINK) | (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
             uint4 rec;
-            rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
+            rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (min(np, 255u) << 16);
             rec.y = dl[0] | ((uint32_t)dl[1] << 16);
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
@@ -545,7 +549,6 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
             const uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
             if (act_[u]) {
                 if (np == 0) { np = 1; dl_[u][0] = (uint16_t)(r + 1); }
-                if (np > 255) bad = 1;
                 if (is_ovf) {
                     if (my_ovf + np > EC) bad = 1;
                     else {
@@ -559,10 +562,11 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
                         }
                     }
                     dl_[u][0] = (uint16_t)(my_ovf & 0xFFFF); dl_[u][1] = (uint16_t)(my_ovf >> 16);
+                    dl_[u][2] = (uint16_t)(np & 0xFFFF); dl_[u][3] = (uint16_t)(np >> 16);
                 }
                 const uint32_t fl = (of_[u] == VC_NONE16 ? VC_RF_SINK : 0u) | (is_ovf ? VC_RF_OVF : 0u) | (hp_[u] ? VC_RF_PREV : 0u);
                 uint4 rec;
-                rec.x = cd_[u] | (fl << 8) | (np << 16);
+                rec.x = cd_[u] | (fl << 8) | (min(np, 255u) << 16);
                 rec.y = dl_[u][0] | ((uint32_t)dl_[u][1] << 16);
                 rec.z = dl_[u][2] | ((uint32_t)dl_[u][3] << 16);
                 rec.w = dl_[u][4] | ((uint32_t)dl_[u][5] << 16);
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
     uint32_t ptop = g.pos[nb + me];
     {
         const uint32_t cnt = g.al_cnt[nb + me];
-        for (uint32_t t = 0; t < cnt; ++t) ptop = max(ptop, (uint32_t)g.pos[nb + g.al[(nb + me) * VC_MAXALN + t]]);
+        for (uint32_t t = 0; t < cnt; ++t) ptop = max(ptop, (uint32_t)g.pos[nb + g.al[(nb + me) * g.ma + t]]);
     }
     int guard = 0;
     for (;;) {
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
                 }
                 const uint32_t cnt = g.al_cnt[nb + v];
                 for (uint32_t t = 0; t < cnt; ++t) {
-                    const uint32_t pa = g.pos[nb + g.al[(nb + v) * VC_MAXALN + t]];
+                    const uint32_t pa = g.pos[nb + g.al[(nb + v) * g.ma + t]];
                     if ((pa >> 6) == (uint32_t)B) pull |= 1ull << (pa & 63);
                     else if (pa <= ptop && is_mem(pa)) ext = true;
                 }
@@ -707,7 +711,6 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
         const uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
         if (act) {
             if (np == 0) { np = 1; dl[0] = (uint16_t)(r + 1); }
-            if (np > 255) bad = 1;
             if (is_ovf) {
                 if (my_ovf + np > EC) bad = 1;
                 else {
@@ -722,6 +725,7 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
                     }
                 }
                 dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
+                dl[2] = (uint16_t)(np & 0xFFFF); dl[3] = (uint16_t)(np >> 16);      // the full count (the header field saturates at 255)
             }
             bool hasout = false;                                // a sink of the subgraph has no member successor
             for (uint32_t e = g.out_first[nb + v]; e != VC_NONE16 && !hasout; ) {
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
             }
             const uint32_t fl = (hasout ? 0u : VC_RF_SINK) | (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
             uint4 rec;
-            rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (np << 16);
+            rec.x = (uint32_t)g.code[nb + v] | (fl << 8) | (min(np, 255u) << 16);
             rec.y = dl[0] | ((uint32_t)dl[1] << 16);
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
 // ------------------------------------------------------------------------------------------------
 __device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const VcBatchDev& b, const VcGraph& g, const VcDp& dp,
                                uint32_t w0, uint32_t nslots, uint32_t NC, uint32_t EC, uint32_t STK,
-                               const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end,
+                               const uint16_t* tie_rows, const uint32_t* tie_cnt, const uint32_t* tie_over, uint32_t tie_over_stride, uint32_t* job_end,
                                const uint32_t* submask, int layer, int force_dfs) {
     if (slot >= nslots) return;
     const uint32_t w = w0 + slot;
@@ -781,7 +785,7 @@ __device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const
     // Hence group A precedes group B if the smallest id that can reach A (forward closure of A over
     // out-edges and aligned links, F(A)) is smaller than that of B; and when min F(A) is itself a member
     // of A, that member is a root and therefore A's leader.  Anything else falls through to the DFS.
-    {
+    if (nt <= VC_MAXTIE) {
         uint32_t* s_vis = (uint32_t*)smem;                        // bitmap [N]
         uint16_t* s_stk = (uint16_t*)(smem + 4 * ((NC + 31) / 32 + 1));   // [256]
         __shared__ uint32_t s_fast;                                // winning row, 0 = undecided
@@ -797,7 +801,7 @@ __device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const
                 uint32_t gm = node[k];
                 const uint32_t cnt = g.al_cnt[nb + node[k]];
                 for (uint32_t t2 = 0; t2 < cnt; ++t2) {
-                    const uint32_t mnode = g.al[(nb + node[k]) * VC_MAXALN + t2];
+                    const uint32_t mnode = g.al[(nb + node[k]) * g.ma + t2];
                     if (in_sub(mnode)) gm = min(gm, mnode);
                 }
                 gid[k] = gm; rmin[k] = 0xFFFFFFFFu; lead[k] = false;
@@ -825,13 +829,13 @@ __device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const
                         e = hn >> 16;
                     }
                     const uint32_t cnt = g.al_cnt[nb + v];
-                    for (uint32_t t2 = 0; t2 < cnt; ++t2) push(g.al[(nb + v) * VC_MAXALN + t2]);
+                    for (uint32_t t2 = 0; t2 < cnt; ++t2) push(g.al[(nb + v) * g.ma + t2]);
                 }
                 rmin[k] = mn;
                 // is the smallest id a member of the group?
                 bool member = mn == node[k];
                 const uint32_t cnt = g.al_cnt[nb + node[k]];
-                for (uint32_t t2 = 0; t2 < cnt; ++t2) member = member || mn == g.al[(nb + node[k]) * VC_MAXALN + t2];   // mn is in the subgraph
+                for (uint32_t t2 = 0; t2 < cnt; ++t2) member = member || mn == g.al[(nb + node[k]) * g.ma + t2];   // mn is in the subgraph
                 lead[k] = member;
                 // groups are disjoint and closures of different tied groups must not share the bitmap
                 for (uint32_t i2 = 0; i2 < (N + 31) / 32; ++i2) s_vis[i2] = 0;
@@ -854,7 +858,7 @@ __device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const
                         for (uint32_t k = 0; k < nt && !win; ++k) if (gid[k] == bestg && node[k] == L) win = row[k];
                         const uint32_t cnt = g.al_cnt[nb + L];
                         for (uint32_t t2 = 0; t2 < cnt && !win; ++t2) {
-                            const uint32_t mnode = g.al[(nb + L) * VC_MAXALN + t2];
+                            const uint32_t mnode = g.al[(nb + L) * g.ma + t2];
                             for (uint32_t k = 0; k < nt; ++k) if (gid[k] == bestg && node[k] == mnode) { win = row[k]; break; }
                         }
                     }
@@ -870,7 +874,7 @@ __device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const
     // exact DFS for what the shortcut left undecided.  It is rare (none in the benchmark workload), so it
     // works out of this workgroup's HBM workspace: the kernel then needs ~1 KB of LDS and can start next
     // to the forward kernel of another chunk instead of waiting for 60 KB to drain.
-    const VcTopoLds t = vc_topo_carve(gws, NC, EC, STK);
+    const VcTopoLds t = vc_topo_carve(gws, NC, EC, STK, g.ma);
     vc_topo_load(g, nb, eb, N, E, t, lane);
     __threadfence_block();
     __syncthreads();
@@ -886,17 +890,24 @@ __device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const
     __threadfence_block();
     __syncthreads();
     if (s_err) { if (lane == 0) vc_fail(b, w, s_err, 14, s_nrows); return; }
-    // exact rank of each tied row's node
-    uint32_t myrank = 0xFFFFFFFFu, myrow = 0;
-    if ((uint32_t)lane < nt) {
-        myrow = tie_rows[(uint64_t)slot * VC_MAXTIE + lane];
-        const uint32_t node = dp.rank2node[nb + myrow - 1];
-        for (uint32_t r = 0; r < s_nrows; ++r) if (t.rank[r] == node) { myrank = r; break; }
+    // exact rank of each tied row's node: the smallest wins (64 ties per sweep; ties beyond VC_MAXTIE sit in tie_over)
+    uint32_t best_rank = 0xFFFFFFFFu, row = 0;
+    for (uint32_t base = 0; base < nt; base += 64) {
+        const uint32_t kk = base + lane;
+        uint32_t myrank = 0xFFFFFFFFu, myrow = 0;
+        if (kk < nt) {
+            myrow = kk < VC_MAXTIE ? (uint32_t)tie_rows[(uint64_t)slot * VC_MAXTIE + kk] : tie_over[(uint64_t)slot * tie_over_stride + kk];
+            const uint32_t node = dp.rank2node[nb + myrow - 1];
+            for (uint32_t r = 0; r < s_nrows; ++r) if (t.rank[r] == node) { myrank = r; break; }
+        }
+        const uint32_t best = wave_min_u32(myrank);
+        if (best < best_rank) {
+            const unsigned long long m = __ballot(myrank == best && kk < nt);
+            const int src = __ffsll((long long)m) - 1;
+            row = (uint32_t)__shfl((int)myrow, src, 64);
+            best_rank = best;
+        }
     }
-    const uint32_t best = wave_min_u32(myrank);
-    const unsigned long long m = __ballot(myrank == best && (uint32_t)lane < nt);
-    const int src = __ffsll((long long)m) - 1;
-    const uint32_t row = (uint32_t)__shfl((int)myrow, src, 64);
     if (lane == 0) job_end[slot] = (row << 16) | (job_end[slot] & 0xFFFF);
 }
 
@@ -904,7 +915,7 @@ __device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const
 // so the thousands of untied windows cost nothing and nobody parks 60 KB of LDS per window
 __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                                 uint32_t NC, uint32_t EC, uint32_t STK,
-                                                const uint16_t* tie_rows, const uint8_t* tie_cnt, uint32_t* job_end,
+                                                const uint16_t* tie_rows, const uint32_t* tie_cnt, const uint32_t* tie_over, uint32_t tie_over_stride, uint32_t* job_end,
                                                 const uint32_t* tie_list, const uint32_t* tie_n,
                                                 const uint32_t* submask, int layer, uint8_t* workspace, uint32_t ws_bytes, int force_dfs) {
     VC_LATENCY_KERNEL_PRIO();
@@ -912,7 +923,7 @@ __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp
     const uint32_t n = *tie_n;
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
         __syncthreads();
-        vc_resolve_one(smem, workspace + (size_t)blockIdx.x * ws_bytes, tie_list[idx], b, g, dp, w0, nslots, NC, EC, STK, tie_rows, tie_cnt,
+        vc_resolve_one(smem, workspace + (size_t)blockIdx.x * ws_bytes, tie_list[idx], b, g, dp, w0, nslots, NC, EC, STK, tie_rows, tie_cnt, tie_over, tie_over_stride,
                        job_end, submask, layer, force_dfs);
     }
 }
@@ -944,7 +955,9 @@ struct VcFwdArgs {
     uint32_t* job_end;             // [jobs] (row << 16) | col ; 0 = empty alignment
     uint8_t*  job_type;            // [jobs] 0 SW, 1 NW, 255 skipped
     uint16_t* tie_rows;            // [jobs * VC_MAXTIE] NW: sink rows sharing the best end score (incremental order only)
-    uint8_t*  tie_cnt;             // [jobs]
+    uint32_t* tie_cnt;             // [jobs]
+    uint32_t* tie_over;            // build phase: [jobs * tie_over_stride] ties beyond VC_MAXTIE (the job's pair list, not yet in use); else null
+    uint32_t  tie_over_stride;
     uint32_t* tie_list;            // [jobs] windows whose alignment ended in a tie (build phase)
     uint32_t* tie_n;               // [1]
     unsigned long long* stat;      // [4] cells, rows, -, far-row reads
@@ -1195,7 +1208,8 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
                 // back from the stored matrix in HBM; long lists come from VcDp::ovf
                 const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
                 const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
-                for (uint32_t p = 0; p < nq; ++p) {
+                const uint32_t nlist = (fl & VC_RF_OVF) ? r2 : nq;
+                for (uint32_t p = 0; p < nlist; ++p) {
                     uint32_t delta;
                     if (fl & VC_RF_OVF) {
                         delta = ovfp[r1 + p];
@@ -1296,7 +1310,10 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
                     best = v; best_row = i; ntie = 1;
                     if (lane == 0) a.tie_rows[(uint64_t)job * VC_MAXTIE] = (uint16_t)i;
                 } else if (v == best) {
-                    if (ntie < VC_MAXTIE && lane == 0) a.tie_rows[(uint64_t)job * VC_MAXTIE + ntie] = (uint16_t)i;
+                    if (lane == 0) {
+                        if (ntie < VC_MAXTIE) a.tie_rows[(uint64_t)job * VC_MAXTIE + ntie] = (uint16_t)i;
+                        else if (a.tie_over && ntie < a.tie_over_stride) a.tie_over[(uint64_t)job * a.tie_over_stride + ntie] = i;
+                    }
                     ntie++;
                 }
             }
@@ -1350,8 +1367,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     if (nw) {
         end = (best_row << 16) | len;
         if (ntie > 1 && (a.dp.flags[slot] & 2u)) {          // tie on a non-reference order: k_resolve decides
-            if (ntie > VC_MAXTIE) { if (lane == 0) vc_fail(a.b, w, VC_WIN_UNSUPPORTED, 15, ntie); }
-            else if (lane == 0) { a.tie_cnt[job] = (uint8_t)ntie; a.tie_list[atomicAdd(a.tie_n, 1u)] = slot; }
+            if (lane == 0) { a.tie_cnt[job] = ntie; a.tie_list[atomicAdd(a.tie_n, 1u)] = slot; }
         }
     } else {
         const int gmax = wave_max_i32(best);
@@ -1499,8 +1515,8 @@ __global__ void k_trace(VcTraceArgs a) {
             uint4 nrec = zero4;
             bool found = false, have_nrec = false;
             if (i != 0) {
-                const uint32_t np = (rec.x >> 16) & 0xFF;
                 const bool isovf = ((rec.x >> 8) & VC_RF_OVF) != 0;
+                const uint32_t np = isovf ? rec.z : ((rec.x >> 16) & 0xFF);
                 auto delta_of = [&](uint32_t p) -> uint32_t {
                     if (isovf) return a.dp.ovf[eb + rec.y + p];
                     const uint32_t wsel = p < 2 ? rec.y : (p < 4 ? rec.z : rec.w);
@@ -1763,8 +1779,8 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
             uint32_t v_pi = 0; int v_hv = 0; uint4 v_rec = zero4;
             int hz = 0;                                                  // lane 15 of the group: T[gi][gj-1]
             if (need && gl == VC_TL - 1 && gj != 0) hz = Tat(gi, gj - 1);
-            const uint32_t np = (need && gi != 0) ? ((grec.x >> 16) & 0xFF) : 0u;
             const bool isovf = ((grec.x >> 8) & VC_RF_OVF) != 0;
+            const uint32_t np = (need && gi != 0) ? (isovf ? grec.z : ((grec.x >> 16) & 0xFF)) : 0u;
             int sc = 0;
             if (np && gj != 0) sc = ((a.b.bases[so + gj - 1] == (grec.x & 0xFF)) ? m : n) - g;
             const bool isd = gl < 7, isv = gl >= 8 && gl < 15;
@@ -1891,7 +1907,7 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
                 uint32_t bs = pn, be = pn;
                 const uint32_t cnt = a.g.al_cnt[nb + nd];
                 for (uint32_t t = 0; t < cnt; ++t) {
-                    const uint32_t pa = a.g.pos[nb + a.g.al[(nb + nd) * VC_MAXALN + t]];
+                    const uint32_t pa = a.g.pos[nb + a.g.al[(nb + nd) * a.g.ma + t]];
                     bs = min(bs, pa); be = max(be, pa);
                 }
                 s_pn[f] = (uint16_t)pn; s_bs[f] = (uint16_t)bs; s_be[f] = (uint16_t)be;
@@ -1906,7 +1922,7 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
                 else {
                     const uint32_t cnt = a.g.al_cnt[nb + nd];
                     for (uint32_t t = 0; t < cnt; ++t) {                   // :258-266
-                        const uint32_t al = a.g.al[(nb + nd) * VC_MAXALN + t];
+                        const uint32_t al = a.g.al[(nb + nd) * a.g.ma + t];
                         if (a.g.code[nb + al] == c) { curr = al; break; }
                     }
                     if (curr == VC_NONE16) isnew = true;                   // :267-277
@@ -1943,26 +1959,26 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
         if (row != 0) {
             const uint32_t nd = a.dp.rank2node[nb + row - 1];
             const uint32_t cnt = a.g.al_cnt[nb + nd];
-            if (cnt + 1 > VC_MAXALN) { err = VC_WIN_UNSUPPORTED; }
+            if (cnt + 1 > a.g.ma) { err = VC_WIN_INVALID; }              // cannot happen: a group holds distinct bytes, ma >= alphabet - 1
             else {
                 for (uint32_t t = 0; t < cnt; ++t) {
-                    const uint32_t al = a.g.al[(nb + nd) * VC_MAXALN + t];
+                    const uint32_t al = a.g.al[(nb + nd) * a.g.ma + t];
                     const uint32_t ac = a.g.al_cnt[nb + al];
-                    if (ac + 1 > VC_MAXALN) { err = VC_WIN_UNSUPPORTED; break; }
-                    a.g.al[(nb + al) * VC_MAXALN + ac] = (uint16_t)curr;
+                    if (ac + 1 > a.g.ma) { err = VC_WIN_INVALID; break; }
+                    a.g.al[(nb + al) * a.g.ma + ac] = (uint16_t)curr;
                     a.g.al_cnt[nb + al] = (uint8_t)(ac + 1);
-                    a.g.al[(nb + curr) * VC_MAXALN + t] = (uint16_t)al;
+                    a.g.al[(nb + curr) * a.g.ma + t] = (uint16_t)al;
                 }
-                a.g.al[(nb + nd) * VC_MAXALN + cnt] = (uint16_t)curr;
+                a.g.al[(nb + nd) * a.g.ma + cnt] = (uint16_t)curr;
                 a.g.al_cnt[nb + nd] = (uint8_t)(cnt + 1);
-                a.g.al[(nb + curr) * VC_MAXALN + cnt] = (uint16_t)nd;
+                a.g.al[(nb + curr) * a.g.ma + cnt] = (uint16_t)nd;
                 mycnt = cnt + 1;
             }
         }
         a.g.al_cnt[nb + curr] = (uint8_t)mycnt;
         a.g.visits[nb + curr] = 0;
     }
-    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_UNSUPPORTED, 7, 0); return; }
+    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 7, 0); return; }
     __syncthreads();      // pass B's stores are complete before pass C touches the same nodes
 
     // every node on the path gains this sequence's label on an adjacent edge (Node::Coverage, graph.cpp:38-56)
@@ -2465,7 +2481,7 @@ __global__ __launch_bounds__(64) void k_consensus(VcConsArgs a) {
         const uint32_t v = s_cons[i];
         uint32_t cv = a.g.visits[nb + v];
         const uint32_t cnt = a.g.al_cnt[nb + v];
-        for (uint32_t t = 0; t < cnt; ++t) cv += a.g.visits[nb + a.g.al[(nb + v) * VC_MAXALN + t]];
+        for (uint32_t t = 0; t < cnt; ++t) cv += a.g.visits[nb + a.g.al[(nb + v) * a.g.ma + t]];
         s_cov[i] = (uint16_t)(cv > 0xFFFF ? 0xFFFF : cv);
     }
     __syncthreads();
@@ -2486,6 +2502,31 @@ __global__ __launch_bounds__(64) void k_consensus(VcConsArgs a) {
     if (outn > a.b.cons_cap) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 18, outn); return; }
     for (uint32_t i = lane; i < outn; i += 64) a.b.cons[(uint64_t)w * a.b.cons_cap + i] = a.g.code[nb + s_cons[begin + i]];
     if (lane == 0) a.b.cons_len[w] = outn;
+}
+
+// which byte values occur in the batch (256-bit mask): sizes the aligned lists (VcGraph::ma)
+__global__ void k_byte_presence(const uint8_t* bases, uint64_t n, uint32_t* mask) {
+    __shared__ uint32_t s_m[8];
+    if (threadIdx.x < 8) s_m[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += stride) {
+        if (i + 16 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4*>(bases + i);           // the buffer is 16-byte aligned and padded
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { const uint32_t c = (w[k] >> (8 * b)) & 0xFF; m[c >> 5] |= 1u << (c & 31); }
+        } else {
+            for (uint64_t j = i; j < n; ++j) { const uint32_t c = bases[j]; m[c >> 5] |= 1u << (c & 31); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (m[k]) atomicOr(&s_m[k], m[k]);
+    __syncthreads();
+    if (threadIdx.x < 8 && s_m[threadIdx.x]) atomicOr(&mask[threadIdx.x], s_m[threadIdx.x]);
 }
 
 __global__ void k_max_u32(const uint32_t* v, uint32_t n, uint32_t* out) {
