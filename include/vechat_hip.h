@@ -36,7 +36,7 @@ enum {
     VC_WIN_OK          = 0,  /* consensus produced; generate_consensus() would return true      */
     VC_WIN_UNPOLISHED  = 1,  /* < 3 sequences: backbone copied, returns false (window.cpp:188-192) */
     VC_WIN_OVERFLOW    = 2,  /* graph outgrew max_nodes/max_edges/stack: resubmit with larger caps */
-    VC_WIN_UNSUPPORTED = 3,  /* outside the kernels' envelope (score range, in-degree, alphabet)  */
+    VC_WIN_UNSUPPORTED = 3,  /* reserved: no longer produced (every valid window is computed on the device) */
     VC_WIN_INVALID     = 4   /* input the reference would throw on (graph.cpp:191-231)          */
 };
 

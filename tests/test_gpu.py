@@ -204,21 +204,32 @@ def test_graph_images_beyond_the_lds_use_the_hbm_workspace(built):
     c.close()
 
 
-def test_overlong_sequence_is_a_per_window_status(built):
-    """A layer longer than the forward kernel's 2 048 columns marks ITS window unsupported; the rest of the
-    batch is processed and stays byte-identical to the oracle."""
+def test_sequences_beyond_2048_columns_and_int32_scores(built):
+    """What the packed-int16 kernel declines goes to k_fwd_wide (int32 lanes, column tiles) instead of being refused:
+    `-w 3000`-style windows (layers of ~3 000 columns, full and partial spans, both overloads), a window whose one layer
+    is longer than 2 048 columns next to ordinary ones, and score sets whose worst case leaves int16 half way through a
+    window (the reference's switch to 32-bit lanes, simd_alignment_engine_implementation.hpp:699-706)."""
+    big = capi.synth_batch(capi.synth_cfg(3001, 3000, 12, frac_partial=0.25), 0, 3)
+    for mode in (0, 1):
+        c = HipContext(device=0, mode=mode)
+        st = _check(c, big, f"3 kb windows mode{mode}")
+        assert c.stats()["cells"] == st.cells
+        c.close()
     good = capi.synth_batch(capi.synth_cfg(81, 120, 6), 0, 3)
     wins = [good.window(w) for w in range(3)]
     seqs, quals, b, e = good.window(1)
     long_layer = (seqs[1] * 20)[:2100]
-    bad = (seqs[:1] + [long_layer] + seqs[2:], quals[:1] + [None] + quals[2:], b, e)
-    batch = capi.Batch.from_windows([wins[0], bad, wins[2]], [0, 0, 0], presorted=True)
+    mixed = capi.Batch.from_windows([wins[0], (seqs[:1] + [long_layer] + seqs[2:], quals[:1] + [None] + quals[2:], b, e), wins[2]],
+                                    [0, 0, 0], presorted=True)
     c = HipContext(device=0)
-    cons, status = c.consensus(batch, retry_overflow=False)
-    assert int(status[1]) == capi.VC_WIN_UNSUPPORTED and cons[1] == b""
-    ref, pol, _ = oa.oracle_run(good, c.params)
-    for w in (0, 2):
-        assert int(status[w]) == capi.VC_WIN_OK and cons[w] == ref[w]
+    _check(c, mixed, "one overlong layer")
+    c.close()
+    deep = capi.synth_batch(capi.synth_cfg(3002, 1000, 48, profile=capi.ONT, frac_partial=0.2), 0, 2)
+    c = HipContext(device=0, match=5, mismatch=-4, gap=-8)          # -8 * (len + 8 + rows) passes -31744 around 3 000 rows
+    _check(c, deep, "int32 score range")
+    c.close()
+    c = HipContext(device=0, match=2, mismatch=-3, gap=-12, sw_match=4, sw_mismatch=1, sw_gap=-2)     # unusual signs and magnitudes
+    _check(c, capi.synth_batch(capi.synth_cfg(3003, 300, 16, frac_partial=0.3), 0, 4), "odd scores")
     c.close()
 
 

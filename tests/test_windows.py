@@ -158,3 +158,22 @@ def test_plumbing_fixture_through_the_oracle(built, mode, key):
     st = wb.stitch(cons, [capi.VC_WIN_OK if x else capi.VC_WIN_UNPOLISHED for x in pol])
     assert [[n, d.decode()] for n, d in st] == exp["stitched"]
     wb.close()
+
+
+def test_cigar_that_overruns_the_read_is_rejected(built):
+    """A CIGAR consuming more query / target than the overlap's spans must be refused when the overlap is added (it would
+    put breaking points past the end of the read)."""
+    import ctypes as C
+    from vechat_amd import capi
+    lib = capi.load_host()
+    wb = lib.vc_wb_create(500, 10.0)
+    t = b"ACGT" * 300
+    r = b"ACGT" * 50
+    assert lib.vc_wb_add_sequence(wb, b"t", t, len(t), None) == 0
+    assert lib.vc_wb_add_sequence(wb, b"r", r, len(r), None) == 1
+    assert lib.vc_wb_set_targets(wb, 1) == 0
+    assert lib.vc_wb_add_overlap(wb, 1, 0, 0, 0, 200, 200, 0, 200, b"200M") == 0
+    assert lib.vc_wb_add_overlap(wb, 1, 0, 0, 0, 200, 200, 0, 1000, b"1000M") != 0
+    assert b"CIGAR" in lib.vc_wb_last_error(wb)
+    assert lib.vc_wb_add_overlap(wb, 1, 0, 0, 0, 200, 200, 0, 200, b"150M") != 0
+    lib.vc_wb_destroy(wb)

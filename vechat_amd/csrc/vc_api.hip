@@ -36,7 +36,7 @@ constexpr int kRing = 8;      // DP rows kept in LDS per alignment (k_topo / k_r
 constexpr int kMaxStreams = 4;
 constexpr uint32_t kTraceTabRows = 8188;           // rows covered by k_tracew's first-in-edge table (4 tables x 2 B x 8192 = 64 KB); later rows are walked without speculation
 constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may ask for (160 KB per CU minus room for static __shared__)
-constexpr uint64_t kMaxColumns = 2048;     // longest sequence k_fwd takes (64 lanes x 32 columns)
+constexpr uint32_t kMaxColumns = 2048;     // longest sequence the packed-int16 k_fwd takes (64 lanes x 32 columns); longer ones go to k_fwd_wide
 constexpr uint32_t kResolveGrid = 128;   // workgroups of k_resolve (each owns one DFS workspace in HBM)
 
 uint32_t topo_lds_bytes(uint32_t NC, uint32_t EC, uint32_t STK, uint32_t MA) {
@@ -48,6 +48,7 @@ struct Work {
     hipStream_t stream = nullptr;
     VcGraph gr[2]{};
     VcDp dp{};
+    int* d_wmat = nullptr; int* d_c0w = nullptr;         // k_fwd_wide: [jobs_cap * NC * wcols] tilted int32 scores, [jobs_cap * NC] column 0
     uint32_t* d_hmat = nullptr; int16_t* d_c0 = nullptr; uint8_t* d_resolve_ws = nullptr;
     uint8_t* d_big_ws = nullptr;        // [CW * big_ws_stride] graph images that do not fit the LDS (k_topo / k_prune_lcc / k_consensus)
     uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
@@ -92,6 +93,7 @@ struct vc_ctx {
     uint32_t* d_lut_w = nullptr; double* d_lut_d = nullptr;
     unsigned long long* d_stat = nullptr;   // [VC_STAT_SLOTS][8] cells, rows, -, far-row reads, trace steps, speculated steps, rounds, -
 
+    uint32_t wcols = 0;                  // != 0: some alignment may need k_fwd_wide; columns of its int32 matrices (multiple of 512)
     uint32_t MA = 4;                     // entries per aligned list: max(4, distinct bytes in the batch - 1), even
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
@@ -203,6 +205,8 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->d_resolve_ws, (size_t)kResolveGrid * ((topo_lds_bytes(NC, c->EC, c->STK, c->MA) + 15u) & ~15u))) ||
         (c->big_ws_stride && (rc = dalloc(c, c->chunk_allocs, &wk->d_big_ws, (size_t)CW * c->big_ws_stride))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_c0, (size_t)c->jobs_cap * NC)) ||
+        (c->wcols && ((rc = dalloc(c, c->chunk_allocs, &wk->d_wmat, (size_t)c->jobs_cap * NC * c->wcols)) ||
+                      (rc = dalloc(c, c->chunk_allocs, &wk->d_c0w, (size_t)c->jobs_cap * NC)))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_end, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_job_type, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_tie_rows, (size_t)c->jobs_cap * VC_MAXTIE)) ||
@@ -277,15 +281,18 @@ void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs) {
 
 // One launch when the batch's sequences fall into one width class or two adjacent ones (the usual case:
 // read pieces of a window differ by a few percent in length); otherwise one launch per class.
-int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs) {
+int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, const Work* wk = nullptr) {
     const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
     VcFwdArgs a = a0;
     a.do_init = 1;
     int lo = -1, hi = -1;
     for (int i = 0; i < 9; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
     if (lo < 0 || hi < 0) return fail(c, VC_ERR_ARG, "unsupported cells-per-lane %u..%u", c->cpl_min, c->cpl);
+    auto wide = [&]() {                     // alignments the packed-int16 kernels declined (their job_type is still 255)
+        if (c->wcols && wk) { Timer t(c, KC_FWD, st); hipLaunchKernelGGL(k_fwd_wide, dim3(jobs), dim3(64), 0, st, a, wk->d_wmat, (uint64_t)c->NC * c->wcols, c->wcols, wk->d_c0w); }
+    };
     if (hi - lo == 1) {
-        Timer t(c, KC_FWD, st);
+        { Timer t(c, KC_FWD, st);
         switch (hi) {
             case 1: launch_fwd_t<4, 6>(st, a, jobs); break;
             case 2: launch_fwd_t<6, 8>(st, a, jobs); break;
@@ -296,6 +303,8 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs) {
             case 7: launch_fwd_t<20, 24>(st, a, jobs); break;
             case 8: launch_fwd_t<24, 32>(st, a, jobs); break;
         }
+        }
+        wide();
         return VC_OK;
     }
     for (int i = lo; i <= hi; ++i) {
@@ -313,6 +322,7 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs) {
         }
         a.do_init = 0;
     }
+    wide();
     return VC_OK;
 }
 
@@ -343,6 +353,7 @@ struct Plan {
         ta.b = c->b; ta.dp = wk.dp; ta.w0 = wk.w0; ta.nslots = wk.ns; ta.NC = NC; ta.EC = EC; ta.cpl = cpl;
         ta.m = c->prm.match; ta.n = c->prm.mismatch; ta.g = c->prm.gap;
         ta.sm = c->prm.sw_match; ta.sn = c->prm.sw_mismatch; ta.sg = c->prm.sw_gap;
+        ta.wmat = wk.d_wmat; ta.wstride = (uint64_t)NC * c->wcols; ta.wcols = c->wcols; ta.c0w = wk.d_c0w; ta.only_wide = 0;
         ta.stat = c->d_stat; ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC;
         return ta;
     }
@@ -374,7 +385,7 @@ struct Plan {
         fa.group = 1; fa.k0 = j; fa.mode = 0; fa.hstride = (uint64_t)NC * rowd;
         fa.tie_over = wk.d_pairs; fa.tie_over_stride = PC;      // the pair list of the job is written only after k_resolve
         HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
-        int rc = launch_fwd(c, wk.stream, fa, ns);
+        int rc = launch_fwd(c, wk.stream, fa, ns, &wk);
         if (rc) return rc;
         { Timer t(c, KC_RESOLVE, wk.stream);
           const uint32_t rs_lds = 4 * ((NC + 31) / 32 + 1) + 2 * 256 + 16;
@@ -387,7 +398,8 @@ struct Plan {
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
         { Timer t(c, KC_TRACE, wk.stream);
           if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = std::min(NC, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, false), wk.stream, ta); }
-          else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
+          else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta);
+          if (c->wcols && c->trace_wave) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); } }
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
         aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16;
@@ -445,13 +457,14 @@ struct Plan {
         for (uint32_t k0 = 0; k0 < wk.nseq_max; k0 += group) {
             const uint32_t gsz = std::min(group, wk.nseq_max - k0);
             fa.group = gsz; fa.k0 = k0; fa.mode = 1; fa.hstride = stride;
-            int rc = launch_fwd(c, wk.stream, fa, ns * gsz);
+            int rc = launch_fwd(c, wk.stream, fa, ns * gsz, &wk);
             if (rc) return rc;
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
             { Timer t(c, KC_TRACE, wk.stream);
           if (c->trace_wave) { ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = std::min(maxn, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns * gsz + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0), wk.stream, ta); }
-          else hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
+          else hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta);
+          if (c->wcols && c->trace_wave) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); ta.only_wide = 0; } }
         }
         VcAddwArgs wa{};
         wa.b = c->b; wa.g = wk.gr[wk.cur]; wa.dp = wk.dp; wa.w0 = wk.w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
@@ -480,14 +493,15 @@ struct Plan {
         const uint32_t ns = wk.ns;
         VcFwdArgs fa = fwd_args(wk);
         fa.group = 1; fa.k0 = 0; fa.mode = 2; fa.hstride = (uint64_t)NC * rowd;
-        int rc = launch_fwd(c, wk.stream, fa, ns);
+        int rc = launch_fwd(c, wk.stream, fa, ns, &wk);
         if (rc) return rc;
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
         { Timer t(c, KC_TRACE, wk.stream);
           if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = std::min(NC, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, false), wk.stream, ta); }
-          else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); }
+          else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta);
+          if (c->wcols && c->trace_wave) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); } }
         VcFinishArgs fn{};
         fn.b = c->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;
         fn.pairs = wk.d_pairs; fn.npairs = wk.d_npairs; fn.PC = PC;
@@ -600,8 +614,6 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         if (L == 0 || L >= 65535) return fail(c, VC_ERR_ARG, "window %u: backbone length %llu unsupported", w, (unsigned long long)L);
         if (!hb->seq_has_qual[s0]) return fail(c, VC_ERR_ARG, "window %u: backbone needs a quality string (dummy '!' for FASTA targets)", w);
         uint64_t sum = 0;
-        for (uint32_t s = s0; s < s1; ++s)                        // the forward kernel holds at most 64 lanes x 32 columns
-            if (s1 - s0 >= 3 && hb->seq_off[s + 1] - hb->seq_off[s] > kMaxColumns) pre[w] = VC_WIN_UNSUPPORTED;
         for (uint32_t s = s0; s < s1; ++s) {
             const uint64_t len = hb->seq_off[s + 1] - hb->seq_off[s];
             if (len == 0 || len >= 65535) return fail(c, VC_ERR_ARG, "window %u: sequence length %llu unsupported", w, (unsigned long long)len);
@@ -676,15 +688,15 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     }
 
     // capacities
-    uint32_t NC = c->prm.max_nodes ? c->prm.max_nodes : (uint32_t)std::min<uint64_t>(need_nodes, 60000);
+    uint32_t NC = c->prm.max_nodes ? c->prm.max_nodes : (uint32_t)std::min<uint64_t>(need_nodes, 59968);
     NC = (NC + 63) & ~63u;
+    if (!c->prm.max_nodes && NC > 59968) NC = 59968;
     uint32_t EC = c->prm.max_edges ? c->prm.max_edges : (uint32_t)std::min<uint64_t>((uint64_t)(2.6 * NC), 32000);
     EC = (EC + 63) & ~63u;
-    if (EC > 32000) EC = 32000;
-    if (NC > 60000) return fail(c, VC_ERR_ARG, "max_nodes %u exceeds the 16-bit id space", NC);
-    const uint32_t cpl = pick_cpl(max_len);
-    c->cpl_min = pick_cpl(min_len);
-    if (!cpl) return fail(c, VC_ERR_ARG, "sequence length %u exceeds the kernels' 2048-column envelope", max_len);
+    if (EC > 32000) EC = 32000;                     // k_prune_lcc keeps 2E adjacency offsets in 16 bits
+    if (NC > 59968) return fail(c, VC_ERR_ARG, "max_nodes %u exceeds the 16-bit id space (59968)", NC);
+    const uint32_t cpl = pick_cpl(std::min(max_len, kMaxColumns));
+    c->cpl_min = pick_cpl(std::min(min_len, kMaxColumns));
     const uint32_t lds_cap = kLdsCap;
     // graph images that do not fit the LDS are worked on in an HBM workspace (slower, not refused)
     uint32_t big = 0;
@@ -703,23 +715,33 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint64_t rowd = 64ull * (cpl / 2);
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
-    const uint64_t per_job = NC * rowd * 4 + NC * 2 + 8 + 2 * VC_MAXTIE + 8;
+    // Can any alignment of this batch leave the packed-int16 kernel's envelope (vc_fwd_body's check: the reference's int16
+    // rule, simd impl:699-706, on the worst case the capacities allow)?  Then k_fwd_wide and its int32 matrices are needed.
+    bool maybe_wide = max_len > kMaxColumns;
+    for (int sw = 0; sw < 2; ++sw) {
+        const long long mm = sw ? c->prm.sw_match : c->prm.match, nn = sw ? c->prm.sw_mismatch : c->prm.mismatch, gg = sw ? c->prm.sw_gap : c->prm.gap;
+        const long long li = (long long)std::min(max_len, kMaxColumns) + 8, lj = NC, mn = std::min(li, lj), d = li > lj ? li - lj : lj - li;
+        const long long wc = std::min(-(mm * mn + (d ? gg * d : 0)), gg * li + gg * lj);
+        if (wc < -31744 || (mm - gg) * (64ll * cpl + 1) >= 32767 || (sw && nn >= 0)) maybe_wide = true;
+    }
+    const uint32_t wcols = maybe_wide ? ((max_len + 64 * VC_WIDE_CPL - 1) / (64 * VC_WIDE_CPL)) * (64 * VC_WIDE_CPL) : 0;
+    const uint64_t per_job = NC * rowd * 4 + NC * 2 + 8 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);
     if (CW == 0) CW = 1;
-    while (CW > 64 && (per_slot_fixed + per_job) * CW > budget) CW /= 2;
+    while (CW > 1 && (per_slot_fixed + per_job) * CW > budget) CW /= 2;
     if ((per_slot_fixed + per_job) * CW > budget) return fail(c, VC_ERR_ARG, "scratch budget %llu too small", (unsigned long long)budget);
     // spare matrix space lets re-alignment rounds run several sequences of a window per launch
     uint64_t spare = budget - (per_slot_fixed + per_job) * CW;
     uint32_t group_max = 1 + (uint32_t)std::min<uint64_t>(spare / (per_job * CW), 7);
     if (group_max > max_nseq) group_max = max_nseq;
 
-    const bool same = c->MA == MA && c->NC == NC && c->EC == EC && c->CW == CW && c->cpl == cpl && c->PC == PC && c->big_ws_stride == big &&
+    const bool same = c->wcols == wcols && c->MA == MA && c->NC == NC && c->EC == EC && c->CW == CW && c->cpl == cpl && c->PC == PC && c->big_ws_stride == big &&
                       c->group_max == group_max && c->max_nseq == max_nseq && !c->chunk_allocs.empty();
     if (!same) {
         free_list(c->chunk_allocs);
         c->chunk_bytes = 0;
-        c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
+        c->wcols = wcols; c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
         c->big_ws_stride = big;
         c->jobs_cap = CW * group_max;
         c->hmat_dwords = (uint64_t)c->jobs_cap * NC * rowd;

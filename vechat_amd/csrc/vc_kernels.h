@@ -1093,7 +1093,9 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         bool ok = wc >= -31744 && ((long long)(m - g) * (64 * CPL + 1) < 32767) && len <= 64u * CPL && len > 0 &&
                   nrows > 0 && !(a.dp.flags[slot] & 1u) && g < 0 && (nw || n < 0);
         if (!ok) {
-            if (lane == 0) vc_fail(a.b, w, (len == 0 || nrows == 0) ? VC_WIN_INVALID : VC_WIN_UNSUPPORTED, 3, (a.dp.flags[slot] & 1u) ? 1 : 2);
+            // outside the packed-int16 envelope: not an error -- the job keeps type 255 and k_fwd_wide (int32 lanes, any
+            // length, like the reference's fallback to 32-bit lanes, simd impl:699-706) takes it
+            if (len == 0 || nrows == 0 || (a.dp.flags[slot] & 1u)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 3, (a.dp.flags[slot] & 1u) ? 1 : 2); }
             return;
         }
     }
@@ -1440,6 +1442,192 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_fwd_wide: the general forward pass for alignments the packed-int16 kernel declines -- score range beyond int16
+// (the reference switches to 32-bit lanes there, simd_alignment_engine_implementation.hpp:699-706), sequences longer
+// than 64 lanes x 32 columns, unusual score signs.  Same recurrence (sisd_alignment_engine.cpp:118-254, 292-360), int32,
+// no assumption beyond what the reference makes: columns are processed in tiles of 512 (64 lanes x 8 cells), one full
+// sweep over the rows per tile, predecessor rows re-read from the stored matrix (raw int32, tilted like k_fwd's:
+// T[i][j] = H[i][j] - j*g), the row directly above kept in registers.  Not tuned: it exists so that no valid window is
+// refused, and it runs only for jobs k_fwd left untouched (job_type still 255).
+// ------------------------------------------------------------------------------------------------
+#define VC_WIDE_CPL 8
+#define VC_WIDE_NEG (-(1 << 29))
+__global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_t wstride, uint32_t wcols, int* c0w) {
+    const int lane = vc_lane();
+    const uint32_t job = blockIdx.x;
+    const uint32_t slot = job / a.group;
+    if (slot >= a.nslots) return;
+    const uint32_t k = a.k0 + job % a.group;
+    const uint32_t w = a.w0 + slot;
+    if (a.job_type[job] != 255) return;                      // k_fwd took it
+    if (a.b.status[w] != VC_WIN_OK) return;
+    const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
+    if (k >= ns) return;
+    const uint64_t so = a.b.seq_off[s0 + k];
+    const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k + 1] - so);
+    const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
+    bool nw = a.mode == 0;
+    if (a.mode == 1) nw = (k == 0) || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L);
+    const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
+    const uint32_t nrows = a.dp.nrows[slot];
+    if (len == 0 || nrows == 0 || (a.dp.flags[slot] & 1u)) return;                 // k_fwd reported it
+    if (len > wcols || (uint64_t)nrows * wcols > wstride) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 26, nrows); return; }
+    const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
+    if (lane == 0) {
+        a.job_type[job] = nw ? 3 : 2;
+        unsigned long long* st = vc_stat_slot(a.stat);
+        atomicAdd(st + 0, (unsigned long long)nrows * len);
+        atomicAdd(st + 1, (unsigned long long)nrows);
+    }
+    int* const T = wmat + (uint64_t)job * wstride;
+    int* const c0out = c0w + (uint64_t)job * a.NC;
+    constexpr int C = VC_WIDE_CPL;
+
+    int best = nw ? VC_INT_MIN : 0;                            // NW: uniform; SW: per lane
+    uint32_t best_row = 0, best_col = 0, ntie = 0;
+    const uint32_t ntile = (len + 64 * C - 1) / (64 * C);
+    for (uint32_t tile = 0; tile < ntile; ++tile) {
+        const uint32_t cb = tile * 64 * C + lane * C;          // 0-based index of my first column (column j = cb + 1 + q)
+        uint32_t sb[C];
+#pragma unroll
+        for (int q = 0; q < C; ++q) sb[q] = cb + q < len ? (uint32_t)a.b.bases[so + cb + q] : 0x100u;
+        int prevT[C], prevLeft = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) prevT[q] = 0;
+        int c0prev = 0, c0vec = 0;
+        for (uint32_t i = 1; i <= nrows; ++i) {
+            const uint4 rec = a.dp.rec[nb + i - 1];
+            const uint32_t x = rec.x & 0xFF, fl = (rec.x >> 8) & 0xFF;
+            const bool isovf = (fl & VC_RF_OVF) != 0;
+            const uint32_t np = isovf ? rec.z : ((rec.x >> 16) & 0xFF);
+            int accd[C], accv[C];
+#pragma unroll
+            for (int q = 0; q < C; ++q) { accd[q] = VC_WIDE_NEG; accv[q] = VC_WIDE_NEG; }
+            int c0m = VC_INT_MIN;
+            for (uint32_t p = 0; p < np; ++p) {
+                uint32_t delta;
+                if (isovf) delta = a.dp.ovf[eb + rec.y + p];
+                else { const uint32_t wsel = p < 2 ? rec.y : (p < 4 ? rec.z : rec.w); delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF); }
+                const uint32_t pr = i - delta;
+                int hv[C], hl, c0p;
+                if (pr == 0) {                                 // virtual row: H[0][j] = j*g (NW) / 0 (SW)
+#pragma unroll
+                    for (int q = 0; q < C; ++q) hv[q] = nw ? 0 : -(int)(cb + 1 + q) * g;
+                    hl = nw ? 0 : -(int)cb * g;
+                    c0p = 0;
+                } else if (delta == 1) {
+#pragma unroll
+                    for (int q = 0; q < C; ++q) hv[q] = prevT[q];
+                    hl = prevLeft; c0p = c0prev;
+                } else {
+                    const int* hr = T + (uint64_t)(pr - 1) * wcols + cb;
+#pragma unroll
+                    for (int q = 0; q < C; ++q) hv[q] = hr[q];
+                    if (delta <= 64) c0p = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
+                    else c0p = (int)__builtin_amdgcn_readfirstlane(c0out[pr - 1]);
+                    const int up = __shfl_up(hv[C - 1], 1, 64);
+                    int edge = nw ? c0p : 0;                   // column 0 of that row
+                    if (tile) edge = (int)__builtin_amdgcn_readfirstlane(T[(uint64_t)(pr - 1) * wcols + tile * 64 * C - 1]);
+                    hl = lane ? up : edge;
+                }
+#pragma unroll
+                for (int q = 0; q < C; ++q) { accv[q] = max(accv[q], hv[q]); accd[q] = max(accd[q], q ? hv[q - 1] : hl); }
+                c0m = max(c0m, c0p);
+            }
+            const int col0 = nw ? c0m + g : 0;
+            int P[C];
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const int j = (int)(cb + 1 + q);
+                int v = max(accd[q] + ((sb[q] == x ? m : n) - g), accv[q] + g);
+                if (!nw) v = max(v, -j * g);                  // SW floor H >= 0
+                P[q] = cb + q < len ? v : VC_WIDE_NEG;
+            }
+            // horizontal pass: prefix maximum with the value entering from the left of the tile
+            const int carry_in = tile ? (int)__builtin_amdgcn_readfirstlane(T[(uint64_t)(i - 1) * wcols + tile * 64 * C - 1]) : col0;
+#pragma unroll
+            for (int q = 1; q < C; ++q) P[q] = max(P[q], P[q - 1]);
+            int sc = P[C - 1];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t2 = __shfl_up(sc, d, 64); if (lane >= d) sc = max(sc, t2); }
+            int carry = __shfl_up(sc, 1, 64);
+            carry = lane ? max(carry, carry_in) : carry_in;
+            int cur[C];
+#pragma unroll
+            for (int q = 0; q < C; ++q) cur[q] = max(P[q], carry);
+            {
+                int* hr = T + (uint64_t)(i - 1) * wcols + cb;
+#pragma unroll
+                for (int q = 0; q < C; ++q) hr[q] = cur[q];
+            }
+            // end cell
+            if (nw) {
+                if ((fl & VC_RF_SINK) && tile + 1 == ntile) {   // sisd :353-355
+                    const uint32_t le = ((len - 1) % (64 * C)) / C, ce = (len - 1) % C;
+                    int v = cur[0];
+#pragma unroll
+                    for (int q = 1; q < C; ++q) v = ce == (uint32_t)q ? cur[q] : v;
+                    v = __shfl(v, (int)le, 64);
+                    if (v > best) {
+                        best = v; best_row = i; ntie = 1;
+                        if (lane == 0) a.tie_rows[(uint64_t)job * VC_MAXTIE] = (uint16_t)i;
+                    } else if (v == best) {
+                        if (lane == 0) {
+                            if (ntie < VC_MAXTIE) a.tie_rows[(uint64_t)job * VC_MAXTIE + ntie] = (uint16_t)i;
+                            else if (a.tie_over && ntie < a.tie_over_stride) a.tie_over[(uint64_t)job * a.tie_over_stride + ntie] = i;
+                        }
+                        ntie++;
+                    }
+                }
+            } else {
+                // sisd :350-352: the first cell in (row, column) order among those with the best score
+#pragma unroll
+                for (int q = 0; q < C; ++q) {
+                    if (cb + q < len) {
+                        const int h = cur[q] + (int)(cb + 1 + q) * g;
+                        if (h > best || (h == best && h > 0 && i < best_row)) { best = h; best_row = i; best_col = cb + 1 + q; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < C; ++q) prevT[q] = cur[q];
+            { const int up = __shfl_up(cur[C - 1], 1, 64); prevLeft = lane ? up : carry_in; }
+            // bookkeeping of column 0 like k_fwd: the last 64 rows in a register, the rest in memory
+            c0prev = col0;
+            c0vec = ((uint32_t)lane == ((i - 1) & 63)) ? col0 : c0vec;
+            if ((i & 63) == 0 || i == nrows) {
+                const uint32_t first = (i - 1) & ~63u;
+                if (first + lane < i) c0out[first + lane] = c0vec;
+                __threadfence_block();
+            }
+            __threadfence_block();                             // rows just written are read back by their successors
+        }
+    }
+    uint32_t end = 0;
+    if (nw) {
+        end = (best_row << 16) | len;
+        if (ntie > 1 && (a.dp.flags[slot] & 2u) && lane == 0) { a.tie_cnt[job] = ntie; a.tie_list[atomicAdd(a.tie_n, 1u)] = slot; }
+    } else {
+        const int gmax = wave_max_i32(best);
+        if (gmax > 0) {
+            const uint32_t rowc = (best == gmax) ? best_row : 0xFFFFFFFFu;
+            const uint32_t rstar = wave_min_u32(rowc);
+            const uint32_t colc = (best == gmax && best_row == rstar) ? best_col : 0xFFFFFFFFu;
+            // a lane keeps one (row, column) per value, the smallest row; the smallest column of THAT row may sit in
+            // another lane or tile, so look the row up again
+            uint32_t cstar = wave_min_u32(colc);
+            for (uint32_t c = lane; c < len; c += 64) {
+                const int h = T[(uint64_t)(rstar - 1) * wcols + c] + (int)(c + 1) * g;
+                if (h == gmax) cstar = min(cstar, c + 1);
+            }
+            cstar = wave_min_u32(cstar);
+            end = (rstar << 16) | cstar;
+        }
+    }
+    if (lane == 0) a.job_end[job] = end;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_trace: backtrack, one alignment per thread, straight from the stored matrix like sisd_alignment_engine.cpp:362-459:
 // diagonal over the in-edges in list order, then vertical over the in-edges in list order, then
 // horizontal.  Pairs are emitted tail-first as (row << 16) | column, 0 meaning "-1"; consumers read
@@ -1460,6 +1648,8 @@ struct VcTraceArgs {
     uint32_t pair_group, pair_k0;   // pairs index = slot*pair_group + (k - pair_k0)
     uint32_t k0;
     unsigned long long* stat;   // [VC_STAT_SLOTS][8], see vc_ctx::d_stat
+    const int* wmat; uint64_t wstride; uint32_t wcols; const int* c0w;   // matrices of k_fwd_wide (job types 2, 3)
+    int only_wide;              // k_trace: take only those jobs (k_tracew walked the rest)
     int shared_table;           // k_tracew: the VC_TG alignments of a wave share a window (group % VC_TG == 0)
     uint32_t tab_rows;          // k_tracew: rows the LDS table is sized for (>= every graph's height in this launch)
 };
@@ -1479,14 +1669,18 @@ __global__ void k_trace(VcTraceArgs a) {
     const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
     const uint8_t type = a.job_type[job];
     if (type == 255) return;
+    const bool wide = type >= 2;
+    if (a.only_wide && !wide) return;
     if (a.b.status[w] != VC_WIN_OK) return;
     uint32_t* out = a.pairs + pj * a.PC;
     const uint32_t end = a.job_end[job];
     uint32_t i = end >> 16, j = end & 0xFFFF;
     const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
-    const bool nw = type == 1;
+    const bool nw = (type & 1) != 0;
     const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
     const uint64_t so = a.b.seq_off[a.b.win_seq_off[w] + k];
+    const int* wm = wide ? a.wmat + (uint64_t)job * a.wstride : nullptr;
+    const int* wc0 = wide ? a.c0w + (uint64_t)job * a.NC : nullptr;
     const uint32_t* hm32 = a.hmat + (uint64_t)job * a.hstride;
     const uint16_t* hm = (const uint16_t*)hm32;
     const int16_t* c0 = a.c0 + (uint64_t)job * a.NC;
@@ -1496,6 +1690,7 @@ __global__ void k_trace(VcTraceArgs a) {
     // diagonal T == T' + (score - g), vertical T == T' + g, horizontal T == T', SW stop T == -col*g
     auto Hat = [&](uint32_t r, uint32_t col) -> int {     // T[r][col] incl. the virtual row 0 / column 0
         if (r == 0) return nw ? 0 : -(int)col * g;
+        if (wide) return col == 0 ? (nw ? wc0[r - 1] : 0) : wm[(uint64_t)(r - 1) * a.wcols + col - 1];
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
         if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl);
@@ -1533,7 +1728,7 @@ __global__ void k_trace(VcTraceArgs a) {
                     const uint32_t bs = a.b.bases[so + j - 1];
                     const uint4 q0 = a.dp.rec[nb + rr - 1];
                     int v0 = v0raw;
-                    if (pr0 == 0 || j == 1) v0 = Hat(pr0, j - 1);
+                    if (pr0 == 0 || j == 1 || wide) v0 = Hat(pr0, j - 1);
                     const int sc = ((bs == (rec.x & 0xFF)) ? m : n) - g;
                     if (Hij == v0 + sc) { pi_ = pr0; pj_ = j - 1; hv = v0; nrec = pr0 ? q0 : zero4; have_nrec = true; found = true; }
                     for (uint32_t p = 1; p < np && !found; ++p) {
@@ -1624,7 +1819,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     const uint32_t w = a.w0 + slot;
     const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
     const uint8_t type = valid ? a.job_type[job] : (uint8_t)255;
-    valid = valid && type != 255;
+    valid = valid && type < 2;                                // 255: nothing to walk; 2, 3: k_fwd_wide's, walked by k_trace
     if (valid && a.b.status[w] != VC_WIN_OK) valid = false;
     if (!__any(valid)) return;
     uint32_t* out = a.pairs + pj * a.PC;

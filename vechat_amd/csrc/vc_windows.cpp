@@ -81,7 +81,9 @@ void make_reverse(Seq& s) {
 // window of the target the overlap touches, the first aligned (target, query) position inside it and the position
 // one past the last aligned pair.  Done run by run here: a run of matches or deletions is cut at the window ends
 // it crosses.  Window ends are the last target position of each window, and the overlap's own end.
-void breaking_points_from_cigar(Ovl& o, const char* cigar, uint32_t window_length) {
+// Returns false when the CIGAR does not consume exactly the query and target spans of the overlap record (then the
+// breaking points would index past the sequences).
+bool breaking_points_from_cigar(Ovl& o, const char* cigar, uint32_t window_length) {
     std::vector<int64_t> ends;
     for (uint64_t e = window_length; e < o.t_end; e += window_length)
         if (e > o.t_begin) ends.push_back((int64_t)e - 1);
@@ -124,6 +126,8 @@ void breaking_points_from_cigar(Ovl& o, const char* cigar, uint32_t window_lengt
         }
         p = e + 1;
     }
+    const int64_t q_last = (int64_t)(o.strand ? o.q_length - o.q_begin : o.q_end) - 1;      // last query / target position of the span
+    return qpos == q_last && tpos == (int64_t)o.t_end - 1;
 }
 
 }  // namespace
@@ -167,7 +171,8 @@ int vc_wb_add_overlap(vc_wb* b, uint32_t q_id, uint32_t t_id, int strand, uint32
     if (q_begin > q_end || q_end > q_length || t_begin > t_end || t_end > b->seqs[t_id].data.size())
         return fail(b, "overlap coordinates out of range");
     Ovl o{q_id, t_id, q_begin, q_end, q_length, t_begin, t_end, strand ? 1 : 0, {}};
-    breaking_points_from_cigar(o, cigar, b->window_length);
+    if (!breaking_points_from_cigar(o, cigar, b->window_length))
+        return fail(b, "CIGAR does not match the overlap's query / target spans");
     b->ovls.emplace_back(std::move(o));
     return VC_OK;
 }
@@ -202,6 +207,7 @@ int vc_wb_build(vc_wb* b, vc_batch* out) {
         if (o.strand) make_reverse(s);
         for (size_t j = 0; j + 1 < o.bp.size(); j += 2) {
             const uint32_t q0 = o.bp[j].second, q1 = o.bp[j + 1].second;
+            if (q1 < q0 || q1 > b->seqs[o.q_id].data.size()) return fail(b, "breaking point beyond the end of the read");
             if ((double)(q1 - q0) < 0.02 * W) continue;                                   // :416
             if (!s.qual.empty()) {                                                        // :420-434
                 const std::string& q = o.strand ? s.rq : s.qual;

@@ -16,6 +16,10 @@ class VcError(RuntimeError):
     pass
 
 
+MAX_NODES = 59968      # 16-bit node ids, capacities are multiples of 64 (vc_submit)
+MAX_EDGES = 32000
+
+
 class HipContext:
     """Owns a vc_ctx (one device, one stream)."""
 
@@ -97,15 +101,17 @@ class HipContext:
         if retry_overflow and over:
             st = self.stats()
             p = capi.VcParams.from_buffer_copy(self.params)
-            p.max_nodes = min(2 * st["max_nodes"], 60000)
-            p.max_edges = min(2 * st["max_edges"], 32000)
-            if p.max_nodes > st["max_nodes"]:
+            p.max_nodes = min(2 * st["max_nodes"], MAX_NODES)
+            p.max_edges = min(2 * st["max_edges"], MAX_EDGES)
+            if p.max_nodes > st["max_nodes"] or p.max_edges > st["max_edges"]:
                 try:
                     sub = HipContext(params=p)
                 except VcError:
                     return cons, status
                 try:
                     c2, s2 = sub.consensus(batch.select(over), retry_overflow=True)
+                except VcError:
+                    return cons, status              # the larger capacities do not fit this device: the windows stay VC_WIN_OVERFLOW
                 finally:
                     sub.close()
                 for k, w in enumerate(over):
