@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: POA windows/s of the per-window SPOA + prune + consensus hot path.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched through torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W      (N > 1: this command starts N ranks itself, one per GPU;
+                                                       under torch.distributed.run it is one of the ranks)
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic windows,
-500 bp backbone x 64 reads, PacBio profile (15 % error, ins:del:sub 0.40:0.30:0.30), FASTQ weights,
-haplotype mode -d 0.2 -s 0.2 -k 3, scores 3/-5/-4.  One step = one pass of the hot path over one
-batch of `--windows` windows per GPU, inputs already resident in HBM, followed by the gather of the
-corrected sequences to rank 0 (RCCL over xGMI when N>1).  Weak scaling: every rank gets its own
-`--windows` windows of the stream.
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic windows, 500 bp backbone x
+64 reads, PacBio profile (15 % error, ins:del:sub 0.40:0.30:0.30), FASTQ weights, haplotype mode -d 0.2 -s 0.2 -k 3,
+scores 3/-5/-4.  One step = one pass of the hot path over `--windows` DISTINCT windows per GPU (default 100 000 =
+config C), inputs already resident in HBM, followed by the gather of the corrected sequences to rank 0 (RCCL over
+xGMI when N > 1).  Weak scaling: every rank gets its own `--windows` windows of the stream (N = 8: 800 000 windows
+per step, config D's shape).
+
+The one JSON line also carries
+  value_e2e   the same windows from host memory to host memory (vc_submit -> vc_run -> vc_collect, H2D and D2H
+              included), two contexts double-buffering batches of 16 384 windows -- SURVEY 8(d)'s definition of the
+              metric; `value` is the resident-input rate the driver's contract asks for
+  roofline    k_fwd: 4 B/cell model of SURVEY 8(d), measured HBM traffic (profiles/r2_hbm_traffic.json, refused when it
+              was taken for other kernels than the ones built here), and the calibrated VALU issue bound
+  cpu_baseline  the reference itself (oracle/_ref, built in place from /root/reference) on the host cores, bounded
+  configs     windows/s on BASELINE configs B and E, short runs
 """
 import argparse
 import hashlib
 import json
 import os
 import sys
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -31,6 +42,7 @@ from vechat_amd.shard import gather_consensus
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_CELL = 4.0           # one int16 score store + one load by a successor row
+E2E_BATCH = 16384
 
 
 def usable_cores():
@@ -45,10 +57,17 @@ def usable_cores():
     return n
 
 
+def kernel_hash():
+    """Identity of the kernels this bench runs: measured-traffic files are only valid for the sources they were taken on."""
+    h = hashlib.sha256()
+    for f in ("vc_kernels.h", "vc_api.hip", "vc_device.h"):
+        h.update(open(os.path.join(ROOT, "vechat_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(batch, params, budget_s):
-    """CHECKER/BASELINE leg (rank 0, N=1): the reference itself when oracle/_ref travelled with the
-    repo ("reference"), else our C restatement ("port"), on a bounded sample of the same workload,
-    one window per task on all host cores."""
+    """CHECKER/BASELINE leg (rank 0, N=1): the reference itself when oracle/_ref travelled with the repo ("reference"),
+    else our C restatement ("port"), on a bounded sample of the same workload, one window per task on all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as oa
     cores = usable_cores()
@@ -70,6 +89,55 @@ def cpu_baseline(batch, params, budget_s):
     dt = time.time() - t0
     return dict(value=done / dt, unit="windows/s", cores=cores, kind=kind,
                 sample=f"first {done} windows of the bench batch, one window per task on {cores} threads, {dt:.1f} s"), out
+
+
+def e2e_rate(batch, device, reps=1):
+    """Host memory in, host memory out: two contexts, each with its own host thread, alternate over batches of E2E_BATCH
+    windows, so one batch's H2D / D2H overlaps the other's kernels.  Returns (windows/s, consensus bytes by window)."""
+    n = batch.n_windows
+    parts = [batch.slice(lo, min(lo + E2E_BATCH, n)) for lo in range(0, n, E2E_BATCH)]
+    free_b, _ = torch.cuda.mem_get_info(device)
+    ctxs = [HipContext(device=device, scratch_bytes=int(0.42 * free_b)) for _ in range(2)]
+    out = [None] * len(parts)
+
+    def worker(k):
+        for i in range(k, len(parts), 2):
+            c = ctxs[k]
+            c.submit(parts[i]); c.run(); c.sync()
+            out[i] = c.collect()
+
+    def once():
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    for k in range(2):                              # first use of a context allocates its workspaces (seconds): not part of the rate
+        ctxs[k].submit(parts[k % len(parts)]); ctxs[k].run(); ctxs[k].sync(); ctxs[k].collect()
+    dt = min(once() for _ in range(reps))
+    for c in ctxs:
+        c.close()
+    cons = [x for p in out for x in p[0]]
+    return n / dt, cons
+
+
+def short_config(device, seed, L, D, n, profile):
+    cfg = capi.synth_cfg(seed, L, D, profile=profile)
+    b = capi.synth_batch(cfg, 0, n)
+    c = HipContext(device=device)
+    c.submit(b)
+    c.run(); c.sync()
+    t0 = time.perf_counter()
+    c.run(); c.sync()
+    dt = time.perf_counter() - t0
+    _, status = c.collect()
+    st = c.stats()
+    c.close()
+    return {"windows_per_s": n / dt, "windows": n, "backbone_len": L, "reads_per_window": D, "gcups": st["cells"] / dt / 1e9,
+            "windows_not_ok": int((status > 1).sum())}
 
 
 def stub_main(a, world):
@@ -104,13 +172,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=32768, help="windows per GPU per step")
+    ap.add_argument("--windows", type=int, default=100000, help="distinct windows per GPU per step (BASELINE config C: 100 000)")
     ap.add_argument("--layers", type=int, default=64)
     ap.add_argument("--length", type=int, default=500)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_e2e, the per-kernel profile pass and the config B / E lines")
+    ap.add_argument("--ab", action="store_true", help="development: only the per-kernel profile pass of the extras")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -140,7 +210,7 @@ def main():
 
     cfg = capi.synth_cfg(1002, a.length, a.layers, profile=capi.PACBIO)
     batch = capi.synth_batch(cfg, rank * a.windows, a.windows)
-    ctx = HipContext(device=local, profile=1, chunk_windows=a.chunk, n_streams=a.streams)
+    ctx = HipContext(device=local, profile=2, chunk_windows=a.chunk, n_streams=a.streams)   # profile 2: HIP events around k_fwd only
     ctx.submit(batch)                                   # H2D: inputs resident before the timed region
 
     n = batch.n_windows
@@ -167,13 +237,12 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    kms, cells = {}, 0
+    fwd_ms, fwd_launches, cells, rows = 0.0, 0, 0, 0
     for _ in range(a.steps):
         cons_all, lens_all = step()
         s = ctx.stats()
-        cells += s["cells"]
-        for k, v in s["kernels"].items():
-            kms[k] = kms.get(k, 0.0) + v["ms"]
+        cells += s["cells"]; rows += s["dp_rows"]
+        fwd_ms += s["kernels"]["k_fwd"]["ms"]; fwd_launches += s["kernels"]["k_fwd"]["launches"]
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -187,56 +256,79 @@ def main():
         bases = int(lens_all.sum().item()) * a.steps
         s = ctx.stats()
         status = d_status.cpu().numpy()
-        fwd_ms = kms.get("k_fwd", 0.0)
-        fwd_launches = s["kernels"]["k_fwd"]["launches"] * a.steps
         achieved = BYTES_PER_CELL * cells / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
-        # measured HBM bytes per cell of k_fwd (rocprofv3 PMC passes, see profiles/r1_hbm_traffic.json)
-        traffic = None
-        valu = None
+        khash = kernel_hash()
+        roof = {"bound": "hbm", "kernel": "k_fwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells / max(fwd_launches, 1),
+                "algorithmic_bytes_per_cell": BYTES_PER_CELL, "cells_per_step": cells / a.steps,
+                "avg_launch_ms": fwd_ms / max(fwd_launches, 1), "launches_per_step": fwd_launches / a.steps,
+                "timing": "HIP events around every k_fwd launch on its own stream, inside the timed region (vc_params.profile = 2)",
+                "kernel_hash": khash}
+        # measured HBM bytes of k_fwd (rocprofv3 PMC passes; profiles/r2_hbm_traffic.json says for which kernel sources)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
-            traffic = tj["bytes_per_cell"] * cells / max(fwd_launches, 1)
-            # the kernel moves less than the 4 B/cell model, so the VALU issue bound is stated beside it:
-            # VALU instructions per DP row (PMC) x 4 cycles per wave64 instruction, against SIMD-cycles of the k_fwd launches
-            prop = torch.cuda.get_device_properties(local)
-            simds = prop.multi_processor_count * 4
-            mhz = getattr(prop, "clock_rate", 0) / 1e3 or 2400.0          # MI355X peak engine clock (MI355X_MICROARCH.md)
-            ipr = tj["instructions_per_dp_row"]["VALU"]
-            rows = s["dp_rows"] * a.steps
-            valu = {"valu_insts_per_dp_row": ipr, "dp_rows_per_step": rows / a.steps, "simds": simds, "clock_mhz": mhz,
-                    "frac_of_valu_issue_peak": (rows * ipr * 4.0) / (fwd_ms * 1e-3 * simds * mhz * 1e6) if fwd_ms > 0 else None}
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")))
+            if tj.get("kernel_hash") != khash:
+                roof["traffic_note"] = f"profiles/r2_hbm_traffic.json was measured for kernels {tj.get('kernel_hash')}, these are {khash}: not used"
+            else:
+                roof["traffic"] = tj["bytes_per_cell"] * cells / max(fwd_launches, 1)
+                roof["hbm_frac_measured"] = tj["bytes_per_cell"] * cells / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                # the kernel moves less than the 4 B/cell model, so the VALU issue bound is stated beside it, against
+                # the issue rate MEASURED on this chip for the instructions k_fwd is made of (tools/valu_peak.hip)
+                vp = json.load(open(os.path.join(ROOT, "profiles", "r2_valu_peak.json")))
+                simds = torch.cuda.get_device_properties(local).multi_processor_count * 4
+                ipr = tj["instructions_per_dp_row"]["VALU"]
+                roof["valu_issue"] = {"valu_insts_per_dp_row": ipr, "dp_rows_per_step": rows / a.steps, "simds": simds,
+                                      "peak_wave_insts_per_us_per_simd": vp["peak_wave_insts_per_us_per_simd"],
+                                      "frac_of_valu_issue_peak": rows * ipr / (fwd_ms * 1e3 * simds * vp["peak_wave_insts_per_us_per_simd"])}
         except Exception as e:
-            valu = valu or {"error": repr(e)}
+            roof["traffic_note"] = repr(e)
         line = {
             "metric": "POA windows/sec (500 bp x 64-read)", "value": total_windows / dt, "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": f"synthetic windows {a.length} bp x {a.layers} reads, PacBio 15% error, "
-                                   f"FASTQ weights, haplotype mode d=0.2 s=0.2 k=3; {a.windows} windows per GPU per step "
-                                   f"(stream of BASELINE config C)",
+            "config": {"workload": f"synthetic windows {a.length} bp x {a.layers} reads, PacBio 15% error, FASTQ weights, haplotype mode "
+                                   f"d=0.2 s=0.2 k=3; {a.windows} distinct windows per GPU per step (BASELINE config C"
+                                   f"{'; x' + str(world) + ' GPUs = config D shape' if world > 1 else ''})",
                        "windows_per_gpu_per_step": a.windows, "backbone_len": a.length, "reads_per_window": a.layers,
                        "chunk_windows": s["chunk_windows"], "streams": s["n_streams"], "max_nodes": s["max_nodes"], "max_edges": s["max_edges"]},
             "corrected_bases_per_s": bases * world / dt if world == 1 else bases / dt,
             "gcups": cells * world / dt / 1e9,
             "windows_not_ok": int((status > 1).sum()),
-            "roofline": {"bound": "hbm", "kernel": "k_fwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells / max(fwd_launches, 1),
-                         "algorithmic_bytes_per_cell": BYTES_PER_CELL, "cells_per_step": cells / a.steps,
-                         "avg_launch_ms": fwd_ms / max(fwd_launches, 1), "launches_per_step": fwd_launches / a.steps,
-                         "valu_issue": valu},
-            "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
+            "roofline": roof,
         }
-        if world == 1 and not a.no_cpu:
-            cb, ref_out = cpu_baseline(batch, ctx.params, a.cpu_seconds)
-            cons_np = cons_all.cpu().numpy()
-            off = np.concatenate([[0], np.cumsum(lens_all.cpu().numpy())])
-            bad = sum(1 for w, c in ref_out.items() if cons_np[off[w]:off[w + 1]].tobytes() != c)
-            cb["parity_windows_checked"] = len(ref_out)
-            cb["parity_mismatches"] = bad
-            line["cpu_baseline"] = cb
-            line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"] if cb["value"] else None
+        if world == 1 and not a.no_extras:
+            # separate pass with every kernel class bracketed by events: the breakdown, not part of `value`
+            ctx.lib.vc_set_profile(ctx.h, 1)
+            ctx.run(); ctx.sync()
+            sp = ctx.stats()
+            line["kernel_ms_per_step"] = {k: v["ms"] for k, v in sp["kernels"].items()}
+            line["kernel_ms_note"] = "separate profiled pass (vc_params.profile = 1); sums exceed ms_per_step because chunk streams overlap"
+            ctx.lib.vc_set_profile(ctx.h, 2)
+    ctx_params = ctx.params
+    if rank == 0 and world == 1 and not a.no_extras and not a.ab:
+        cons_np = cons_all.cpu().numpy()
+        off = np.concatenate([[0], np.cumsum(lens_all.cpu().numpy())])
+        ctx.close()                                     # its workspaces go back before the two e2e contexts plan theirs
+        torch.cuda.empty_cache()
+        rate, cons_e2e = e2e_rate(batch, local)
+        line["value_e2e"] = rate
+        line["e2e"] = {"definition": "host arrays -> vc_submit -> vc_run -> vc_collect -> host bytes, H2D and D2H included, "
+                                     f"two contexts / two host threads alternating over batches of {E2E_BATCH} windows",
+                       "identical_to_resident_run": all(cons_np[off[w]:off[w + 1]].tobytes() == cons_e2e[w] for w in range(0, n, 97))}
+        line["configs"] = {"B": short_config(local, 1001, 500, 32, 10000, capi.PACBIO),
+                           "E": short_config(local, 1005, 1000, 128, 4096, capi.ONT)}
+    if rank == 0 and world == 1 and not a.no_cpu:
+        cb, ref_out = cpu_baseline(batch, ctx_params, a.cpu_seconds)
+        cons_np = cons_all.cpu().numpy()
+        off = np.concatenate([[0], np.cumsum(lens_all.cpu().numpy())])
+        bad = sum(1 for w, c in ref_out.items() if cons_np[off[w]:off[w + 1]].tobytes() != c)
+        cb["parity_windows_checked"] = len(ref_out)
+        cb["parity_mismatches"] = bad
+        line["cpu_baseline"] = cb
+        line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"] if cb["value"] else None
+    if rank == 0:
         out_line = json.dumps(line)
     if world > 1 or force_dist:
         dist.barrier()

@@ -56,7 +56,7 @@ typedef struct vc_params {
     uint32_t max_edges;                     /* 0 = derive                                          */
     uint32_t chunk_windows;                 /* windows resident per pass; 0 = derive from memory   */
     uint64_t scratch_bytes;                 /* device scratch budget; 0 = 1/4 of free memory       */
-    int32_t  profile;                       /* 1 = bracket every kernel class with HIP events      */
+    int32_t  profile;                       /* 1 = bracket every kernel launch with HIP events, 2 = only the forward kernel's */
     uint32_t n_streams;                     /* chunks in flight on separate HIP streams; 0 = 2     */
 } vc_params;
 
@@ -120,6 +120,7 @@ int vc_get_stats(vc_ctx* ctx, vc_stats* s);
 /* diagnostics: per-window (site << 16) | detail of the kernel that took the window out of VC_WIN_OK */
 int vc_debug_errinfo(vc_ctx* ctx, uint32_t* out /*[n_windows]*/);
 void* vc_stream(vc_ctx* ctx);                         /* the hipStream_t the context launches on               */
+int   vc_set_profile(vc_ctx* ctx, int profile);       /* change vc_params.profile of a live context (0, 1, 2)  */
 
 /* -- host helpers that keep reference semantics on the host side of the boundary ---------------- */
 /* rank[] as produced by window.cpp:203-210: rank[0]=0, rank[1..] = std::sort of 1..n-1 by begin

@@ -365,7 +365,7 @@ def test_bench_single_rank_through_rccl(built):
     env = dict(os.environ, VC_FORCE_DIST="1", MASTER_PORT="29573")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--windows", "512",
-                          "--layers", "16", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+                          "--layers", "16", "--no-cpu", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["windows_not_ok"] == 0

@@ -5,7 +5,7 @@ args=$1; shift
 for v in "$@"; do
   lib=vechat_amd/lib/variants/libvechat_hip_$v.so
   [ "$v" = main ] && lib=vechat_amd/lib/libvechat_hip.so
-  VECHAT_HIP_LIB=$lib python bench.py --no-cpu $args 2>gpurun_out/ab_$v.err | tail -1 > gpurun_out/ab_$v.json
+  VECHAT_HIP_LIB=$lib python bench.py --no-cpu --ab $args 2>gpurun_out/ab_$v.err | tail -1 > gpurun_out/ab_$v.json
   python - "$v" <<'PY'
 import json,sys
 v=sys.argv[1]

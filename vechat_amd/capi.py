@@ -261,6 +261,8 @@ def load_hip():
         lib.vc_get_stats.restype = C.c_int
         lib.vc_debug_errinfo.argtypes = [vp, C.POINTER(C.c_uint32)]
         lib.vc_debug_errinfo.restype = C.c_int
+        lib.vc_set_profile.argtypes = [vp, C.c_int]
+        lib.vc_set_profile.restype = C.c_int
         lib.vc_stream.argtypes = [vp]
         lib.vc_stream.restype = vp
         _hip = lib

@@ -95,6 +95,7 @@ struct vc_ctx {
 
     uint32_t wcols = 0;                  // != 0: some alignment may need k_fwd_wide; columns of its int32 matrices (multiple of 512)
     uint32_t MA = 4;                     // entries per aligned list: max(4, distinct bytes in the batch - 1), even
+    uint32_t ws_cpl = 0, ws_max_len = 0, cw_run = 0;   // width class / longest sequence the workspaces are sized for; chunk size of the current batch
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
     uint32_t big_ws_stride = 0;          // bytes per window of the HBM workspace for oversized graph images (0: all fit the LDS)
@@ -248,10 +249,11 @@ int h2d(vc_ctx* c, void* dst, const void* src, size_t bytes) {
 }
 
 struct Timer {
-    vc_ctx* c; int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    vc_ctx* c; int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool timed = false;
     Timer(vc_ctx* c_, int cls_, hipStream_t st_) : c(c_), cls(cls_), st(st_) {
         c->stats.launches[cls]++;
-        if (!c->prm.profile) return;
+        timed = c->prm.profile == 1 || (c->prm.profile == 2 && cls == KC_FWD);
+        if (!timed) return;
         if (c->ev_next + 2 > c->ev_pool.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
         }
@@ -259,7 +261,7 @@ struct Timer {
         (void)hipEventRecord(a, st);
     }
     ~Timer() {
-        if (!c->prm.profile) return;
+        if (!timed) return;
         (void)hipEventRecord(b, st);
         c->ev_recs.push_back({cls, a, b});
     }
@@ -592,6 +594,12 @@ void vc_destroy(vc_ctx* c) {
 
 void* vc_stream(vc_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+int vc_set_profile(vc_ctx* c, int profile) {
+    if (!c || profile < 0 || profile > 2) return VC_ERR_ARG;
+    c->prm.profile = profile;
+    return VC_OK;
+}
+
 int vc_submit(vc_ctx* c, const vc_batch* hb) {
     if (!c || !hb) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -691,12 +699,21 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint32_t NC = c->prm.max_nodes ? c->prm.max_nodes : (uint32_t)std::min<uint64_t>(need_nodes, 59968);
     NC = (NC + 63) & ~63u;
     if (!c->prm.max_nodes && NC > 59968) NC = 59968;
+    // Workspaces are grow-only across batches: a batch whose own estimate is a little smaller than its predecessor's keeps
+    // the capacities that exist (a few percent of difference would otherwise re-create ~100 GB of buffers, seconds per
+    // batch).  Results do not depend on capacities; pinned capacities (max_nodes / max_edges) are taken literally.
+    const bool have_ws = !c->chunk_allocs.empty();
+    if (have_ws && !c->prm.max_nodes) NC = std::max(NC, c->NC);
+    if (have_ws) { MA = std::max(MA, c->MA); max_nseq = std::max(max_nseq, c->max_nseq); }
+    const uint32_t ws_max_len = have_ws ? std::max(max_len, c->ws_max_len) : max_len;
     uint32_t EC = c->prm.max_edges ? c->prm.max_edges : (uint32_t)std::min<uint64_t>((uint64_t)(2.6 * NC), 32000);
     EC = (EC + 63) & ~63u;
     if (EC > 32000) EC = 32000;                     // k_prune_lcc keeps 2E adjacency offsets in 16 bits
+    if (have_ws && !c->prm.max_edges) EC = std::max(EC, c->EC);
     if (NC > 59968) return fail(c, VC_ERR_ARG, "max_nodes %u exceeds the 16-bit id space (59968)", NC);
-    const uint32_t cpl = pick_cpl(std::min(max_len, kMaxColumns));
+    c->cpl = pick_cpl(std::min(max_len, kMaxColumns));                  // width classes of THIS batch (kernel selection)
     c->cpl_min = pick_cpl(std::min(min_len, kMaxColumns));
+    const uint32_t cpl = pick_cpl(std::min(ws_max_len, kMaxColumns));   // width class the matrices are sized for
     const uint32_t lds_cap = kLdsCap;
     // graph images that do not fit the LDS are worked on in an HBM workspace (slower, not refused)
     uint32_t big = 0;
@@ -704,7 +721,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     if (vc_prune_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_prune_lds_bytes(NC, EC));
     if (c->prm.mode == 1 && vc_cons_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_cons_lds_bytes(NC, EC));
     big = (big + 255u) & ~255u;
-    const uint32_t PC = NC + max_len + 8;
+    const uint32_t PC = NC + ws_max_len + 8;
 
     // chunk size from the scratch budget (split over the streams)
     size_t free_b = 0, total_b = 0;
@@ -717,14 +734,14 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
     // Can any alignment of this batch leave the packed-int16 kernel's envelope (vc_fwd_body's check: the reference's int16
     // rule, simd impl:699-706, on the worst case the capacities allow)?  Then k_fwd_wide and its int32 matrices are needed.
-    bool maybe_wide = max_len > kMaxColumns;
+    bool maybe_wide = ws_max_len > kMaxColumns || (have_ws && c->wcols);
     for (int sw = 0; sw < 2; ++sw) {
         const long long mm = sw ? c->prm.sw_match : c->prm.match, nn = sw ? c->prm.sw_mismatch : c->prm.mismatch, gg = sw ? c->prm.sw_gap : c->prm.gap;
-        const long long li = (long long)std::min(max_len, kMaxColumns) + 8, lj = NC, mn = std::min(li, lj), d = li > lj ? li - lj : lj - li;
+        const long long li = (long long)std::min(ws_max_len, kMaxColumns) + 8, lj = NC, mn = std::min(li, lj), d = li > lj ? li - lj : lj - li;
         const long long wc = std::min(-(mm * mn + (d ? gg * d : 0)), gg * li + gg * lj);
         if (wc < -31744 || (mm - gg) * (64ll * cpl + 1) >= 32767 || (sw && nn >= 0)) maybe_wide = true;
     }
-    const uint32_t wcols = maybe_wide ? ((max_len + 64 * VC_WIDE_CPL - 1) / (64 * VC_WIDE_CPL)) * (64 * VC_WIDE_CPL) : 0;
+    const uint32_t wcols = maybe_wide ? ((ws_max_len + 64 * VC_WIDE_CPL - 1) / (64 * VC_WIDE_CPL)) * (64 * VC_WIDE_CPL) : 0;
     const uint64_t per_job = NC * rowd * 4 + NC * 2 + 8 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);
@@ -736,12 +753,13 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint32_t group_max = 1 + (uint32_t)std::min<uint64_t>(spare / (per_job * CW), 7);
     if (group_max > max_nseq) group_max = max_nseq;
 
-    const bool same = c->wcols == wcols && c->MA == MA && c->NC == NC && c->EC == EC && c->CW == CW && c->cpl == cpl && c->PC == PC && c->big_ws_stride == big &&
-                      c->group_max == group_max && c->max_nseq == max_nseq && !c->chunk_allocs.empty();
+    const bool same = have_ws && c->wcols == wcols && c->MA == MA && c->NC == NC && c->EC == EC && c->CW >= CW && c->ws_cpl == cpl && c->PC == PC &&
+                      c->big_ws_stride == big && c->max_nseq == max_nseq;
     if (!same) {
         free_list(c->chunk_allocs);
         c->chunk_bytes = 0;
-        c->wcols = wcols; c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
+        c->wcols = wcols; c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->ws_cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
+        c->ws_max_len = ws_max_len;
         c->big_ws_stride = big;
         c->jobs_cap = CW * group_max;
         c->hmat_dwords = (uint64_t)c->jobs_cap * NC * rowd;
@@ -757,7 +775,15 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     HIPCHK(c, hipMemsetAsync(b.status, 0, nw, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, nw * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->stats.max_nodes = NC; c->stats.max_edges = EC; c->stats.chunk_windows = CW;
+    // chunks of this batch: as large as the workspace allows, and equal, so that the last round of chunks is not a lone one
+    {
+        const uint64_t per_round = (uint64_t)S * c->CW;
+        const uint64_t rounds = (nw + per_round - 1) / per_round;
+        uint64_t cw = (nw + S * rounds - 1) / (S * rounds);
+        cw = std::min<uint64_t>((cw + 63) & ~63ull, c->CW);
+        c->cw_run = (uint32_t)std::max<uint64_t>(cw, 1);
+    }
+    c->stats.max_nodes = NC; c->stats.max_edges = EC; c->stats.chunk_windows = c->cw_run;
     c->have_batch = true;
     return VC_OK;
 }
@@ -774,7 +800,7 @@ int vc_run(vc_ctx* c) {
     pl.add_lds = 2 * c->PC + 2 * (c->PC - c->NC) + 64;
     pl.rows_lds = 0;
     pl.cons_lds = vc_cons_lds_bytes(c->NC, c->EC);
-    pl.rowd = 64ull * (c->cpl / 2);
+    pl.rowd = 64ull * (c->ws_cpl / 2);
     HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.topo_lds, kLdsCap)));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.prune_lds, kLdsCap)));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
@@ -788,7 +814,7 @@ int vc_run(vc_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < KC_N; ++i) { c->stats.ms[i] = 0; c->stats.launches[i] = 0; }
 
-    const uint32_t S = c->n_streams, CW = c->CW;
+    const uint32_t S = c->n_streams, CW = c->cw_run;
     for (uint32_t g0 = 0; g0 < b.n_windows; g0 += S * CW) {
         // S chunks advance in lockstep, each on its own stream
         uint32_t max_layers = 0;
@@ -927,7 +953,7 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
     pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
     pl.add_lds = 2 * c->PC + 2 * (c->PC - c->NC) + 64;
     pl.rows_lds = 0; pl.cons_lds = 0;
-    pl.rowd = 64ull * (c->cpl / 2);
+    pl.rowd = 64ull * (c->ws_cpl / 2);
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
     HIPCHK(c, hipMemsetAsync(c->b.status, 0, c->b.n_windows, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -935,7 +961,7 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
     static uint32_t built_to = 0;
     int rc;
     if (built_to != layer) {
-        pl.begin(wk, 0, std::min(c->CW, c->b.n_windows));
+        pl.begin(wk, 0, std::min(c->cw_run, c->b.n_windows));
         for (uint32_t j = 1; j < layer; ++j) if ((rc = pl.build_layer(wk, j))) return rc;
         hipLaunchKernelGGL(k_rows, dim3(wk.ns), dim3(64), 0, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, wk.ns, pl.NC, pl.EC, (int)layer, (uint32_t)kRing);
         built_to = layer;
