@@ -22,38 +22,55 @@ def _open(path):
     return gzip.open(path, "rb") if str(path).endswith(".gz") else open(path, "rb")
 
 
-def read_sequences(path):
-    """FASTA or FASTQ (optionally .gz) -> [(name, data, quality|None)]"""
-    out = []
+def _records(path):
+    """FASTA / FASTQ records of a file, one at a time (the file is streamed, not held)."""
     with _open(path) as f:
-        lines = f.read().split(b"\n")
-    i = 0
-    while i < len(lines):
-        ln = lines[i]
-        if not ln:
-            i += 1
-            continue
-        if ln[:1] == b">":
-            name = ln[1:].split()[0] if ln[1:].split() else b""
-            i += 1
-            parts = []
-            while i < len(lines) and lines[i][:1] != b">":
-                parts.append(lines[i].strip())
-                i += 1
-            out.append((name.decode(), b"".join(parts).upper(), None))
-        elif ln[:1] == b"@":
-            name = ln[1:].split()[0] if ln[1:].split() else b""
-            data = lines[i + 1].strip().upper()
-            qual = lines[i + 3].strip()
-            if len(qual) != len(data):
-                raise ValueError(f"{path}: quality length differs from sequence length for {name.decode()}")
-            if sum(c - 33 for c in qual) == 0:
-                qual = None
-            out.append((name.decode(), data, qual))
-            i += 4
-        else:
-            raise ValueError(f"{path}: unrecognised record at line {i + 1}")
-    return out
+        pending = None                                   # a header line already read while collecting a FASTA record
+        lineno = 0
+        while True:
+            ln = pending if pending is not None else f.readline()
+            pending = None
+            if not ln:
+                return
+            lineno += 1
+            ln = ln.rstrip(b"\n")
+            if not ln:
+                continue
+            if ln[:1] == b">":
+                name = ln[1:].split()[0] if ln[1:].split() else b""
+                parts = []
+                while True:
+                    nx = f.readline()
+                    if not nx:
+                        break
+                    if nx[:1] == b">":
+                        pending = nx
+                        break
+                    parts.append(nx.strip())
+                yield name.decode(), b"".join(parts).upper(), None
+            elif ln[:1] == b"@":
+                name = ln[1:].split()[0] if ln[1:].split() else b""
+                data = f.readline().strip().upper()
+                f.readline()
+                qual = f.readline().strip()
+                if len(qual) != len(data):
+                    raise ValueError(f"{path}: quality length differs from sequence length for {name.decode()}")
+                if sum(c - 33 for c in qual) == 0:
+                    qual = None
+                yield name.decode(), data, qual
+            else:
+                raise ValueError(f"{path}: unrecognised record at line {lineno}")
+
+
+def read_sequences(path, keep=None):
+    """FASTA or FASTQ (optionally .gz) -> [(name, data, quality|None)].  keep: a set of names -- the other records are
+    passed over without being held (a rank of a multi-GPU run loads only the sequences of its own targets)."""
+    return [r for r in _records(path) if keep is None or r[0] in keep]
+
+
+def sequence_index(path):
+    """[(name, length)] of every record, in file order, without keeping the data."""
+    return [(n, len(d)) for n, d, _ in _records(path)]
 
 
 _CIG = re.compile(rb"(\d+)([MIDNSHP=X])")

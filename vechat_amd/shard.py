@@ -44,11 +44,14 @@ def shard_range_balanced(cost, rank: int, world: int):
     return lo, hi
 
 
-def gather_consensus(cons: torch.Tensor, lens: torch.Tensor, dst: int = 0, force: bool = False):
+def gather_consensus(cons: torch.Tensor, lens: torch.Tensor, dst=0, force: bool = False):
     """cons: uint8 [sum(lens)] consensus bytes of this rank's windows, lens: int64 [n_local].
     Returns (cons_all, lens_all) on rank `dst` (window order), (None, None) elsewhere; dst=None: on every rank.
-    Two collectives: all_gather of (n_windows, n_bytes), then an all_gather of payloads padded to
-    the largest shard (one large message per peer link; no ring dependency on payload size)."""
+
+    dst = r (the path's one exchange): a small all_gather of (n_windows, n_bytes), then every other rank SENDS
+    its exact payload to r and r receives each into its place of the output -- point-to-point over the xGMI link between the
+    two GPUs, no padding to the largest shard, nothing delivered to ranks that do not need it.
+    dst = None: every rank needs everything (sharing device-aligned CIGAR strings): all_gather of padded payloads."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return cons, lens
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -57,7 +60,36 @@ def gather_consensus(cons: torch.Tensor, lens: torch.Tensor, dst: int = 0, force
     metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(metas, meta)
     metas = torch.stack(metas).cpu()
-    max_w, max_b = int(metas[:, 0].max()), int(metas[:, 1].max())
+    nw, nb = [int(x) for x in metas[:, 0]], [int(x) for x in metas[:, 1]]
+    if dst is not None:
+        if rank != dst:
+            ops = []
+            if nw[rank]:
+                ops.append(dist.P2POp(dist.isend, lens.contiguous(), dst))
+            if nb[rank]:
+                ops.append(dist.P2POp(dist.isend, cons.contiguous(), dst))
+            if ops:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+            return None, None
+        lens_all = torch.empty(sum(nw), dtype=torch.int64, device=dev)
+        cons_all = torch.empty(sum(nb), dtype=torch.uint8, device=dev)
+        ops, wo, bo = [], 0, 0
+        for r in range(world):
+            lv, cv = lens_all[wo:wo + nw[r]], cons_all[bo:bo + nb[r]]
+            if r == rank:
+                lv.copy_(lens); cv.copy_(cons)
+            else:
+                if nw[r]:
+                    ops.append(dist.P2POp(dist.irecv, lv, r))
+                if nb[r]:
+                    ops.append(dist.P2POp(dist.irecv, cv, r))
+            wo += nw[r]; bo += nb[r]
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        return cons_all, lens_all
+    max_w, max_b = max(nw), max(nb)
     pl = torch.zeros(max(max_w, 1), dtype=torch.int64, device=dev)
     pl[:lens.numel()] = lens
     pc = torch.zeros(max(max_b, 1), dtype=torch.uint8, device=dev)
@@ -66,8 +98,6 @@ def gather_consensus(cons: torch.Tensor, lens: torch.Tensor, dst: int = 0, force
     all_c = [torch.empty_like(pc) for _ in range(world)]
     dist.all_gather(all_l, pl)
     dist.all_gather(all_c, pc)
-    if dst is not None and rank != dst:
-        return None, None
-    lens_all = torch.cat([all_l[r][:int(metas[r, 0])] for r in range(world)])
-    cons_all = torch.cat([all_c[r][:int(metas[r, 1])] for r in range(world)])
+    lens_all = torch.cat([all_l[r][:nw[r]] for r in range(world)])
+    cons_all = torch.cat([all_c[r][:nb[r]] for r in range(world)])
     return cons_all, lens_all
