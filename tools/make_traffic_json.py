@@ -1,0 +1,66 @@
+"""Build profiles/r2_hbm_traffic.json and profiles/r2_valu_peak.json from the PMC passes of tools/pmc_run.sh and tools/valu_peak.bin.
+
+  python tools/make_traffic_json.py <dir with pmc1..4 counter csv> <gpu_scale stats json> <valu_peak output> <out dir>
+
+FETCH_SIZE is doubled (gfx950: 128-B requests counted as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported.
+Both are in KB.  The kernel hash ties the file to the sources it was measured on (bench.py refuses any other)."""
+import csv, collections, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pmc_dir, stats_json, valu_out, out_dir = sys.argv[1:5]
+
+
+def kernel_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("vc_kernels.h", "vc_api.hip", "vc_device.h"):
+        h.update(open(os.path.join(ROOT, "vechat_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.Counter()
+for f in glob.glob(os.path.join(pmc_dir, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = k.split("<")[0]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[(k, r["Counter_Name"])] += 1
+st = json.load(open(stats_json))            # summed over the repetitions the PMC command ran
+cells, rows, moves = st["cells"], st["dp_rows"], st["trace_steps"]
+out = {"source": "rocprofv3 --kernel-trace --pmc <group>, one counter group per pass (tools/pmc_run.sh), command: " + st["command"],
+       "kernel_hash": kernel_hash(), "cells": cells, "dp_rows": rows, "backtrack_moves": moves,
+       "fetch_correction": 2.0, "units": "FETCH_SIZE / WRITE_SIZE in KB; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes",
+       "kernels": {}}
+for k, d in sorted(agg.items()):
+    e = {c: v for c, v in d.items()}
+    e["dispatches"] = max(n for (kk, _), n in disp.items() if kk == k)
+    if "FETCH_SIZE" in d:
+        e["hbm_read_bytes"] = d["FETCH_SIZE"] * 1024 * 2.0
+    if "WRITE_SIZE" in d:
+        e["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024
+    out["kernels"][k] = e
+f = out["kernels"].get("k_fwd", {})
+if f:
+    out["bytes_per_cell_written"] = f.get("hbm_write_bytes", 0) / cells
+    out["bytes_per_cell_read"] = f.get("hbm_read_bytes", 0) / cells
+    out["bytes_per_cell"] = out["bytes_per_cell_written"] + out["bytes_per_cell_read"]
+    out["instructions_per_dp_row"] = {n: f.get("SQ_INSTS_" + n, 0) / rows for n in ("VALU", "SALU", "LDS", "VMEM_WR", "VMEM_RD")}
+    if "SQ_INSTS_BRANCH" in f:
+        out["instructions_per_dp_row"]["BRANCH"] = f["SQ_INSTS_BRANCH"] / rows
+t = out["kernels"].get("k_tracew", {})
+if t and moves:
+    out["k_tracew_bytes_fetched_per_move"] = t.get("hbm_read_bytes", 0) / moves
+os.makedirs(out_dir, exist_ok=True)
+json.dump(out, open(os.path.join(out_dir, "r2_hbm_traffic.json"), "w"), indent=1)
+print("bytes/cell", out.get("bytes_per_cell"), "insts/row", out.get("instructions_per_dp_row"), "tracew B/move", out.get("k_tracew_bytes_fetched_per_move"))
+
+tests = [json.loads(l) for l in open(valu_out) if l.startswith("{")]
+dev = tests[0]
+ind = [x for x in tests[1:] if x["test"] == "pk_i16_independent"]
+best = max(ind, key=lambda x: x["inst_per_us_per_simd"])
+json.dump({"source": "tools/valu_peak.bin on the bench box", "device": dev, "tests": tests[1:],
+           "peak_wave_insts_per_us_per_simd": best["inst_per_us_per_simd"],
+           "note": f"best issue rate of independent v_pk_max_i16 / v_pk_add_i16 chains ({best['waves_per_simd']} waves per SIMD)"},
+          open(os.path.join(out_dir, "r2_valu_peak.json"), "w"), indent=1)
+print("valu peak", best["inst_per_us_per_simd"], "wave insts / us / SIMD")
