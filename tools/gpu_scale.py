@@ -13,7 +13,7 @@ fp = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
 t0 = time.time()
 b = capi.synth_batch(capi.synth_cfg(1002, L, D, frac_partial=fp), 0, n)
 print(f"generated {n} windows in {time.time()-t0:.1f}s, {b.bases.size/1e6:.1f} MB bases", flush=True)
-ctx = HipContext(device=0, profile=1, chunk_windows=chunk, n_streams=streams)
+ctx = HipContext(device=0, profile=1, chunk_windows=chunk, n_streams=streams, num_prune=int(os.environ.get('VC_NUM_PRUNE', '3')))
 t0 = time.time(); ctx.submit(b); ts = time.time() - t0
 print(f"vc_submit (validation + H2D of {2*b.bases.size/1e6:.0f} MB): {ts:.3f}s = {n/ts:.0f} win/s", flush=True)
 acc = {"cells": 0, "dp_rows": 0, "trace_steps": 0, "command": "python tools/gpu_scale.py " + " ".join(sys.argv[1:])}

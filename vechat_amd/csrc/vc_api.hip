@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,7 +33,10 @@ enum KClass { KC_AVG = 0, KC_INIT, KC_TOPO, KC_FWD, KC_TRACE, KC_ADDALN, KC_PRUN
 const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace", "k_addaln", "k_prune_lcc",
                                  "k_addw", "k_finish", "k_rows", "k_resolve", "k_consensus"};
 
-constexpr int kRing = 8;      // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
+#ifndef VC_RING
+#define VC_RING 8
+#endif
+constexpr int kRing = VC_RING;      // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
 constexpr int kMaxStreams = 4;
 constexpr uint32_t kTraceTabRows = 8188;           // rows covered by k_tracew's first-in-edge table (4 tables x 2 B x 8192 = 64 KB); later rows are walked without speculation
 constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may ask for (160 KB per CU minus room for static __shared__)
@@ -96,11 +100,13 @@ struct vc_ctx {
     uint32_t wcols = 0;                  // != 0: some alignment may need k_fwd_wide; columns of its int32 matrices (multiple of 512)
     uint32_t MA = 4;                     // entries per aligned list: max(4, distinct bytes in the batch - 1), even
     uint32_t ws_cpl = 0, ws_max_len = 0, cw_run = 0;   // width class / longest sequence the workspaces are sized for; chunk size of the current batch
-    uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, n_streams = 1;
+    uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, rgroup_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
     uint32_t big_ws_stride = 0;          // bytes per window of the HBM workspace for oversized graph images (0: all fit the LDS)
     std::vector<uint8_t> h_pre_status;   // per-window status decided at submit (outside the envelope), empty = none
     bool trace_wave = true;
+    int trace_impl = 1;           // 1: k_tracew (16 lanes, two round trips per round, LDS table); 2 / 3: k_tracex with 8 / 16 lanes per alignment
+                                  // (one round trip, no LDS, a third of the instructions -- measured equal alone and 2 % behind beside k_fwd)
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
@@ -197,11 +203,13 @@ int alloc_work(vc_ctx* c, Work* wk) {
     const size_t CW = c->CW, NC = c->NC, EC = c->EC, PC = c->PC;
     int rc;
     if ((rc = alloc_graph(c, &wk->gr[0])) || (rc = alloc_graph(c, &wk->gr[1]))) return rc;
+    wk->dp.pstride = (uint32_t)NC + 8;
     if ((rc = dalloc(c, c->chunk_allocs, &wk->dp.nrows, CW)) || (rc = dalloc(c, c->chunk_allocs, &wk->dp.flags, CW)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rec, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.frec, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
+        (c->trace_impl >= 2 && ((rc = dalloc(c, c->chunk_allocs, &wk->dp.par, CW * (NC + 8))) || (rc = dalloc(c, c->chunk_allocs, &wk->dp.anc, CW * NC)))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_resolve_ws, (size_t)kResolveGrid * ((topo_lds_bytes(NC, c->EC, c->STK, c->MA) + 15u) & ~15u))) ||
         (c->big_ws_stride && (rc = dalloc(c, c->chunk_allocs, &wk->d_big_ws, (size_t)CW * c->big_ws_stride))) ||
@@ -360,6 +368,24 @@ struct Plan {
         return ta;
     }
 
+    // the backtrack of `njobs` alignments (gsz per window) whose graphs have at most `max_rows` rows
+    void launch_trace(Work& wk, VcTraceArgs& ta, uint32_t njobs, uint32_t gsz, uint32_t max_rows) {
+        Timer t(c, KC_TRACE, wk.stream);
+        if (!c->trace_wave) {
+            hipLaunchKernelGGL(k_trace, dim3((njobs + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta);
+            return;
+        }
+        if (c->trace_impl == 1) {
+            ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = std::min(max_rows, kTraceTabRows);
+            hipLaunchKernelGGL(k_tracew, dim3((njobs + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0), wk.stream, ta);
+        } else {
+            const uint32_t tg = c->trace_impl == 2 ? 8u : 4u;
+            if (tg == 8) hipLaunchKernelGGL(k_tracex<8>, dim3((njobs + tg - 1) / tg), dim3(64), 0, wk.stream, ta);
+            else hipLaunchKernelGGL(k_tracex<16>, dim3((njobs + tg - 1) / tg), dim3(64), 0, wk.stream, ta);
+        }
+        if (c->wcols) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((njobs + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); ta.only_wide = 0; }
+    }
+
     void begin(Work& wk, uint32_t w0, uint32_t ns) {
         wk.w0 = w0; wk.ns = ns; wk.cur = 0; wk.layers = 0; wk.nseq_max = 0; wk.active = true; wk.pruned_known = false;
         for (uint32_t w = w0; w < w0 + ns; ++w) {
@@ -398,10 +424,7 @@ struct Plan {
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
-        { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = std::min(NC, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, false), wk.stream, ta); }
-          else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta);
-          if (c->wcols && c->trace_wave) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); } }
+        launch_trace(wk, ta, ns, 1, NC);
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
         aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16;
@@ -451,9 +474,10 @@ struct Plan {
         if (maxn == 0) maxn = 1;
         if (maxn > NC) maxn = NC;
         const uint64_t stride = (uint64_t)maxn * rowd;
-        uint32_t group = (uint32_t)std::min<uint64_t>(c->hmat_dwords / (stride * ns), c->group_max);
+        uint32_t group = (uint32_t)std::min<uint64_t>(c->hmat_dwords / (stride * ns), c->rgroup_max);
         if (group == 0) group = 1;
         group = std::min(group, wk.nseq_max);
+        if (group >= 8) group &= ~7u;                          // whole waves of k_tracex share one jump table
         VcFwdArgs fa = fwd_args(wk);
         VcTraceArgs ta = trace_args(wk);
         for (uint32_t k0 = 0; k0 < wk.nseq_max; k0 += group) {
@@ -463,10 +487,7 @@ struct Plan {
             if (rc) return rc;
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
-            { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = std::min(maxn, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns * gsz + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0), wk.stream, ta); }
-          else hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta);
-          if (c->wcols && c->trace_wave) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((ns * gsz + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); ta.only_wide = 0; } }
+            launch_trace(wk, ta, ns * gsz, gsz, maxn);
         }
         VcAddwArgs wa{};
         wa.b = c->b; wa.g = wk.gr[wk.cur]; wa.dp = wk.dp; wa.w0 = wk.w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
@@ -500,10 +521,7 @@ struct Plan {
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
-        { Timer t(c, KC_TRACE, wk.stream);
-          if (c->trace_wave) { ta.shared_table = 0; ta.tab_rows = std::min(NC, kTraceTabRows); hipLaunchKernelGGL(k_tracew, dim3((ns + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, false), wk.stream, ta); }
-          else hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta);
-          if (c->wcols && c->trace_wave) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((ns + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); } }
+        launch_trace(wk, ta, ns, 1, NC);
         VcFinishArgs fn{};
         fn.b = c->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;
         fn.pairs = wk.d_pairs; fn.npairs = wk.d_npairs; fn.PC = PC;
@@ -541,6 +559,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 2;
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
+    if (const char* ti = getenv("VC_TRACE_IMPL")) c->trace_impl = std::atoi(ti) >= 1 && std::atoi(ti) <= 3 ? std::atoi(ti) : 1;
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }
     // The chunk streams must run CONCURRENTLY.  HIP multiplexes streams of one priority onto a small pool of
     // hardware queues (GPU_MAX_HW_QUEUES, default 4) round-robin, so two of ours can land on the same queue
@@ -730,7 +749,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint32_t S = c->n_streams;
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6)) / S;
     const uint64_t rowd = 64ull * (cpl / 2);
-    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6) + EC * 12ull + 8) + (NC * (16ull + 2 + 2) + EC * 2ull + 8) +
+    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2) + EC * 2ull + 32) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
     // Can any alignment of this batch leave the packed-int16 kernel's envelope (vc_fwd_body's check: the reference's int16
     // rule, simd impl:699-706, on the worst case the capacities allow)?  Then k_fwd_wide and its int32 matrices are needed.
@@ -761,8 +780,11 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         c->wcols = wcols; c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->ws_cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
         c->ws_max_len = ws_max_len;
         c->big_ws_stride = big;
-        c->jobs_cap = CW * group_max;
-        c->hmat_dwords = (uint64_t)c->jobs_cap * NC * rowd;
+        // re-alignment rounds work on pruned graphs (a quarter of NC rows, typically), so more alignments per window fit the
+        // same matrix space than full-height ones: the small per-job arrays are sized for up to 16 (two waves of k_tracex)
+        c->rgroup_max = wcols ? group_max : std::min(std::max(group_max, 16u), std::max(max_nseq, 1u));
+        c->jobs_cap = CW * c->rgroup_max;
+        c->hmat_dwords = (uint64_t)CW * group_max * NC * rowd;
         size_t f0 = 0, f1 = 0, tt = 0;
         (void)hipMemGetInfo(&f0, &tt);
         for (uint32_t s = 0; s < S; ++s)
@@ -1004,6 +1026,10 @@ int vc_get_stats(vc_ctx* c, vc_stats* s) {
     c->stats.trace_steps = st[4]; c->stats.trace_spec = st[5]; c->stats.trace_rounds = st[6];
     c->stats.alignments = c->stats.launches[KC_FWD];
     c->stats.n_streams = c->n_streams;
+#ifdef VC_TX_PROF
+    std::fprintf(stderr, "[tx prof] backtrack waves %llu: shader cycles per wave %.0f, of which table prologue %.0f; rounds per wave-group %.1f\n",
+                 st[3], st[3] ? (double)st[2] / st[3] : 0.0, st[3] ? (double)st[7] / st[3] : 0.0, st[3] ? (double)st[6] / st[3] : 0.0);
+#endif
     *s = c->stats;
     return VC_OK;
 }

@@ -53,6 +53,11 @@ struct VcDp {
     uint4*    frec;       // [CW*NC] the forward kernel's view of the same row (see vc_make_frec)
     uint16_t* rank2node;  // [CW*NC]
     uint16_t* ovf;        // [CW*EC]
+    uint16_t* par;        // [CW*pstride] row behind the first in-edge of DP row r (entry r, 1-based; entry 0 = 0xFFFF):
+                          //   0 = the virtual row 0, 0xFFFF = not listed inline (overflow list)
+    uint32_t  pstride;    // NC + 8
+    uint4*    anc;        // nullptr unless k_tracex is the backtrack in use.  [CW*NC] entry r-1: 8 x u16, the rows 1 .. 8 links behind row r along first in-edges
+                          //   (0 = the virtual row, after which the chain ends; 0xFFFF = the chain has ended)
 };
 
 struct VcBatchDev {

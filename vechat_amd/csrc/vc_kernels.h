@@ -115,6 +115,38 @@ __device__ __forceinline__ uint4 vc_make_frec(uint32_t code, uint32_t fl, uint32
     return o;
 }
 
+// First-in-edge chains for the backtrack.  ~85 % of the backtrack's moves are "diagonal through the first in-edge", so
+// k_tracex speculates along that chain.  The kernels that write the row records store the chain's parent of every row
+// (VcDp::par: the row behind the first in-edge; 0 = the virtual row 0, 0xFFFF = not listed inline) and then call
+// vc_anc_finish, which follows the parents eight links deep: VcDp::anc[r-1] = the rows 1 .. 8 links behind row r
+// (0xFFFF once the chain has ended), one 16-byte load for the backtrack instead of a table in LDS.
+__device__ __forceinline__ uint16_t vc_parent(uint32_t r1, uint32_t np, uint32_t d0, bool is_ovf) {
+    return (uint16_t)((np != 0 && !is_ovf && d0 <= r1) ? r1 - d0 : 0xFFFFu);
+}
+__device__ __forceinline__ void vc_anc_finish(uint16_t* par, uint4* anc, uint32_t nrows, int lane) {
+    if (lane == 0) par[0] = 0xFFFF;                    // the virtual row has no parent
+    __syncthreads();                                   // every row's parent is in memory (same workgroup: visible after the barrier)
+    constexpr int U = 4;                               // rows per lane per pass: independent chains in flight
+    for (uint32_t r0 = 1; r0 <= nrows; r0 += 64 * U) {
+        uint32_t cur[U], w[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const uint32_t r = r0 + 64 * u + lane; cur[u] = r <= nrows ? r : 0xFFFFu; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                cur[u] = par[cur[u] == 0xFFFFu ? 0u : cur[u]];
+                if (k & 1) w[u][k >> 1] |= cur[u] << 16; else w[u][k >> 1] = cur[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = r0 + 64 * u + lane;
+            if (r <= nrows) anc[r - 1] = make_uint4(w[u][0], w[u][1], w[u][2], w[u][3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_avg: average_weight per window -- a strictly ordered fp64 sum (window.cpp:225-236,283,292-309)
 // ------------------------------------------------------------------------------------------------
@@ -457,9 +489,11 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             dp.rec[nb + r] = rec;
             dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl, is_ovf, hasprev, r, ring);
+            if (dp.anc) dp.par[(uint64_t)slot * dp.pstride + r + 1] = vc_parent(r + 1, np, rec.y & 0xFFFF, is_ovf);
         }
         ovf_base += tot_ovf;
     }
+    if (dp.anc) vc_anc_finish(dp.par + (uint64_t)slot * dp.pstride, dp.anc + nb, nrows, lane);
     bad = __any(bad);
     if (lane == 0) {
         dp.nrows[slot] = nrows;
@@ -573,10 +607,12 @@ __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, u
                 dp.rec[nb + r] = rec;
                 dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl_[u], is_ovf, hp_[u], r, ring);
                 dp.rank2node[nb + r] = (uint16_t)v;
+                if (dp.anc) dp.par[(uint64_t)slot * dp.pstride + r + 1] = vc_parent(r + 1, np, rec.y & 0xFFFF, is_ovf);
             }
             ovf_base += tot_ovf;
         }
     }
+    if (dp.anc) vc_anc_finish(dp.par + (uint64_t)slot * dp.pstride, dp.anc + nb, N, lane);
     bad = __any(bad);
     broken = __any(broken);
     if (broken) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 12, 0); return; }   // order invariant violated
@@ -743,9 +779,11 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
             dp.rec[nb + r] = rec;
             dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl, is_ovf, hasprev, r, ring);
             dp.rank2node[nb + r] = (uint16_t)v;
+            if (dp.anc) dp.par[(uint64_t)slot * dp.pstride + r + 1] = vc_parent(r + 1, np, rec.y & 0xFFFF, is_ovf);
         }
         ovf_base += tot_ovf;
     }
+    if (dp.anc) vc_anc_finish(dp.par + (uint64_t)slot * dp.pstride, dp.anc + nb, nrows, lane);
     for (uint32_t i = lane; i < NC / 32 + 1; i += 64) submask[(uint64_t)slot * (NC / 32 + 1) + i] = s_sub[i];
     bad = __any(bad);
     broken = __any(broken);
@@ -1362,7 +1400,9 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
       if ((uint32_t)lane < cnt) c0p_out[i0 - 1 + lane] = (int16_t)c0vec;   // column 0 of the block just completed
       __threadfence_block();
     }
+#ifndef VC_TX_PROF
     if (lane == 0 && far_reads) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
+#endif
 
     // publish the end cell
     uint32_t end = 0;
@@ -2038,6 +2078,319 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
             atomicAdd(st + 4, (unsigned long long)s0); atomicAdd(st + 5, (unsigned long long)s1); atomicAdd(st + 6, (unsigned long long)s2);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tracex<TL>: the cooperative backtrack, 64 / TL alignments per wave, TL lanes each, ONE memory round trip per round, no
+// LDS (it runs beside the forward kernel of another chunk, which fills a CU's LDS).  The walk of
+// sisd_alignment_engine.cpp:362-459 is a chain of dependent lookups; ~85 % of its moves are "diagonal through the first
+// in-edge".  Per round, for the current cell (gi, gj):
+//   * lane p of the group evaluates in-edge p of row gi completely -- the row behind it, its record, the diagonal cell
+//     (pr, gj-1) and the vertical cell (pr, gj); the last lane also fetches the horizontal cell (gi, gj-1).  Ballots then
+//     give the reference's decision exactly: first diagonal match in list order, else first vertical match in list order,
+//     else horizontal (rows whose in-edges sit in the overflow list loop over it before a vertical move is accepted);
+//   * at the same time lane t >= 1 speculates that the t moves before it are all "diagonal through the first in-edge":
+//     its row is the t-th link of that chain (VcDp::anc of row gi, carried with the row's record), and it fetches the
+//     diagonal cell behind ITS first in-edge together with that row's record and chain, plus the two cells that settle a
+//     row with a single in-edge (vertical through it, horizontal);
+//   * all loads of a round are issued together; afterwards the longest prefix of confirmed speculations is accepted (each
+//     is exactly the reference's first test at that cell), and if the first unconfirmed position lies on a row with one
+//     in-edge its vertical / horizontal move is taken in the same round; otherwise the general move decided above.
+// Compared with k_tracew (two round trips per round, a per-alignment table in LDS, eight serial table lookups): a third of
+// the instructions per move, no LDS, no table-building prologue.
+// ------------------------------------------------------------------------------------------------
+#define VC_TX_SPECW 8
+// floor(x / d) == umulhi(x, vc_magic(d)) for x < 65536 and 2 <= d <= 64
+__host__ __device__ inline uint32_t vc_magic(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
+
+// One stored cell, branch-free: the loads are issued for every lane (idle lanes read dword 0 of a matrix), the special
+// rows / columns are patched in afterwards, so that all loads of a round are in flight together.
+template <bool PACKED>
+struct VcCellRd {
+    const uint32_t* hm32;
+    uint32_t cpl, cmagic, rowdw, nds;          // rowdw: dwords per stored row
+    uint32_t ash, aidx;                        // packed rows: dword index and shift of the lane's int16 anchor
+    __device__ __forceinline__ void issue(uint32_t r, uint32_t col, uint32_t& w1, uint32_t& w2, uint32_t& cc) const {
+        const uint32_t r1 = r ? r - 1 : 0u, ci = col ? col - 1 : 0u;
+        const uint32_t lc = __umulhi(ci, cmagic);
+        cc = ci - lc * cpl;
+        if (PACKED) {
+            const uint32_t o = r1 * rowdw + lc * nds;
+            w1 = hm32[o + (cc >> 2)];
+            w2 = hm32[o + aidx];
+        } else {
+            w1 = hm32[r1 * rowdw + (cc >> 1) * 64 + lc];
+            w2 = 0;
+        }
+    }
+    __device__ __forceinline__ int decode(uint32_t w1, uint32_t w2, uint32_t cc) const {
+        if (PACKED) {
+            const uint32_t an = (w2 >> ash) & 0xFFFFu;
+            const uint32_t b = (w1 >> ((cc & 3) * 8)) & 0xFFu;
+            return (int)(short)an + (int)((b - an) & 0xFFu);
+        }
+        return (int)(short)(w1 >> ((cc & 1) * 16));
+    }
+};
+
+template <int TL, bool PACKED>
+__device__ __forceinline__ void vc_tracex_body(const VcTraceArgs& a, bool valid, uint32_t job, uint32_t slot, uint32_t k, uint32_t type) {
+    const int lane = vc_lane();
+    const uint32_t grp = (uint32_t)lane / TL, gl = (uint32_t)lane % TL, gbase = grp * TL;
+    const uint32_t w = a.w0 + slot;
+    const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
+    uint32_t* out = a.pairs + pj * a.PC;
+    const uint32_t end = valid ? a.job_end[job] : 0u;
+    const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
+    const bool nw = type == 1;
+    const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
+    const uint32_t sq = a.b.win_seq_off[w] + (valid ? k : 0);
+    const uint64_t so = a.b.seq_off[sq];
+    const uint8_t* seq = a.b.bases + so;
+    const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
+    const uint4* recs = a.dp.rec + nb;
+    const uint4* ancs = a.dp.anc + nb;
+    const uint16_t* ovfp = a.dp.ovf + eb;
+    VcCellRd<PACKED> rd;
+    {
+        const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so));
+        rd.hm32 = a.hmat + (uint64_t)(valid ? job : 0) * a.hstride;
+        rd.cpl = cpl ? cpl : 4u; rd.cmagic = vc_magic(rd.cpl);
+        rd.nds = (uint32_t)vc_nds((int)rd.cpl);
+        rd.rowdw = PACKED ? rd.nds * 64 : (rd.cpl / 2) * 64;
+        rd.aidx = rd.cpl >> 2; rd.ash = (rd.cpl & 2) * 8;
+    }
+    const uint4 zero4 = make_uint4(0, 0, 0, 0), none4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    auto gmask = [&](unsigned long long mm) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(mm >> gbase) & ((1u << TL) - 1u); };
+    auto bcast = [&](uint32_t v, uint32_t l) __attribute__((always_inline)) -> uint32_t { return (uint32_t)__shfl((int)v, (int)l, 64); };
+    auto bcast4 = [&](const uint4& v, uint32_t l) __attribute__((always_inline)) -> uint4 { return make_uint4(bcast(v.x, l), bcast(v.y, l), bcast(v.z, l), bcast(v.w, l)); };
+    // element e (0..7) of a chain: the row e+1 links behind
+    auto anc_at = [&](const uint4& c, uint32_t e) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t lo = (e & 2) ? c.y : c.x, hi = (e & 2) ? c.w : c.z;
+        const uint32_t d = (e & 4) ? hi : lo;
+        return (e & 1) ? (d >> 16) : (d & 0xFFFFu);
+    };
+    // a cell including the virtual row 0 and column 0 (setup and rare paths only: it branches)
+    auto Tslow = [&](uint32_t r, uint32_t col) -> int {
+        if (r == 0) return nw ? 0 : -(int)col * g;
+        if (col == 0) return nw ? (int)c0[r - 1] : 0;
+        uint32_t w1, w2, cc;
+        rd.issue(r, col, w1, w2, cc);
+        return rd.decode(w1, w2, cc);
+    };
+
+    bool walking = valid && end != 0;
+    uint32_t gi = end >> 16, gj = end & 0xFFFF, gnout = 0, nspec_ok = 0, nrounds = 0;
+    bool govf = false, gbroken = false;
+    int gT = 0;
+    uint4 grec = zero4, ganc = none4;
+    if (walking) {
+        gT = Tslow(gi, gj);
+        if (gi) { grec = recs[gi - 1]; ganc = ancs[gi - 1]; }
+    }
+    const int mg = m - g, ng = n - g;
+    for (;;) {
+        if (walking && (nw ? (gi == 0 && gj == 0) : (gT == -(int)gj * g))) walking = false;
+        if (!__any(walking)) break;
+        nrounds += (walking && gl == 0) ? 1u : 0u;
+        const bool rowovf = ((grec.x >> 8) & VC_RF_OVF) != 0;                      // in-edges in VcDp::ovf: the loop further down
+        const bool slow = walking && gi != 0 && rowovf;
+        const uint32_t np = (walking && gi != 0 && !rowovf) ? ((grec.x >> 16) & 0xFF) : 0u;     // <= VC_INLINE_PRED < TL
+        const uint32_t code_i = grec.x & 0xFF;
+        // ---- in-edge p = gl of row gi: the row behind it
+        const bool actg = gl < np;
+        const uint32_t wsel = gl < 2 ? grec.y : (gl < 4 ? grec.z : grec.w);
+        const uint32_t pr = actg ? gi - ((gl & 1) ? (wsel >> 16) : (wsel & 0xFFFF)) : 0u;
+        // ---- speculated positions: lane t at (row t links down the first-in-edge chain, gj - t), moving on to row t + 1 links down
+        const bool specable = np != 0 && gj > gl && gl < VC_TX_SPECW;
+        const uint32_t a_me = anc_at(ganc, gl ? gl - 1 : 0u), a_nx = anc_at(ganc, gl < 8 ? gl : 7u);
+        const uint32_t my_i = gl ? a_me : gi;
+        const uint32_t my_in = gl ? a_nx : pr;                                     // lane 0: in-edge 0 itself
+        const bool ok = specable && (gl == 0 || (a_me != 0 && a_me != 0xFFFFu && a_nx != 0xFFFFu));
+        const uint32_t nspec = (uint32_t)__ffs((int)~gmask(__ballot(ok))) - 1;    // leading ones
+        const bool lb = gl < nspec;
+        const bool sl_ = lb && gl != 0;                                            // lanes with a speculated position of their own
+        const uint32_t jk = gj - gl;                                               // column of position gl (lb lanes)
+        // ---- all loads of the round, unconditional (idle requests read row 0 / column 0 addresses and are patched below)
+        //   V: vertical candidate (pr, gj); the last lane of the group reads the horizontal cell (gi, gj - 1) here
+        //   D: diagonal candidate (pr, gj - 1)
+        //   S: speculated diagonal (my_in, jk - 1)   SV: vertical at my position (my_in, jk)   SH: horizontal there (my_i, jk - 1)
+        const bool hl = gl == TL - 1;
+        const uint32_t vr = hl ? (walking ? gi : 0u) : pr, vc = hl ? (gj ? gj - 1 : 0u) : (actg ? gj : 0u);
+        const uint32_t dr = pr, dc = (actg && gj) ? gj - 1 : 0u;
+        const uint32_t sr = sl_ ? my_in : 0u, sc = sl_ ? jk - 1 : 0u;
+        const uint32_t svc = sl_ ? jk : 0u;
+        const uint32_t hr = sl_ ? my_i : 0u;
+        uint32_t v1, v2, vcc, d1w, d2w, dcc, s1, s2, scc, sv1, sv2, svcc, sh1, sh2, shcc;
+        rd.issue(vr, vc, v1, v2, vcc);
+        rd.issue(dr, dc, d1w, d2w, dcc);
+        rd.issue(sr, sc, s1, s2, scc);
+#ifndef VC_TX_NOLOCAL
+        rd.issue(sr, svc, sv1, sv2, svcc);
+        rd.issue(hr, sc, sh1, sh2, shcc);
+#else
+        sv1 = sv2 = svcc = sh1 = sh2 = shcc = 0;
+#endif
+        const uint32_t ri1 = pr ? pr - 1 : 0u, ri2 = sr ? sr - 1 : 0u;
+        const uint4 rr_l = recs[ri1], ra_l = ancs[ri1];
+        const uint4 rn_l = recs[ri2], na_l = ancs[ri2];
+        const uint32_t bs_l = seq[sl_ ? jk - 1 : 0u];
+        const uint32_t bs0 = seq[(walking && gj) ? gj - 1 : 0u];
+        int vcell = rd.decode(v1, v2, vcc), dcell = rd.decode(d1w, d2w, dcc), tv = rd.decode(s1, s2, scc);
+        int svcell = rd.decode(sv1, sv2, svcc), shcell = rd.decode(sh1, sh2, shcc);
+        // column 0 of a real row is not in the matrix (NW: VcFwdArgs::c0, SW: 0): rare, patched with one more load
+        const bool vz = vr != 0 && vc == 0 && (hl ? (walking && gj == 1) : actg);   // horizontal into column 0 / vertical along column 0
+        const bool dz = dr != 0 && dc == 0 && actg && gj == 1;
+        const bool sz = sr != 0 && sc == 0 && sl_, hz_ = hr != 0 && sc == 0 && sl_; // S / SH (same column) at column 0
+        if (__any(vz || dz || sz || hz_)) {
+            const int cv = (nw && vz) ? (int)c0[vr - 1] : 0, cd = (nw && dz) ? (int)c0[dr - 1] : 0, cs = (nw && sz) ? (int)c0[sr - 1] : 0;
+            const int ch = (nw && hz_) ? (int)c0[hr - 1] : 0;
+            if (vz) vcell = cv;
+            if (dz) dcell = cd;
+            if (sz) tv = cs;
+            if (hz_) shcell = ch;
+        }
+        if (vr == 0) vcell = nw ? 0 : -(int)vc * g;                                // the virtual row 0
+        if (dr == 0) dcell = nw ? 0 : -(int)dc * g;
+        if (sr == 0) { tv = nw ? 0 : -(int)sc * g; svcell = nw ? 0 : -(int)svc * g; }
+        uint4 rr = pr ? rr_l : zero4, ranc = pr ? ra_l : none4;
+        uint4 rnext = sr ? rn_l : zero4, nanc = sr ? na_l : none4;
+        uint32_t bs = bs_l;
+        if (gl == 0) { bs = bs0; rnext = rr; nanc = ranc; tv = dcell; }            // position 0's speculated move IS the diagonal through in-edge 0
+        const int hzv = (int)bcast((uint32_t)vcell, gbase + TL - 1);
+        // ---- the confirmed prefix
+        const uint32_t sh_x = (uint32_t)vc_row_shr1((int)rnext.x, 0);              // record of MY position's row: the left lane fetched it (all lanes take part)
+        const int sh_tv = vc_row_shr1(tv, 0);
+        const uint32_t codek = gl ? (sh_x & 0xFFu) : code_i;                       // code of position gl's row
+        const int tprev = gl ? sh_tv : gT;                                         // T at position gl
+        const bool stop_here = !nw && gl != 0 && tprev == -(int)jk * g;            // SW: the walk ends at this position
+        const bool okc = lb && !stop_here && tprev == tv + ((bs == codek) ? mg : ng);
+        const uint32_t f = (uint32_t)__ffs((int)~gmask(__ballot(okc))) - 1;
+        // a row with a single in-edge at the first unconfirmed position: vertical through that in-edge, else horizontal
+#ifdef VC_TX_NOLOCAL
+        const bool single = false;
+#else
+        const bool single = sl_ && gl == f && !stop_here && ((sh_x >> 8) & VC_RF_OVF) == 0 && ((sh_x >> 16) & 0xFF) == 1;
+#endif
+        const bool locv = single && tprev == svcell + g, loch = single && !locv && tprev == shcell;
+        const uint32_t lv = gmask(__ballot(locv)), lh = gmask(__ballot(loch));
+        // ---- the general decision at (gi, gj), in the reference's order
+        const int sc0 = (bs0 == code_i) ? mg : ng;
+        const uint32_t dm = gmask(__ballot(actg && gj != 0 && gT == dcell + sc0));
+        const uint32_t vm = gmask(__ballot(actg && !hl && gT == vcell + g));
+        const bool hmatch = gj != 0 && gT == hzv;
+        // 1 confirmed prefix, 2 diagonal, 3 vertical, 4 horizontal, 5 no move explains the cell, 6 prefix + vertical, 7 prefix + horizontal
+        uint32_t kind = 0, srcl = 0;
+        if (walking) {
+            if (f) { kind = lv ? 6u : (lh ? 7u : 1u); srcl = lv ? f : f - 1; }
+            else if (dm) { kind = 2; srcl = (uint32_t)__ffs((int)dm) - 1; }
+            else if (vm) { kind = 3; srcl = (uint32_t)__ffs((int)vm) - 1; }
+            else if (hmatch) kind = 4;
+            else kind = 5;
+        }
+        // what the group continues from, offered by every lane for its own candidate: row, record + chain, T
+        uint32_t xi = 0; int xT = 0; uint4 xrec = zero4, xanc = none4;
+        if (kind == 1 || kind == 7) { xi = my_in; xT = tv; xrec = rnext; xanc = nanc; }       // lane f-1: the row it moved on to (7: T comes from lane f)
+        else if (kind == 6) { xi = my_in; xT = svcell; xrec = rnext; xanc = nanc; }           // lane f: the row behind its in-edge, same column
+        else if (kind == 2) { xi = pr; xT = dcell; xrec = rr; xanc = ranc; }
+        else if (kind == 3) { xi = pr; xT = vcell; xrec = rr; xanc = ranc; }
+        // rows whose in-edges live in the overflow list (more than VC_INLINE_PRED): TL of them per pass; a diagonal match
+        // anywhere beats every vertical one, the first vertical match beats the horizontal move
+        if (__any(slow)) {
+            const uint32_t npf = slow ? grec.z : 0u;
+            bool have_v = false, found_d = false;
+            for (uint32_t base = 0; __any(slow && !found_d && base < npf); base += TL) {
+                const uint32_t p = base + gl;
+                const bool act2 = slow && !found_d && p < npf;
+                uint32_t pr2 = 0; uint4 rr2 = zero4, ra2 = none4; int d2 = 0, v2c = 0;
+                if (act2) {
+                    pr2 = gi - (uint32_t)ovfp[grec.y + p];
+                    if (pr2) { rr2 = recs[pr2 - 1]; ra2 = ancs[pr2 - 1]; }
+                    v2c = Tslow(pr2, gj);
+                    if (gj != 0) d2 = Tslow(pr2, gj - 1);
+                }
+                const uint32_t dm2 = gmask(__ballot(act2 && gj != 0 && gT == d2 + sc0));
+                const uint32_t vm2 = gmask(__ballot(act2 && gT == v2c + g));
+                if (slow && !found_d) {
+                    if (dm2) {
+                        found_d = true; kind = 2; srcl = (uint32_t)__ffs((int)dm2) - 1;
+                        if (gl == srcl) { xi = pr2; xT = d2; xrec = rr2; xanc = ra2; }
+                    } else if (vm2 && !have_v) {
+                        have_v = true; kind = 3; srcl = (uint32_t)__ffs((int)vm2) - 1;
+                        if (gl == srcl) { xi = pr2; xT = v2c; xrec = rr2; xanc = ra2; }
+                    }
+                }
+            }
+        }
+        if (kind == 5) { gbroken = true; walking = false; kind = 0; }
+        const uint32_t nmov = (kind == 1 ? f : (kind >= 6 ? f + 1 : (kind != 0 ? 1u : 0u)));
+        if (nmov && gnout + nmov > a.PC) { govf = true; walking = false; kind = 0; }
+        const uint32_t src = gbase + srcl;
+        const uint32_t b_i = bcast(xi, src);
+        const int b_T = (int)bcast((uint32_t)xT, src);
+        const int b_hT = (int)bcast((uint32_t)shcell, gbase + f);                 // kind 7: the horizontal cell lane f read
+        const uint4 b_rec = bcast4(xrec, src), b_anc = bcast4(xanc, src);
+        if (kind == 1 || kind >= 6) {
+            if (gl < f) out[gnout + gl] = (my_i << 16) | jk;
+            if (kind == 6 && gl == f) out[gnout + f] = my_i << 16;                 // vertical: row only
+            if (kind == 7 && gl == f) out[gnout + f] = jk;                         // horizontal: column only
+            gnout += nmov; nspec_ok += f;
+            gi = b_i; gT = kind == 7 ? b_hT : b_T; grec = b_rec; ganc = b_anc;
+            gj -= kind == 6 ? f : nmov;
+        } else if (kind == 2) {
+            if (gl == 0) out[gnout] = (gi << 16) | gj;
+            gnout++;
+            gi = b_i; gj -= 1; gT = b_T; grec = b_rec; ganc = b_anc;
+        } else if (kind == 3) {
+            if (gl == 0) out[gnout] = gi << 16;
+            gnout++;
+            gi = b_i; gT = b_T; grec = b_rec; ganc = b_anc;
+        } else if (kind == 4) {
+            if (gl == 0) out[gnout] = gj;
+            gnout++;
+            gj -= 1; gT = hzv;
+        }
+    }
+    if (valid && gl == 0) {
+        if (gbroken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, gi); gnout = 0; }
+        if (govf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, gnout); gnout = 0; }
+        a.npairs[pj] = gnout;
+    }
+    {   // statistics: summed over the wave first, then one of VC_STAT_SLOTS counter sets
+        uint32_t s0 = (valid && gl == 0) ? gnout : 0u, s1x = (valid && gl == 0) ? nspec_ok : 0u, s2x = (valid && gl == 0) ? nrounds : 0u;
+#pragma unroll
+        for (int o = TL; o < 64; o <<= 1) { s0 += (uint32_t)__shfl_xor((int)s0, o, 64); s1x += (uint32_t)__shfl_xor((int)s1x, o, 64); s2x += (uint32_t)__shfl_xor((int)s2x, o, 64); }
+        if (lane == 0) {
+            unsigned long long* st = vc_stat_slot(a.stat);
+            atomicAdd(st + 4, (unsigned long long)s0); atomicAdd(st + 5, (unsigned long long)s1x); atomicAdd(st + 6, (unsigned long long)s2x);
+        }
+    }
+}
+
+template <int TL>
+__global__ __launch_bounds__(64) void k_tracex(VcTraceArgs a) {
+    VC_LATENCY_KERNEL_PRIO();
+    constexpr uint32_t TG = 64 / TL;
+    const uint32_t grp = (uint32_t)vc_lane() / TL;
+    const uint32_t njobs = a.nslots * a.group;
+    const uint32_t job = blockIdx.x * TG + grp;
+    bool valid = job < njobs;
+    const uint32_t slot = valid ? job / a.group : 0, k = valid ? a.k0 + job % a.group : 0;
+    const uint32_t w = a.w0 + slot;
+    const uint32_t type = valid ? (uint32_t)a.job_type[job] : 255u;
+    valid = valid && type < 2;                                // 255: nothing to walk; 2, 3: k_fwd_wide's, walked by k_trace
+    if (valid && a.b.status[w] != VC_WIN_OK) valid = false;
+    if (!__any(valid)) return;
+    // stored form of the alignment's matrix (vc_row_packed): one form per wave almost always; a mixed wave walks twice
+    bool packed = false;
+    if (valid) {
+        const uint32_t sq = a.b.win_seq_off[w] + k;
+        const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - a.b.seq_off[sq]));
+        const bool nw = type == 1;
+        packed = vc_row_packed(nw ? a.m : a.sm, nw ? a.n : a.sn, nw ? a.g : a.sg, (int)cpl);
+    }
+    if (__any(valid && packed)) vc_tracex_body<TL, true>(a, valid && packed, job, slot, k, type);
+    if (__any(valid && !packed)) vc_tracex_body<TL, false>(a, valid && !packed, job, slot, k, type);
 }
 
 // ------------------------------------------------------------------------------------------------
