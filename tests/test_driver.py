@@ -1,0 +1,155 @@
+"""the two-round driver (`python -m vechat_amd.driver`, reference: scripts/vechat).  CPU tests follow the
+command lines and the file hand-off with stand-ins for the external tools; the GPU test runs both rounds on the device with
+a stub overlapper and checks that the reads come out closer to their haplotypes."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from vechat_amd import driver
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STUBS = os.path.join(HERE, "stubs")
+OVL = f"{sys.executable} {os.path.join(STUBS, 'stub_overlapper.py')} {{targets}} {{reads}} {{out}}"
+POL = f"{sys.executable} {os.path.join(STUBS, 'stub_polisher.py')}"
+
+
+def simulate(path, n_reads=12, genome_len=3000, read_len=1800, err=0.10, seed=5, fastq=True):
+    """Reads from two haplotypes (SNPs every ~150 bp) of a random genome, both strands, names <id>_<start>_<end>_<strand>."""
+    rng = np.random.default_rng(seed)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    g = rng.choice(np.frombuffer(b"ACGT", np.uint8), genome_len)
+    haps = [g.copy(), g.copy()]
+    for p in range(75, genome_len, 150):
+        haps[1][p] = rng.choice([c for c in b"ACGT" if c != g[p]])
+    truth, recs = {}, []
+    for k in range(n_reads):
+        h = k % 2
+        s = int(rng.integers(0, genome_len - read_len + 1)) if k >= 2 else 0
+        e = s + read_len
+        src = haps[h][s:e]
+        out = bytearray()
+        for c in src:
+            r = rng.random()
+            if r < err * 0.3:
+                continue
+            if r < err * 0.7:
+                out.append(int(rng.choice(np.frombuffer(b"ACGT", np.uint8)))); out.append(int(c))
+            elif r < err:
+                out.append(int(rng.choice([x for x in b"ACGT" if x != c])))
+            else:
+                out.append(int(c))
+        strand = "+" if k % 3 else "-"
+        seq, tr = bytes(out), bytes(src)
+        if strand == "-":
+            seq = bytes(comp[c] for c in reversed(seq)); tr = bytes(comp[c] for c in reversed(tr))
+        name = f"h{h}r{k}_{s}_{e}_{strand}"
+        truth[name] = tr
+        recs.append((name, seq))
+    with open(path, "w") as f:
+        for name, seq in recs:
+            if fastq:
+                f.write(f"@{name}\n{seq.decode()}\n+\n{'5' * len(seq)}\n")
+            else:
+                f.write(f">{name}\n{seq.decode()}\n")
+    return recs, truth
+
+
+def run_driver(tmp_path, monkeypatch, extra, fastq=True, n_reads=6):
+    reads = tmp_path / ("reads.fastq" if fastq else "reads.fasta")
+    recs, _ = simulate(str(reads), n_reads=n_reads, fastq=fastq)
+    log = tmp_path / "polisher.log"
+    monkeypatch.setenv("VC_STUB_LOG", str(log))
+    out = tmp_path / "out.fa"
+    rc = driver.main([str(reads), "-o", str(out), "--workdir", str(tmp_path / "work"), "--overlapper-r1", OVL, "--overlapper-r2", OVL,
+                      "--polisher", POL] + extra)
+    assert rc == 0
+    calls = [json.loads(l) for l in open(log)]
+    return recs, calls, out, tmp_path / "work", reads
+
+
+def test_two_rounds_command_lines_and_hand_off(tmp_path, monkeypatch):
+    recs, calls, out, work, reads = run_driver(tmp_path, monkeypatch, ["-t", "3"])
+    tmp1 = str(work / "reads.corrected.tmp1.fa")
+    paf = str(work / "overlap.paf")
+    # round 1: vechat_racon -f -p -d 0.2 -s 0.2 -t T reads overlap.paf reads (scripts/vechat:70-72); round 2: -f -t T on round 1's output (:91-93)
+    assert calls == [["-f", "-p", "-d", "0.2", "-s", "0.2", "-t", "3", str(reads), paf, str(reads)],
+                     ["-f", "-t", "3", tmp1, paf, tmp1]]
+    got = open(out).read().split("\n")
+    assert [l[1:] for l in got[0::2] if l] == [n for n, _ in recs]
+    left = sorted(os.listdir(work))
+    assert not [f for f in left if f.startswith("reads.corrected.tmp") or f.startswith("reads_chunk") or f.startswith("query_sequences")], left
+    assert os.path.getsize(paf) > 0                         # the stub overlapper found the simulated overlaps
+
+
+def test_linear_is_one_round(tmp_path, monkeypatch):
+    _, calls, _, _, reads = run_driver(tmp_path, monkeypatch, ["--linear", "-u"])
+    assert len(calls) == 1 and calls[0][:4] == ["-f", "-u", "-t", "1"] and calls[0][-1] == str(reads)
+
+
+@pytest.mark.parametrize("fastq", [True, False])
+def test_split_chunks_targets_and_narrows_queries(tmp_path, monkeypatch, fastq):
+    per = 4 if fastq else 2
+    recs, calls, out, work, reads = run_driver(tmp_path, monkeypatch, ["--split", "--split-size", str(2 * per)], fastq=fastq, n_reads=6)
+    # round 1: 6 records, 2 per chunk; round 2 splits the FASTA of round 1 with split_size/2 lines for FASTQ input (scripts/vechat:318-319)
+    assert len(calls) == 6
+    r1, r2 = calls[:3], calls[3:]
+    assert all(c[:2] == ["-f", "-p"] for c in r1) and all(c[0] == "-f" and "-p" not in c for c in r2)
+    assert [os.path.basename(c[-1]) for c in r1] == [f"reads_chunk{k:02d}.{'fq' if fastq else 'fa'}" for k in range(3)]
+    assert [os.path.basename(c[-1]) for c in r2] == [f"reads_chunk{k:02d}.fa" for k in range(3)]
+    assert all(os.path.basename(c[-3]).startswith("query_sequences.tmp.") for c in calls)      # scripts/vechat:54-57
+    names = [l[1:] for l in open(out).read().split("\n")[0::2] if l]
+    assert names == [n for n, _ in recs]                     # chunk outputs concatenated in order
+    assert not [f for f in os.listdir(work) if f.startswith("reads_chunk") or f.startswith("reads.corrected.tmp")]
+
+
+def test_helpers(tmp_path):
+    p = tmp_path / "x.fa"
+    p.write_text(">a\nAC\n>b\nGT\n>c\nAA\n")
+    assert driver.fq_or_fa(str(p)) == "fa"
+    chunks = driver.split_lines(str(p), 4, "fa", str(tmp_path))
+    assert [os.path.basename(c) for c in chunks] == ["reads_chunk00.fa", "reads_chunk01.fa"]
+    assert open(chunks[1]).read() == ">c\nAA\n"
+    q = tmp_path / "x.fq"
+    q.write_text("@a\nAC\n+\n!!\n")
+    assert driver.fq_or_fa(str(q)) == "fq"
+    with pytest.raises(ValueError):
+        (tmp_path / "bad").write_text("hello\n")
+        driver.fq_or_fa(str(tmp_path / "bad"))
+
+
+def _edit_distance(a, b):
+    a, b = np.frombuffer(a, np.uint8), np.frombuffer(b, np.uint8)
+    prev = np.arange(len(b) + 1)
+    for i in range(1, len(a) + 1):
+        cur = np.empty_like(prev)
+        cur[0] = i
+        sub = prev[:-1] + (b != a[i - 1])
+        cur[1:] = np.minimum(sub, prev[1:] + 1)
+        # horizontal pass
+        for j in range(1, len(b) + 1):
+            if cur[j - 1] + 1 < cur[j]:
+                cur[j] = cur[j - 1] + 1
+        prev = cur
+    return int(prev[-1])
+
+
+@pytest.mark.gpu
+def test_both_rounds_on_the_device(built, tmp_path):
+    """reads.fastq -> round 1 (haplotype-aware, -f -p -d 0.2 -s 0.2) -> round 2 (linear, -f) through the real polisher; overlaps
+    from the stub overlapper (plain PAF, aligned on the device).  Every read is corrected and ends up much closer to the
+    haplotype it was drawn from."""
+    reads = tmp_path / "reads.fastq"
+    recs, truth = simulate(str(reads), n_reads=16, genome_len=2400, read_len=1500, err=0.10, seed=9)
+    out = tmp_path / "out.fa"
+    rc = driver.main([str(reads), "-o", str(out), "--workdir", str(tmp_path / "work"), "--overlapper-r1", OVL, "--overlapper-r2", OVL + " 400",
+                      "-u"])
+    assert rc == 0
+    lines = open(out).read().split("\n")
+    got = {lines[i][1:].split()[0]: lines[i + 1].encode() for i in range(0, len(lines) - 1, 2)}
+    assert set(got) == {n for n, _ in recs}
+    before = sum(_edit_distance(s, truth[n]) for n, s in recs[:6])
+    after = sum(_edit_distance(got[n], truth[n]) for n, _ in recs[:6])
+    assert after * 3 < before, (before, after)
