@@ -119,6 +119,11 @@ int vc_collect_device(vc_ctx* ctx, void* d_cons, uint64_t cons_cap, void* d_cons
 int vc_get_stats(vc_ctx* ctx, vc_stats* s);
 /* diagnostics: per-window (site << 16) | detail of the kernel that took the window out of VC_WIN_OK */
 int vc_debug_errinfo(vc_ctx* ctx, uint32_t* out /*[n_windows]*/);
+/* Test hooks for localising a divergence (tests/golden/stages.json): stop vc_run after a stage (kind 1 build layer `index`
+ * added, 2 prune `index` done, 3 AddWeights round `index` done, 0 run to the end) and digest a window's graph / last alignment
+ * where it stands, in the record format of the oracle's vco_window_stages.  Single-chunk batches. */
+int vc_debug_stop_after(vc_ctx* ctx, uint32_t kind, uint32_t index);
+int vc_debug_stage_digest(vc_ctx* ctx, uint32_t window, int with_pairs, uint64_t* out /*[8], [0..1] untouched*/);
 void* vc_stream(vc_ctx* ctx);                         /* the hipStream_t the context launches on               */
 int   vc_set_profile(vc_ctx* ctx, int profile);       /* change vc_params.profile of a live context (0, 1, 2)  */
 

@@ -65,6 +65,15 @@ static void g_free(graph* g) {
     memset(g, 0, sizeof(*g));
 }
 
+/* ------------------------------------------------------------------ stage digests (vco_window_stages)
+ * Same records as oracle/ref_harness.cpp:vcref_window_stages writes for the real reference: 8 x u64 per stage
+ * (kind, index, nodes, edges, hash(nodes), hash(edges), pairs, hash(pairs)), FNV-1a over little-endian fields. */
+typedef struct { uint64_t* d; uint32_t n, cap; int overflow; } stagevec;
+static __thread stagevec* g_stages = NULL;
+static uint64_t fnv_u8(uint64_t h, uint8_t b) { h ^= b; return h * 1099511628211ull; }
+static uint64_t fnv_u32(uint64_t h, uint32_t v) { for (int i = 0; i < 4; ++i) h = fnv_u8(h, (uint8_t)(v >> (8 * i))); return h; }
+static uint64_t fnv_u64(uint64_t h, uint64_t v) { for (int i = 0; i < 8; ++i) h = fnv_u8(h, (uint8_t)(v >> (8 * i))); return h; }
+
 /* Graph::AddNode, graph.cpp:88-92 */
 static uint32_t g_add_node(graph* g, uint32_t code) {
     if (g->n_nodes == g->cap_nodes) {
@@ -617,6 +626,25 @@ static uint32_t* make_weights(const seqview* s, int use_qual) {
     return W;
 }
 
+static void stage_emit(uint64_t kind, uint64_t index, const graph* g, const alnvec* A) {
+    if (!g_stages) return;
+    if (g_stages->n + 8 > g_stages->cap) { g_stages->overflow = 1; return; }
+    const uint64_t seed = 1469598103934665603ull;
+    uint64_t hn = seed, he = seed, hp = seed, np = 0;
+    if (g) {
+        for (uint32_t v = 0; v < g->n_nodes; ++v) {
+            hn = fnv_u8(hn, (uint8_t)g->decoder[g->code[v]]);
+            hn = fnv_u32(hn, g->aligned[v].n);
+            for (uint32_t k = 0; k < g->aligned[v].n; ++k) hn = fnv_u32(hn, g->aligned[v].d[k]);
+        }
+        for (uint32_t e = 0; e < g->n_edges; ++e) { he = fnv_u32(he, g->tail[e]); he = fnv_u32(he, g->head[e]); he = fnv_u64(he, (uint64_t)g->weight[e]); }
+    }
+    if (A) { np = A->n / 2; for (uint32_t k = 0; k < A->n; ++k) hp = fnv_u32(hp, (uint32_t)A->d[k]); }
+    uint64_t* r = g_stages->d + g_stages->n;
+    r[0] = kind; r[1] = index; r[2] = g ? g->n_nodes : 0; r[3] = g ? g->n_edges : 0; r[4] = g ? hn : 0; r[5] = g ? he : 0; r[6] = np; r[7] = A ? hp : 0;
+    g_stages->n += 8;
+}
+
 /* the build loop shared by both overloads, window.cpp:100-136 / :239-298 */
 static int build_graph(graph* G, const seqview* sv, uint32_t nseq, uint32_t L, const vco_params* p,
                        double* total, int fasta, vco_stats* stats) {
@@ -646,6 +674,7 @@ static int build_graph(graph* G, const seqview* sv, uint32_t nseq, uint32_t L, c
         W = make_weights(s, s->has_qual);
         rc = g_add_alignment(G, &A, s->seq, s->len, W);
         free(W);
+        if (rc == 0) stage_emit(1, j, G, &A);
         if (total) {
             if (!s->has_qual) *total += (double)s->len;                              /* :283 */
             else for (uint32_t q = 0; q < s->len; ++q) *total += g_qlut_d[s->qual[q]];  /* :292-296 */
@@ -687,6 +716,7 @@ static int window_hap(const seqview* sv, uint32_t nseq, int fasta, const vco_par
     graph* P = (graph*)malloc(sizeof(graph));
     g_largest_subgraph(&G, P);                            /* :319 */
     g_free(&G);
+    stage_emit(2, 0, P, NULL);
 
     uint32_t offset = (uint32_t)(0.01 * L);
     alnvec A = {0, 0, 0};
@@ -704,15 +734,18 @@ static int window_hap(const seqview* sv, uint32_t nseq, int fasta, const vco_par
             free(W);
         }
         if (rc) break;
+        stage_emit(3, k, P, NULL);
         g_prune(P, 0, p->min_confidence, p->min_support, avg);
         graph* Q = (graph*)malloc(sizeof(graph));
         g_largest_subgraph(P, Q);
         g_free(P); free(P);
         P = Q;
+        stage_emit(2, k + 1, P, NULL);
     }
     if (rc == 0) {
         rc = g_align(P, 0, p->sw_match, p->sw_mismatch, p->sw_gap, sv[0].seq, sv[0].len, &A, stats);  /* :391 */
         if (rc == 0) {
+            stage_emit(4, 0, P, &A);
             for (uint32_t k = 0; k < A.n / 2; ++k) {      /* GenerateCorrectedSequence, graph.cpp:1167-1179 */
                 if (A.d[2 * k] == -1) continue;
                 b_push(cons, (uint8_t)P->decoder[P->code[A.d[2 * k]]]);
@@ -794,6 +827,24 @@ int vco_run(const vco_batch* b, const vco_params* p, uint32_t w0, uint32_t w1,
 }
 
 /* ------------------------------------------------------------------ spoa KAT flow */
+/* Stage digests of window w (haplotype overload), see stage_emit; returns the number of records through n_rec. */
+int vco_window_stages(const vco_batch* b, const vco_params* p, uint32_t w, uint64_t* rec, uint32_t rec_cap, uint32_t* n_rec) {
+    stagevec sv = {rec, 0, rec_cap * 8, 0};
+    uint64_t* off = (uint64_t*)calloc((size_t)w + 2, sizeof(uint64_t));      /* vco_run indexes both by window number */
+    uint8_t* pol = (uint8_t*)calloc((size_t)w + 1, 1);
+    const uint32_t s0 = b->win_seq_off[w], s1 = b->win_seq_off[w + 1];
+    uint64_t cap = 4096;
+    for (uint32_t s = s0; s < s1; ++s) cap += b->seq_off[s + 1] - b->seq_off[s];
+    uint8_t* cons = (uint8_t*)malloc(cap);
+    g_stages = &sv;
+    int rc = vco_run(b, p, w, w + 1, off, cons, cap, pol, NULL);
+    g_stages = NULL;
+    free(cons); free(off); free(pol);
+    *n_rec = sv.n / 8;
+    if (rc) return rc;
+    return sv.overflow ? -2 : 0;
+}
+
 static int spoa_build(graph* G, uint32_t n_seqs, const uint8_t* const* seqs, const uint32_t* lens,
                       const uint8_t* const* quals, int type, int m, int n, int g) {
     lut_init();

@@ -70,6 +70,10 @@ int vco_spoa_align_probe(uint32_t n_seqs, const uint8_t* const* seqs, const uint
                          int32_t* pairs, uint32_t pairs_cap, uint32_t* n_pairs,
                          uint32_t* rank_to_node, uint32_t rank_cap, uint32_t* n_nodes);
 
+/* Per-stage digests of one window's haplotype-overload run (graph after every layer, after every prune and AddWeights
+ * round, the final alignment) in the record format of oracle/ref_harness.cpp:vcref_window_stages: 8 x u64 each. */
+int vco_window_stages(const vco_batch* b, const vco_params* p, uint32_t w, uint64_t* rec, uint32_t rec_cap, uint32_t* n_rec);
+
 /* Quality -> weight table, graph.cpp:165-170 / window.cpp:366: uint32((1-10^((33-q)/10))*1000). */
 void vco_weight_lut(uint32_t lut[256]);
 

@@ -157,6 +157,24 @@ def main():
     add("deep_64", capi.synth_cfg(112, 100, 64), 1)
     add("pacbio_500x32", capi.synth_cfg(1001, 500, 32), 1)
 
+    # the final local alignment of the backbone is EMPTY (window.cpp:391-394 -> GenerateCorrectedSequence of nothing,
+    # graph.cpp:1167-1179): the layers outvote a backbone that shares no base with them, the pruned graph keeps only their
+    # path, and generate_consensus returns true with an empty consensus
+    def disjoint(win):
+        L = len(win["backbone"])
+        win["backbone"] = "A" * L
+        for l in win["layers"]:
+            l["seq"] = "C" * len(l["seq"])
+            l["begin"], l["end"] = 0, L - 1
+    add("empty_final_alignment", capi.synth_cfg(113, 60, 8), 1, disjoint)
+
+    # more than six distinct bytes in one column (IUPAC reads): aligned groups beyond A/C/G/T/N (graph.cpp:258-277)
+    def iupac(win):
+        alpha = "ACGTURYSWKMBDHVN"
+        for l in win["layers"]:
+            l["seq"] = "".join(rnd.choice(alpha) if rnd.random() < 0.35 else c for c in l["seq"])
+    add("iupac_columns", capi.synth_cfg(114, 120, 24, frac_partial=0.2), 2, iupac)
+
     json.dump(dict(params=dict(match=3, mismatch=-5, gap=-4, min_confidence=0.2, min_support=0.2, num_prune=3,
                                window_type=1, trim=1), windows=cases),
               open(os.path.join(HERE, "windows.json"), "w"), indent=0)

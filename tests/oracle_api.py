@@ -52,8 +52,25 @@ def load_oracle():
         lib.vco_spoa_consensus.restype = C.c_int
         lib.vco_spoa_align_probe.restype = C.c_int
         lib.vco_weight_lut.argtypes = [C.POINTER(C.c_uint32)]
+        lib.vco_window_stages.argtypes = [C.POINTER(VcBatch), C.POINTER(VcoParams), C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32,
+                                          C.POINTER(C.c_uint32)]
+        lib.vco_window_stages.restype = C.c_int
         _oracle = lib
     return _oracle
+
+
+def oracle_stages(batch: Batch, params: VcParams, w=0):
+    """Per-stage digests of window w (haplotype overload): list of [kind, index, nodes, edges, hash, hash, pairs, hash]."""
+    lib = load_oracle()
+    vb = batch.as_struct()
+    vp = vco_params(params)
+    cap = 3 * int(batch.win_seq_off[w + 1] - batch.win_seq_off[w]) + 64
+    rec = np.zeros(8 * cap, np.uint64)
+    n = C.c_uint32(0)
+    rc = lib.vco_window_stages(C.byref(vb), C.byref(vp), w, rec.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"vco_window_stages failed: {rc}")
+    return [[int(x) for x in rec[8 * i:8 * i + 8]] for i in range(n.value)]
 
 
 def have_ref(kind="sse41"):

@@ -18,7 +18,7 @@ def records(path):
 
 def origin(name):
     p = name.split("_")
-    return int(p[-3]), int(p[-2]), p[-1]
+    return int(p[-3]), int(p[-2]), p[-1][:1]          # fragment correction appends an 'r' to the name per round (src/polisher.cpp:525)
 
 
 def span(lo, hi, g0, g1, length, strand):

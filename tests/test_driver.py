@@ -120,27 +120,27 @@ def test_helpers(tmp_path):
         driver.fq_or_fa(str(tmp_path / "bad"))
 
 
-def _edit_distance(a, b):
+def _fit_distance(a, b):
+    """Edit distance of `a` against the best-matching substring of `b` (a corrected read may have lost its ends to windows
+    without coverage: what counts is the error rate of what is there)."""
     a, b = np.frombuffer(a, np.uint8), np.frombuffer(b, np.uint8)
-    prev = np.arange(len(b) + 1)
+    prev = np.zeros(len(b) + 1, np.int64)
     for i in range(1, len(a) + 1):
         cur = np.empty_like(prev)
         cur[0] = i
-        sub = prev[:-1] + (b != a[i - 1])
-        cur[1:] = np.minimum(sub, prev[1:] + 1)
-        # horizontal pass
-        for j in range(1, len(b) + 1):
+        cur[1:] = np.minimum(prev[:-1] + (b != a[i - 1]), prev[1:] + 1)
+        for j in range(1, len(b) + 1):                        # horizontal pass
             if cur[j - 1] + 1 < cur[j]:
                 cur[j] = cur[j - 1] + 1
         prev = cur
-    return int(prev[-1])
+    return int(prev.min())
 
 
 @pytest.mark.gpu
 def test_both_rounds_on_the_device(built, tmp_path):
     """reads.fastq -> round 1 (haplotype-aware, -f -p -d 0.2 -s 0.2) -> round 2 (linear, -f) through the real polisher; overlaps
     from the stub overlapper (plain PAF, aligned on the device).  Every read is corrected and ends up much closer to the
-    haplotype it was drawn from."""
+    haplotype it was drawn from (error rate of the corrected bases, ends lost to uncovered windows not counted)."""
     reads = tmp_path / "reads.fastq"
     recs, truth = simulate(str(reads), n_reads=16, genome_len=2400, read_len=1500, err=0.10, seed=9)
     out = tmp_path / "out.fa"
@@ -148,8 +148,10 @@ def test_both_rounds_on_the_device(built, tmp_path):
                       "-u"])
     assert rc == 0
     lines = open(out).read().split("\n")
-    got = {lines[i][1:].split()[0]: lines[i + 1].encode() for i in range(0, len(lines) - 1, 2)}
+    got = {lines[i][1:].split()[0].rstrip("r"): lines[i + 1].encode() for i in range(0, len(lines) - 1, 2)}    # one 'r' per round
     assert set(got) == {n for n, _ in recs}
-    before = sum(_edit_distance(s, truth[n]) for n, s in recs[:6])
-    after = sum(_edit_distance(got[n], truth[n]) for n, _ in recs[:6])
-    assert after * 3 < before, (before, after)
+    picks = recs[:6]
+    before = sum(_fit_distance(s, truth[n]) for n, s in picks) / sum(len(s) for _, s in picks)
+    after = sum(_fit_distance(got[n], truth[n]) for n, _ in picks) / sum(len(got[n]) for n, _ in picks)
+    assert all(len(got[n]) > 0.7 * len(truth[n]) for n, _ in picks)
+    assert after * 3 < before, (before, after)               # ~10 % raw error rate

@@ -421,3 +421,26 @@ def test_wide_alphabet_aligned_groups_beyond_five(built):
     c = HipContext(device=0)
     _check(c, lower, "26-letter alphabet")
     c.close()
+
+
+def test_stage_digests_on_the_device(built):
+    """SURVEY 8(c) golden intermediates on the HIP path: the run is stopped after every build layer, every prune, every
+    AddWeights round and at the end, and the window's graph (node bytes, aligned lists, edges with weights) and the
+    alignment walked last are digested and compared with what the REAL reference had at that stage
+    (tests/golden/stages.json).  A kernel regression shows up at the first stage it touches."""
+    import json
+    import os
+    st = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stages.json")))
+    gold = fixtures.load_windows()
+    by_name = {w["name"]: w for w in gold["windows"]}
+    c = HipContext(device=0)
+    for name, exp in st["windows"].items():
+        c.submit(fixtures.fixture_batch([by_name[name]]))
+        for k, e in enumerate(exp):
+            kind, index = e[0], e[1]
+            got = c.stage_digest(kind, index)
+            want = [e[2], e[3], int(e[4], 16), int(e[5], 16), e[6], int(e[7], 16)]
+            if kind in (2, 3):
+                got, want = got[:4], want[:4]
+            assert got == want, (name, "first differing stage", k, e[:2], got, want)
+    c.close()

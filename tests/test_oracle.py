@@ -73,3 +73,22 @@ def test_alignment_and_rank_internals_match_reference(built):
         a = oa.spoa_align_probe(oa.load_oracle(), "vco", seqs[:20], quals[:20], build_type, 3, -5, -4, seqs[21], qtype)
         b = oa.spoa_align_probe(oa.load_ref(), "vcref", seqs[:20], quals[:20], build_type, 3, -5, -4, seqs[21], qtype)
         assert a == b
+
+
+def test_stage_digests_match_the_reference(built):
+    """SURVEY 8(c) golden intermediates: the graph after every layer, after every prune and AddWeights round, and the final
+    alignment, as digests taken from the real reference (tests/golden/stages.json, generator make_stages.py).  A mismatch
+    names the first stage that differs -- incl. the window whose final alignment is empty and the IUPAC one."""
+    import json
+    import os
+    st = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stages.json")))
+    gold = fixtures.load_windows()
+    by_name = {w["name"]: w for w in gold["windows"]}
+    assert len(st["windows"]) >= 5
+    for name, exp in st["windows"].items():
+        batch = fixtures.fixture_batch([by_name[name]])
+        got = oa.oracle_stages(batch, capi.default_params(mode=0), 0)
+        got = [[r[0], r[1], r[2], r[3], f"{r[4]:016x}", f"{r[5]:016x}", r[6], f"{r[7]:016x}"] for r in got]
+        assert len(got) == len(exp), (name, len(got), len(exp))
+        for k, (g, e) in enumerate(zip(got, exp)):
+            assert g == e, (name, "first differing stage", k, g, e)

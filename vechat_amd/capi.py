@@ -261,6 +261,10 @@ def load_hip():
         lib.vc_get_stats.restype = C.c_int
         lib.vc_debug_errinfo.argtypes = [vp, C.POINTER(C.c_uint32)]
         lib.vc_debug_errinfo.restype = C.c_int
+        lib.vc_debug_stop_after.argtypes = [vp, C.c_uint32, C.c_uint32]
+        lib.vc_debug_stop_after.restype = C.c_int
+        lib.vc_debug_stage_digest.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]
+        lib.vc_debug_stage_digest.restype = C.c_int
         lib.vc_set_profile.argtypes = [vp, C.c_int]
         lib.vc_set_profile.restype = C.c_int
         lib.vc_stream.argtypes = [vp]

@@ -107,6 +107,7 @@ struct vc_ctx {
     bool trace_wave = true;
     int trace_impl = 1;           // 1: k_tracew (16 lanes, two round trips per round, LDS table); 2 / 3: k_tracex with 8 / 16 lanes per alignment
                                   // (one round trip, no LDS, a third of the instructions -- measured equal alone and 2 % behind beside k_fwd)
+    uint32_t dbg_stop_kind = 0, dbg_stop_index = 0;   // vc_debug_stop_after: leave the chunk's graphs as they are after that stage
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
@@ -848,9 +849,11 @@ int vc_run(vc_ctx* c) {
             max_layers = std::max(max_layers, c->works[s].layers);
         }
         int rc;
-        for (uint32_t j = 1; j <= max_layers; ++j)
+        for (uint32_t j = 1; j <= max_layers; ++j) {
             for (uint32_t s = 0; s < S; ++s)
                 if (c->works[s].active && j <= c->works[s].layers && (rc = pl.build_layer(c->works[s], j))) return rc;
+            if (c->dbg_stop_kind == 1 && c->dbg_stop_index == j) { c->ran = false; return VC_OK; }
+        }
         if (c->prm.mode == 1) {
             for (uint32_t s = 0; s < S; ++s) {
                 if (!c->works[s].active) continue;
@@ -863,9 +866,11 @@ int vc_run(vc_ctx* c) {
             const bool more = r + 1 < c->prm.num_prune;
             for (uint32_t s = 0; s < S; ++s)
                 if (c->works[s].active && c->works[s].layers && (rc = pl.prune(c->works[s], more))) return rc;
+            if (c->dbg_stop_kind == 2 && c->dbg_stop_index == r) { c->ran = false; return VC_OK; }
             if (!more) break;
             for (uint32_t s = 0; s < S; ++s)
                 if (c->works[s].active && c->works[s].layers && (rc = pl.realign(c->works[s]))) return rc;
+            if (c->dbg_stop_kind == 3 && c->dbg_stop_index == r) { c->ran = false; return VC_OK; }
         }
         for (uint32_t s = 0; s < S; ++s) {
             if (!c->works[s].active) continue;
@@ -960,6 +965,67 @@ int vc_debug_errinfo(vc_ctx* c, uint32_t* out) {
     if (!c || !out || !c->have_batch) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(out, c->b.errinfo, (size_t)c->b.n_windows * 4, hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+// Test hook (tests/test_gpu.py::test_stage_digests_on_the_device): make vc_run return after a given stage -- kind 1: build
+// layer `index` added; 2: prune + LargestSubgraph number `index` done; 3: AddWeights round `index` done; 0: run to the end --
+// so that vc_debug_stage_digest can look at the graphs where they stand.  A run stopped this way has no result to collect.
+int vc_debug_stop_after(vc_ctx* c, uint32_t kind, uint32_t index) {
+    if (!c || kind > 3) return VC_ERR_ARG;
+    c->dbg_stop_kind = kind; c->dbg_stop_index = index;
+    return VC_OK;
+}
+
+// Digest of window w's current graph and of the alignment that was walked last, in the record format of
+// oracle/ref_harness.cpp:vcref_window_stages (nodes, edges, hash(nodes: byte, aligned ids), hash(edges: tail, head, weight),
+// pairs, hash(pairs: node id or -1, sequence position or -1)); out[0..1] are left to the caller.  Single-chunk batches only.
+int vc_debug_stage_digest(vc_ctx* c, uint32_t w, int with_pairs, uint64_t* out) {
+    if (!c || !out || !c->have_batch || w >= c->b.n_windows) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->b.n_windows > c->cw_run) return fail(c, VC_ERR_ARG, "vc_debug_stage_digest: the batch spans several chunks");
+    sync_ctx(c);
+    const Work& wk = c->works[0];
+    const VcGraph& g = wk.gr[wk.cur];
+    const uint32_t slot = w, NC = c->NC, EC = c->EC, MA = c->MA;
+    uint32_t N = 0, E = 0, P = 0;
+    HIPCHK(c, hipMemcpy(&N, g.n_nodes + slot, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&E, g.n_edges + slot, 4, hipMemcpyDeviceToHost));
+    if (N > NC || E > EC) return fail(c, VC_ERR_STATE, "vc_debug_stage_digest: graph sizes out of range");
+    std::vector<uint8_t> code(NC), alc(NC);
+    std::vector<uint16_t> al((size_t)NC * MA), r2n(NC);
+    std::vector<uint32_t> etn(EC), ehn(EC), ew(EC);
+    HIPCHK(c, hipMemcpy(code.data(), g.code + (size_t)slot * NC, NC, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(alc.data(), g.al_cnt + (size_t)slot * NC, NC, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(al.data(), g.al + (size_t)slot * NC * MA, (size_t)NC * MA * 2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(etn.data(), g.e_tn + (size_t)slot * EC, (size_t)EC * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ehn.data(), g.e_hn + (size_t)slot * EC, (size_t)EC * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ew.data(), g.e_w + (size_t)slot * EC, (size_t)EC * 4, hipMemcpyDeviceToHost));
+    struct Fnv {
+        uint64_t h = 1469598103934665603ull;
+        void u8(uint8_t b) { h ^= b; h *= 1099511628211ull; }
+        void u32(uint32_t v) { for (int i = 0; i < 4; ++i) u8((uint8_t)(v >> (8 * i))); }
+        void u64(uint64_t v) { for (int i = 0; i < 8; ++i) u8((uint8_t)(v >> (8 * i))); }
+    } hn, he, hp;
+    for (uint32_t v = 0; v < N; ++v) {
+        hn.u8(code[v]); hn.u32(alc[v]);
+        for (uint32_t k = 0; k < alc[v]; ++k) hn.u32(al[(size_t)v * MA + k]);
+    }
+    for (uint32_t e = 0; e < E; ++e) { he.u32(etn[e] & 0xFFFF); he.u32(ehn[e] & 0xFFFF); he.u64(ew[e]); }
+    out[2] = N; out[3] = E; out[4] = hn.h; out[5] = he.h; out[6] = 0; out[7] = 0;
+    if (with_pairs) {
+        HIPCHK(c, hipMemcpy(&P, wk.d_npairs + slot, 4, hipMemcpyDeviceToHost));
+        if (P > c->PC) return fail(c, VC_ERR_STATE, "vc_debug_stage_digest: pair count out of range");
+        std::vector<uint32_t> pr(P);
+        if (P) HIPCHK(c, hipMemcpy(pr.data(), wk.d_pairs + (size_t)slot * c->PC, (size_t)P * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(r2n.data(), wk.dp.rank2node + (size_t)slot * NC, (size_t)NC * 2, hipMemcpyDeviceToHost));
+        for (uint32_t f = 0; f < P; ++f) {                    // stored tail first as (row << 16) | column, 0 = none
+            const uint32_t pv = pr[P - 1 - f], row = pv >> 16, col = pv & 0xFFFF;
+            hp.u32(row ? (uint32_t)r2n[row - 1] : 0xFFFFFFFFu);
+            hp.u32(col ? col - 1 : 0xFFFFFFFFu);
+        }
+        out[6] = P; out[7] = hp.h;
+    }
     return VC_OK;
 }
 

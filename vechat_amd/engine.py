@@ -73,6 +73,18 @@ class HipContext:
         out = [cons[int(off[w]):int(off[w + 1])].tobytes() for w in range(n)]
         return out, status
 
+    def stage_digest(self, kind, index, window=0):
+        """Test hook: run the submitted (single-chunk) batch up to a stage and digest one window's graph / last alignment
+        there -- [nodes, edges, hash(nodes), hash(edges), pairs, hash(pairs)] in the oracle's record format."""
+        self._chk(self.lib.vc_debug_stop_after(self.h, 0 if kind == 4 else kind, index), "vc_debug_stop_after")
+        try:
+            self.run(); self.sync()
+            out = (C.c_uint64 * 8)()
+            self._chk(self.lib.vc_debug_stage_digest(self.h, window, 1 if kind in (1, 4) else 0, out), "vc_debug_stage_digest")
+        finally:
+            self.lib.vc_debug_stop_after(self.h, 0, 0)
+        return [int(x) for x in out[2:8]]
+
     def errinfo(self):
         n = self._batch.n_windows
         out = np.zeros(n, np.uint32)
