@@ -229,6 +229,49 @@ def adapter_run(batch: Batch, params: VcParams):
     return rc
 
 
+def adapter_polish(batch: Batch, ids, target_names, target_cov, params: VcParams, cpu_only=False, batch_windows=0,
+                   max_nodes=0, max_edges=0, drop_unpolished=True, fragment=True):
+    """oracle/ref_adapter.cpp:vcadapter_polish -- the loop of CUDAPolisher::polish over real racon::Window objects of several
+    targets (batch fill, generateConsensus, CPU path for windows the device did not take, stitching with tags).
+    -> (FASTA text, number of windows that took the CPU path)."""
+    lib = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libvcadapter.so"))
+    lib.vcadapter_polish.restype = C.c_long
+    nw = batch.n_windows
+    bbs, bqs, bls, off, seqs, lens, quals, begins, ends = [], [], [], [0], [], [], [], [], []
+    for w in range(nw):
+        s, q, b, e = batch.window(w)
+        s0 = int(batch.win_seq_off[w])
+        n = len(s)
+        orig = [int(x) for x in batch.seq_orig[s0:s0 + n]] if batch.seq_orig is not None else list(range(n))
+        inv = [0] * n
+        for k, o in enumerate(orig):
+            inv[o] = k
+        L = len(s[0])
+        bq = q[0]
+        if not batch.win_fasta[w] and bq == b"!" * L:
+            bq = bq + b"!" * 8
+        bbs.append(s[0]); bqs.append(bq); bls.append(L)
+        for i in range(1, n):
+            k = inv[i]
+            seqs.append(s[k]); lens.append(len(s[k])); quals.append(q[k]); begins.append(b[k]); ends.append(e[k])
+        off.append(len(seqs))
+    nl, nt = max(len(seqs), 1), len(target_names)
+    CP, U = C.c_char_p, C.c_uint32
+    cap = int(batch.bases.size) + 4096 * nw + 65536
+    out = C.create_string_buffer(cap)
+    err = C.create_string_buffer(512)
+    ncpu = U(0)
+    rc = lib.vcadapter_polish(U(nw), (U * nw)(*[i for i, _ in ids]), (U * nw)(*[r for _, r in ids]), (CP * nw)(*bbs), (U * nw)(*bls),
+                              (CP * nw)(*bqs), (U * (nw + 1))(*off), (CP * nl)(*seqs), (U * nl)(*lens), (CP * nl)(*quals),
+                              (U * nl)(*begins), (U * nl)(*ends), U(nt), (CP * nt)(*[t.encode() for t in target_names]),
+                              (U * nt)(*target_cov), C.c_int(1 if params.mode == 0 else 0), C.c_int(params.trim), C.c_int(int(fragment)),
+                              C.c_int(int(drop_unpolished)), U(batch_windows), C.c_int(int(cpu_only)), U(max_nodes), U(max_edges),
+                              out, C.c_uint64(cap), C.byref(ncpu), err, U(512))
+    if rc < 0:
+        raise RuntimeError(f"vcadapter_polish: {rc} {err.value.decode()}")
+    return out.raw[:rc].decode(), int(ncpu.value)
+
+
 def have_seqparse():
     return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libvcseq.so"))
 

@@ -137,6 +137,30 @@ def test_reference_windows_through_the_compiled_adapter(built, mode):
     assert oa.adapter_run(batch, p) == 0
 
 
+@pytest.mark.parametrize("mode,key", [(0, "hap"), (1, "linear")])
+def test_polish_loop_compiled_against_the_reference(built, mode, key):
+    """HipPolisher::polish() as INTEGRATION.md describes it, compiled against the reference's own window.hpp
+    (oracle/ref_adapter.cpp: the loop of CUDAPolisher::polish, src/cuda/cudapolisher.cpp:217-414): windows of two targets in
+    batches of three through the device, stitched with LN/RC/XC tags -- the same text as the loop run on the reference's CPU
+    path, and as the fixture's expected sequences; with graph capacities too small for some windows those come back as
+    overflowed, take the reference's CPU path like CUDAPolisher's failed windows (:355-379), and the text does not change."""
+    if not oa.have_adapter():
+        pytest.skip("oracle/_ref/libvcadapter.so not built (no reference tree at build time)")
+    fx, wb = fixtures.load_plumbing()
+    batch, ids = wb.build()
+    wb.close()
+    names = [s[0] for s in fx["sequences"][:fx["n_targets"]]]
+    cov = [int(n.split("RC:i:")[1].split()[0]) for n, _ in fx["expected"][key]["stitched"]]     # targets_coverages_: kept overlaps per target
+    p = capi.default_params(mode=mode)
+    want = "".join(f">{n}\n{d}\n" for n, d in fx["expected"][key]["stitched"])
+    cpu, ncpu = oa.adapter_polish(batch, ids, names, cov, p, cpu_only=True)
+    assert ncpu == batch.n_windows and cpu == want
+    gpu, ncpu = oa.adapter_polish(batch, ids, names, cov, p, batch_windows=3)
+    assert ncpu == 0 and gpu == want
+    small, ncpu = oa.adapter_polish(batch, ids, names, cov, p, batch_windows=4, max_nodes=1280, max_edges=2560)     # three of the seven graphs need more nodes
+    assert ncpu == 3 and small == want
+
+
 def test_thread_per_alignment_backtrack_agrees(built, monkeypatch):
     """The simple one-thread-per-alignment backtrack (kept as a cross-check of the cooperative k_tracew)."""
     monkeypatch.setenv("VC_TRACE_THREAD", "1")
