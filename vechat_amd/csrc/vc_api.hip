@@ -695,7 +695,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     b.lut_w = c->d_lut_w; b.lut_d = c->d_lut_d;
     c->h_win_seq_off.assign(hb->win_seq_off, hb->win_seq_off + nw + 1);
     c->h_layer_partial = layer_partial;
-    c->h_layer_partial.resize(max_nseq + 2, 0);
+    c->h_layer_partial.resize(std::max<size_t>(layer_partial.size(), max_nseq) + 2, 0);      // indexed by layer up to the deepest window of the batch
     c->max_layers = max_layers; c->max_len = max_len;
     c->h_pre_status = any_pre ? pre : std::vector<uint8_t>();
     if (max_len == 0) { max_len = 1; min_len = 1; }              // every window was outside the envelope

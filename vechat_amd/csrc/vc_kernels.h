@@ -70,6 +70,9 @@ __host__ __device__ inline uint32_t vc_cpl_for(uint32_t len) {
     return 0;
 }
 
+// floor(x / d) == umulhi(x, vc_magic(d)) for x < 65536 and 2 <= d <= 64
+__host__ __device__ inline uint32_t vc_magic(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
+
 __device__ __forceinline__ bool vc_full_span(uint32_t begin, uint32_t end, uint32_t L) {
     uint32_t offset = (uint32_t)(0.01 * (double)L);          // window.cpp:212
     return begin < offset && end > L - offset;              // window.cpp:253-254
@@ -510,7 +513,9 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
 // "first sink in rank order" among equal end scores (sisd :353-355) -- is settled by k_resolve,
 // which runs the exact DFS only for the ~1-2 % of alignments that actually tie.
 // ------------------------------------------------------------------------------------------------
+#ifndef VC_ROWS_U
 #define VC_ROWS_U 4
+#endif
 __global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                              uint32_t NC, uint32_t EC, int next_layer, uint32_t ring) {
     VC_LATENCY_KERNEL_PRIO();
@@ -1876,7 +1881,8 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     const bool packed = vc_row_packed(m, n, g, (int)cpl);
     const uint32_t nrows = valid ? min(a.dp.nrows[slot], a.tab_rows) : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
-    // horizontal T == T', SW stop T == -col*g
+    // horizontal T == T', SW stop T == -col*g.  (The runtime division by cpl stays: a multiply-high in its place made the
+    // kernel 10 % SLOWER -- 352 -> 390 ms per 32 768 windows -- the compiler then schedules the loads of a round differently.)
     auto Tat = [&](uint32_t r, uint32_t col) __attribute__((always_inline)) -> int {
         if (r == 0) return nw ? 0 : -(int)col * g;
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
@@ -2100,8 +2106,6 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
 // the instructions per move, no LDS, no table-building prologue.
 // ------------------------------------------------------------------------------------------------
 #define VC_TX_SPECW 8
-// floor(x / d) == umulhi(x, vc_magic(d)) for x < 65536 and 2 <= d <= 64
-__host__ __device__ inline uint32_t vc_magic(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
 
 // One stored cell, branch-free: the loads are issued for every lane (idle lanes read dword 0 of a matrix), the special
 // rows / columns are patched in afterwards, so that all loads of a round are in flight together.
