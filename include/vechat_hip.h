@@ -57,7 +57,7 @@ typedef struct vc_params {
     uint32_t chunk_windows;                 /* windows resident per pass; 0 = derive from memory   */
     uint64_t scratch_bytes;                 /* device scratch budget; 0 = 1/4 of free memory       */
     int32_t  profile;                       /* 1 = bracket every kernel launch with HIP events, 2 = only the forward kernel's */
-    uint32_t n_streams;                     /* chunks in flight on separate HIP streams; 0 = 2     */
+    uint32_t n_streams;                     /* chunks in flight on separate HIP streams; 0 = 4     */
 } vc_params;
 
 /* A batch of windows, the unit the reference's accelerated path fills with
@@ -99,6 +99,8 @@ typedef struct vc_stats {
     uint64_t launches[16];
     char     names[16][24];
     uint32_t max_nodes, max_edges, chunk_windows, n_streams;   /* what the context actually used */
+    double   busy_ms[16];    /* per class: time during which at least one launch of it was running (the chunk streams overlap,  */
+                             /* so a class's launches overlap each other and `ms` counts such time once per launch)             */
 } vc_stats;
 
 /* -- lifecycle: stands in for createCUDABatch / ~CUDABatchProcessor (cudabatch.hpp:26,33) ------ */

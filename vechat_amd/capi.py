@@ -62,6 +62,7 @@ class VcStats(C.Structure):
         ("launches", C.c_uint64 * 16),
         ("names", (C.c_char * 24) * 16),
         ("max_nodes", C.c_uint32), ("max_edges", C.c_uint32), ("chunk_windows", C.c_uint32), ("n_streams", C.c_uint32),
+        ("busy_ms", C.c_double * 16),
     ]
 
 

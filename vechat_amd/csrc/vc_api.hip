@@ -37,7 +37,7 @@ const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace"
 #define VC_RING 8
 #endif
 constexpr int kRing = VC_RING;      // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
-constexpr int kMaxStreams = 4;
+constexpr int kMaxStreams = 8;
 constexpr uint32_t kTraceTabRows = 8188;           // rows covered by k_tracew's first-in-edge table (4 tables x 2 B x 8192 = 64 KB); later rows are walked without speculation
 constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may ask for (160 KB per CU minus room for static __shared__)
 constexpr uint32_t kMaxColumns = 2048;     // longest sequence the packed-int16 k_fwd takes (64 lanes x 32 columns); longer ones go to k_fwd_wide
@@ -277,9 +277,24 @@ struct Timer {
 };
 
 void flush_events(vc_ctx* c) {
+    // per class: the sum of the launch durations, and the length of the union of the launch intervals (launches of one class
+    // on different chunk streams overlap each other)
+    std::vector<std::pair<float, float>> iv[KC_N];
     for (auto& r : c->ev_recs) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->stats.ms[r.cls] += ms;
+        float ms = 0, t0 = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        c->stats.ms[r.cls] += ms;
+        if (hipEventElapsedTime(&t0, c->ev_recs.front().a, r.a) == hipSuccess) iv[r.cls].emplace_back(t0, t0 + ms);
+    }
+    for (int k = 0; k < KC_N; ++k) {
+        std::sort(iv[k].begin(), iv[k].end());
+        float end = -1e30f;
+        double busy = 0;
+        for (auto& x : iv[k]) {
+            if (x.first > end) { busy += x.second - x.first; end = x.second; }
+            else if (x.second > end) { busy += x.second - end; end = x.second; }
+        }
+        c->stats.busy_ms[k] += busy;
     }
     c->ev_recs.clear();
     c->ev_next = 0;
@@ -557,7 +572,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     vc_ctx* c = new vc_ctx();
     c->prm = *p;
     c->device = p->device;
-    c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 2;
+    c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 4;      // measured: 2 -> 22.6 k, 3 -> 23.0 k, 4 -> 23.4 k windows/s on config C
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
     if (const char* ti = getenv("VC_TRACE_IMPL")) c->trace_impl = std::atoi(ti) >= 1 && std::atoi(ti) <= 3 ? std::atoi(ti) : 1;
@@ -835,7 +850,7 @@ int vc_run(vc_ctx* c) {
     HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, (size_t)b.n_windows * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < KC_N; ++i) { c->stats.ms[i] = 0; c->stats.launches[i] = 0; }
+    for (int i = 0; i < KC_N; ++i) { c->stats.ms[i] = 0; c->stats.busy_ms[i] = 0; c->stats.launches[i] = 0; }
 
     const uint32_t S = c->n_streams, CW = c->cw_run;
     for (uint32_t g0 = 0; g0 < b.n_windows; g0 += S * CW) {

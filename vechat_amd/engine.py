@@ -98,7 +98,7 @@ class HipContext:
                  max_nodes=int(s.max_nodes), max_edges=int(s.max_edges), chunk_windows=int(s.chunk_windows), n_streams=int(s.n_streams),
                  kernels={})
         for i in range(s.n_classes):
-            d["kernels"][s.names[i].value.decode()] = dict(ms=float(s.ms[i]), launches=int(s.launches[i]))
+            d["kernels"][s.names[i].value.decode()] = dict(ms=float(s.ms[i]), launches=int(s.launches[i]), busy_ms=float(s.busy_ms[i]))
         return d
 
     def consensus(self, batch: capi.Batch, retry_overflow=True):
