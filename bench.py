@@ -58,10 +58,15 @@ def usable_cores():
 
 
 def kernel_hash():
-    """Identity of the kernels this bench runs: measured-traffic files are only valid for the sources they were taken on."""
+    """Identity of the kernels this bench runs: measured-traffic files are only valid for the sources they were taken on.
+    Comments and whitespace do not count (a reworded comment does not invalidate a measurement)."""
+    import re
     h = hashlib.sha256()
     for f in ("vc_kernels.h", "vc_api.hip", "vc_device.h"):
-        h.update(open(os.path.join(ROOT, "vechat_amd", "csrc", f), "rb").read())
+        src = open(os.path.join(ROOT, "vechat_amd", "csrc", f), "r").read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", " ", src)
+        h.update(" ".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 

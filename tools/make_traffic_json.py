@@ -10,12 +10,7 @@ sys.path.insert(0, ROOT)
 pmc_dir, stats_json, valu_out, out_dir = sys.argv[1:5]
 
 
-def kernel_hash():
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("vc_kernels.h", "vc_api.hip", "vc_device.h"):
-        h.update(open(os.path.join(ROOT, "vechat_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+from bench import kernel_hash  # noqa: E402  (the same identity bench.py checks)
 
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -106,7 +106,7 @@ struct vc_ctx {
     std::vector<uint8_t> h_pre_status;   // per-window status decided at submit (outside the envelope), empty = none
     bool trace_wave = true;
     int trace_impl = 1;           // 1: k_tracew (16 lanes, two round trips per round, LDS table); 2 / 3: k_tracex with 8 / 16 lanes per alignment
-                                  // (one round trip, no LDS, a third of the instructions -- measured equal alone and 2 % behind beside k_fwd)
+                                  // (one round trip, no LDS, fewer instructions -- measured no faster)
     uint32_t dbg_stop_kind = 0, dbg_stop_index = 0;   // vc_debug_stop_after: leave the chunk's graphs as they are after that stage
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
     Work works[kMaxStreams];

@@ -2102,8 +2102,9 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
 //   * all loads of a round are issued together; afterwards the longest prefix of confirmed speculations is accepted (each
 //     is exactly the reference's first test at that cell), and if the first unconfirmed position lies on a row with one
 //     in-edge its vertical / horizontal move is taken in the same round; otherwise the general move decided above.
-// Compared with k_tracew (two round trips per round, a per-alignment table in LDS, eight serial table lookups): a third of
-// the instructions per move, no LDS, no table-building prologue.
+// Compared with k_tracew (two round trips per round, a per-alignment table in LDS, eight serial table lookups): 45 % fewer
+// wave instructions at TL = 8 (PMC), no LDS, no table-building prologue -- and measured no faster (the
+// backtrack is bound by its scattered 128-byte reads), which is why k_tracew remains the default.
 // ------------------------------------------------------------------------------------------------
 #define VC_TX_SPECW 8
 
