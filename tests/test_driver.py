@@ -105,6 +105,51 @@ def test_split_chunks_targets_and_narrows_queries(tmp_path, monkeypatch, fastq):
     assert not [f for f in os.listdir(work) if f.startswith("reads_chunk") or f.startswith("reads.corrected.tmp")]
 
 
+def test_scrub_and_default_overlapper_command_lines(tmp_path, monkeypatch):
+    """--scrub (scripts/vechat:189-205) and the default minimap2 | awk | fpa pipelines (:36-49), followed through stand-ins for
+    the external binaries put first on PATH: each records its arguments, minimap2 prints the stub overlapper's PAF, fpa passes
+    its input through, yacrd copies the reads to the scrubbed file."""
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    log = tmp_path / "tools.log"
+    stub = os.path.join(STUBS, "stub_overlapper.py")
+    (bindir / "minimap2").write_text(f"""#!/bin/bash
+echo "minimap2 $@" >> {log}
+args=("$@"); n=${{#args[@]}}
+t=""; q=""
+for a in "${{args[@]}}"; do if [ -f "$a" ]; then if [ -z "$t" ]; then t="$a"; else q="$a"; fi; fi; done
+{sys.executable} {stub} "$t" "$q" /dev/stdout 300
+""")
+    (bindir / "fpa").write_text(f"#!/bin/bash\necho \"fpa $@\" >> {log}\ncat\n")
+    (bindir / "yacrd").write_text(f"""#!/bin/bash
+echo "yacrd $@" >> {log}
+args=("$@"); for ((i=0;i<${{#args[@]}};i++)); do if [ "${{args[$i]}}" = "scrubb" ]; then in="${{args[$((i+2))]}}"; out="${{args[$((i+4))]}}"; fi; done
+cp "$in" "$out"
+""")
+    for f in ("minimap2", "fpa", "yacrd"):
+        os.chmod(bindir / f, 0o755)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    monkeypatch.setenv("VC_STUB_LOG", str(tmp_path / "polisher.log"))
+    reads = tmp_path / "reads.fastq"
+    recs, _ = simulate(str(reads), n_reads=6)
+    out = tmp_path / "out.fa"
+    work = tmp_path / "work"
+    assert driver.main([str(reads), "-o", str(out), "--workdir", str(work), "--polisher", POL, "--scrub", "--platform", "ont", "-t", "2"]) == 0
+    lines = open(log).read().strip().split("\n")
+    scrubbed = str(work / "reads.scrubbed.fq")
+    tmp1 = str(work / "reads.corrected.tmp1.fa")
+    assert lines[0] == f"minimap2 -x ava-ont -g 500 -t 2 {reads} {reads}"                          # scripts/vechat:198
+    assert lines[1] == f"yacrd -i {work / 'scrub.paf'} -o {work / 'report.yacrd'} -c 4 -n 0.4 scrubb -i {reads} -o {scrubbed}"   # :199
+    rest = sorted(lines[2:])                                 # the members of a pipeline start together: their log order is not fixed
+    assert rest == sorted([f"minimap2 -x ava-ont --dual=yes {scrubbed} {scrubbed} -t 2",           # round 1, :36
+                           "fpa drop --same-name --internalmatch -",
+                           f"minimap2 -cx ava-ont --dual=yes {tmp1} {tmp1} -t 2",                  # round 2: base-level, :47
+                           "fpa drop --same-name --internalmatch -"])
+    calls = [json.loads(l) for l in open(tmp_path / "polisher.log")]
+    assert calls[0][-1] == scrubbed and calls[0][-3] == scrubbed                                   # the scrubbed reads are queries and targets
+    assert [l[1:] for l in open(out).read().split("\n")[0::2] if l] == [n for n, _ in recs]
+
+
 def test_helpers(tmp_path):
     p = tmp_path / "x.fa"
     p.write_text(">a\nAC\n>b\nGT\n>c\nAA\n")
