@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/driver_cmds.json from the REFERENCE driver itself (build container only).
+
+The reference's wrapper `scripts/vechat` is Python; it is executed here, in place, under `runpy` with its `__main__`
+block live, one scenario (argument vector) at a time.  `os.system` / `os.popen` / `subprocess.check_call` are replaced:
+  * every shell command the script issues is RECORDED;
+  * coreutils commands (split, ls, cat, mv, rm) run for real in a scratch directory, so the script's own file hand-off
+    (reads_chunk*, reads.corrected.tmp<i>.fa, query_sequences.tmp.*) is exercised;
+  * the external tools are stood in for: `minimap2 ... > out` writes an all-vs-all PAF of the two files it was given,
+    `yacrd` copies the reads to the scrubbed file, `vechat_racon` writes its targets back as FASTA with one 'r'
+    appended to each name (the fragment-correction tag of src/polisher.cpp:525) -- the same stand-ins
+    tests/test_driver.py gives vechat_amd.driver, so both sides see the same inputs;
+  * the cmake bootstrap of scripts/vechat:211-225 is a no-op.
+What is written: per scenario the argument vector, the input records, the recorded commands with the scratch directory
+and the polisher path replaced by placeholders, the final output file and what is left in the directory.  Only this
+JSON travels; the reference's source text never leaves /root/reference.
+
+  python tests/golden/make_driver.py        # rewrites tests/golden/driver_cmds.json
+"""
+import json
+import os
+import re
+import runpy
+import shutil
+import subprocess
+import sys
+import tempfile
+
+REF = "/root/reference/scripts/vechat"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+READS = [("r%d" % k, "ACGTTGCA" * (3 + k % 3) + "AC" * k) for k in range(6)]
+
+
+def write_reads(path, fastq):
+    with open(path, "w") as f:
+        for n, s in READS:
+            f.write(("@%s\n%s\n+\n%s\n" % (n, s, "5" * len(s))) if fastq else (">%s\n%s\n" % (n, s)))
+
+
+def records(path):
+    lines = [l.rstrip("\n") for l in open(path)]
+    per = 4 if lines and lines[0].startswith("@") else 2
+    return [(lines[i][1:].split()[0], lines[i + 1]) for i in range(0, len(lines) - 1, per)]
+
+
+def run_scenario(name, argv, fastq):
+    work = tempfile.mkdtemp(prefix="vcdrv_")
+    reads = os.path.join(work, "reads.fastq" if fastq else "reads.fasta")
+    write_reads(reads, fastq)
+    log = []
+    real_system, real_popen, real_check = os.system, os.popen, subprocess.check_call
+    racon = os.path.dirname(os.path.realpath(REF)) + "/../build/bin/vechat_racon"
+
+    def norm(cmd):
+        return cmd.replace(racon, "{RACON}").replace(work + "/", "{CWD}/").replace(work, "{CWD}")
+
+    def fake_system(cmd):
+        log.append(norm(cmd))
+        head = cmd.strip().split()[0]
+        if head == "minimap2":
+            out = cmd.rsplit(">", 1)[1].strip()
+            files = [t for t in cmd.split("|")[0].split() if os.path.isfile(t)]
+            tgt, qry = files[0], files[1]
+            with open(out, "w") as fw:
+                for qn, qs in records(qry):
+                    for tn, ts in records(tgt):
+                        if qn != tn:
+                            fw.write("\t".join(map(str, [qn, len(qs), 0, len(qs), "+", tn, len(ts), 0, len(ts), 5000, 5000, 60])) + "\n")
+            return 0
+        if head == "yacrd":
+            toks = cmd.split()
+            k = toks.index("scrubb")
+            shutil.copy(toks[k + 2], toks[k + 4])
+            return 0
+        if head == racon:
+            body, out = cmd.rsplit(">", 1)
+            targets = body.split()[-1]
+            with open(out.strip(), "w") as fw:
+                for n, s in records(targets):
+                    fw.write(">%sr\n%s\n" % (n, s))
+            return 0
+        return real_system(cmd)
+
+    cwd = os.getcwd()
+    old_argv = sys.argv
+    try:
+        os.chdir(work)
+        os.system = fake_system
+        subprocess.check_call = lambda *a, **k: 0
+        sys.argv = [REF, reads] + argv
+        try:
+            runpy.run_path(REF, run_name="__main__")
+        except SystemExit as e:
+            if e.code not in (0, None):
+                raise
+    finally:
+        os.system, os.popen, subprocess.check_call = real_system, real_popen, real_check
+        sys.argv = old_argv
+        os.chdir(cwd)
+    outname = argv[argv.index("-o") + 1] if "-o" in argv else "reads.corrected.fa"
+    final = open(os.path.join(work, outname)).read()
+    left = sorted(f for f in os.listdir(work))
+    shutil.rmtree(work)
+    return {"argv": argv, "fastq": fastq, "reads": READS, "commands": log, "output": final, "left_behind": left}
+
+
+SCENARIOS = [
+    ("default", [], True),
+    ("default_fasta", [], False),
+    ("threads_and_thresholds", ["-t", "4", "-d", "0.25", "-s", "0.15", "--platform", "ont"], True),
+    ("base", ["--base", "--min-identity", "0.85"], True),
+    ("linear", ["--linear"], True),
+    ("linear_unpolished", ["--linear", "-u"], True),
+    ("unpolished", ["-u"], True),
+    ("consensus_filters", ["--min-ovlplen-cns", "800", "--min-identity-cns", "0.98"], True),
+    ("split_fastq", ["--split", "--split-size", "8"], True),
+    ("split_fasta", ["--split", "--split-size", "4"], False),
+    ("scrub_pb", ["--scrub"], True),
+    ("scrub_ont", ["--scrub", "--platform", "ont", "-t", "2"], True),
+    ("accelerator_switches", ["-b", "--cudaaligner-batches", "2", "-c", "3"], True),
+    ("accelerator_switches_linear_unpolished", ["--linear", "-u", "-b", "-c", "1"], True),
+    ("poa_batches_without_banding", ["-c", "4"], True),
+    ("ignored_options", ["-w", "800", "-q", "12", "-e", "0.25", "-m", "3", "-x", "-5", "-g", "-4"], True),
+    ("outfile", ["-o", "my.fa"], True),
+]
+
+
+def main():
+    if not os.path.exists(REF):
+        raise SystemExit("needs /root/reference (build container only)")
+    out = {"generator": "tests/golden/make_driver.py", "reference": "scripts/vechat", "scenarios": {}}
+    for name, argv, fastq in SCENARIOS:
+        out["scenarios"][name] = run_scenario(name, argv, fastq)
+        print(name, len(out["scenarios"][name]["commands"]), "commands")
+    with open(os.path.join(HERE, "driver_cmds.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -13,5 +13,6 @@ op = gzip.open if targets.endswith(".gz") else open
 with op(targets, "rt") as f:
     lines = [l.rstrip("\n") for l in f]
 per = 4 if lines and lines[0].startswith("@") else 2
+tag = os.environ.get("VC_STUB_TAG", "")          # "r": the tag fragment correction appends to a name (src/polisher.cpp:525)
 for i in range(0, len(lines) - 1, per):
-    sys.stdout.write(">" + lines[i][1:].split()[0] + "\n" + lines[i + 1].upper() + "\n")
+    sys.stdout.write(">" + lines[i][1:].split()[0] + tag + "\n" + lines[i + 1].upper() + "\n")

@@ -90,7 +90,7 @@ def test_paf_without_cigar_end_to_end(built, tmp_path, capsys, monkeypatch, dist
     rp, op, tp = write_inputs(fx, tmp_path, sam=False)
     txt = "\n".join(ln.split("\tcg:Z:")[0] for ln in open(op).read().strip().split("\n")) + "\n"
     open(op, "w").write(txt)
-    assert polish.main([str(rp), str(op), str(tp), "-p"]) == 0
+    assert polish.main([str(rp), str(op), str(tp), "-p", "-d", "0.2", "-s", "0.2"]) == 0
     out = capsys.readouterr().out.strip().split("\n")
     got = {out[i][1:].split()[0]: out[i + 1] for i in range(0, len(out), 2)}
     exp = {n.split()[0]: d for n, d in fx["expected"]["hap"]["stitched"]}

@@ -70,84 +70,101 @@ def run_driver(tmp_path, monkeypatch, extra, fastq=True, n_reads=6):
     return recs, calls, out, tmp_path / "work", reads
 
 
-def test_two_rounds_command_lines_and_hand_off(tmp_path, monkeypatch):
-    recs, calls, out, work, reads = run_driver(tmp_path, monkeypatch, ["-t", "3"])
-    tmp1 = str(work / "reads.corrected.tmp1.fa")
-    paf = str(work / "overlap.paf")
-    # round 1: vechat_racon -f -p -d 0.2 -s 0.2 -t T reads overlap.paf reads (scripts/vechat:70-72); round 2: -f -t T on round 1's output (:91-93)
-    assert calls == [["-f", "-p", "-d", "0.2", "-s", "0.2", "-t", "3", str(reads), paf, str(reads)],
-                     ["-f", "-t", "3", tmp1, paf, tmp1]]
-    got = open(out).read().split("\n")
-    assert [l[1:] for l in got[0::2] if l] == [n for n, _ in recs]
-    left = sorted(os.listdir(work))
-    assert not [f for f in left if f.startswith("reads.corrected.tmp") or f.startswith("reads_chunk") or f.startswith("query_sequences")], left
-    assert os.path.getsize(paf) > 0                         # the stub overlapper found the simulated overlaps
+# ---- N4 pinned against the reference: tests/golden/driver_cmds.json was recorded from scripts/vechat ITSELF (make_driver.py runs it
+# in place with its shell-outs captured); every scenario below replays the same argument vector through vechat_amd.driver.
+FIX = json.load(open(os.path.join(HERE, "golden", "driver_cmds.json")))
+TOOL_HEADS = ("minimap2", "yacrd", "{RACON}")
 
 
-def test_linear_is_one_round(tmp_path, monkeypatch):
-    _, calls, _, _, reads = run_driver(tmp_path, monkeypatch, ["--linear", "-u"])
-    assert len(calls) == 1 and calls[0][:4] == ["-f", "-u", "-t", "1"] and calls[0][-1] == str(reads)
+def _norm(cmd):
+    """One command line, comparable across the two drivers: directories dropped from file arguments, whitespace collapsed."""
+    out = []
+    for tok in cmd.split():
+        lead = ">" if tok.startswith(">") and len(tok) > 1 else ""
+        body = tok[len(lead):].strip("'\"")
+        if "|" not in tok and (body.startswith("/") or body.startswith("{CWD}/")) and not body.startswith("/dev/"):
+            tok = lead + os.path.basename(body)
+        out.append(tok)
+    return " ".join(out).replace("| ", "|").replace(" |", "|")       # `a| b` and `a|b` are the same pipeline
 
 
-@pytest.mark.parametrize("fastq", [True, False])
-def test_split_chunks_targets_and_narrows_queries(tmp_path, monkeypatch, fastq):
-    per = 4 if fastq else 2
-    recs, calls, out, work, reads = run_driver(tmp_path, monkeypatch, ["--split", "--split-size", str(2 * per)], fastq=fastq, n_reads=6)
-    # round 1: 6 records, 2 per chunk; round 2 splits the FASTA of round 1 with split_size/2 lines for FASTQ input (scripts/vechat:318-319)
-    assert len(calls) == 6
-    r1, r2 = calls[:3], calls[3:]
-    assert all(c[:2] == ["-f", "-p"] for c in r1) and all(c[0] == "-f" and "-p" not in c for c in r2)
-    assert [os.path.basename(c[-1]) for c in r1] == [f"reads_chunk{k:02d}.{'fq' if fastq else 'fa'}" for k in range(3)]
-    assert [os.path.basename(c[-1]) for c in r2] == [f"reads_chunk{k:02d}.fa" for k in range(3)]
-    assert all(os.path.basename(c[-3]).startswith("query_sequences.tmp.") for c in calls)      # scripts/vechat:54-57
-    names = [l[1:] for l in open(out).read().split("\n")[0::2] if l]
-    assert names == [n for n, _ in recs]                     # chunk outputs concatenated in order
-    assert not [f for f in os.listdir(work) if f.startswith("reads_chunk") or f.startswith("reads.corrected.tmp")]
-
-
-def test_scrub_and_default_overlapper_command_lines(tmp_path, monkeypatch):
-    """--scrub (scripts/vechat:189-205) and the default minimap2 | awk | fpa pipelines (:36-49), followed through stand-ins for
-    the external binaries put first on PATH: each records its arguments, minimap2 prints the stub overlapper's PAF, fpa passes
-    its input through, yacrd copies the reads to the scrubbed file."""
+@pytest.fixture
+def tool_stand_ins(tmp_path, monkeypatch):
+    """minimap2 / fpa / yacrd stand-ins first on PATH -- the same ones make_driver.py gave the reference script: minimap2 prints an
+    all-vs-all PAF of the two files it is given (wide enough to pass the awk filters), fpa passes its input through, yacrd copies
+    the reads to the scrubbed file."""
     bindir = tmp_path / "bin"
     bindir.mkdir()
-    log = tmp_path / "tools.log"
-    stub = os.path.join(STUBS, "stub_overlapper.py")
-    (bindir / "minimap2").write_text(f"""#!/bin/bash
-echo "minimap2 $@" >> {log}
-args=("$@"); n=${{#args[@]}}
-t=""; q=""
-for a in "${{args[@]}}"; do if [ -f "$a" ]; then if [ -z "$t" ]; then t="$a"; else q="$a"; fi; fi; done
-{sys.executable} {stub} "$t" "$q" /dev/stdout 300
+    (bindir / "minimap2").write_text(f"""#!{sys.executable}
+import gzip, os, sys
+files = [a for a in sys.argv[1:] if os.path.isfile(a)]
+def records(path):
+    lines = [l.rstrip("\\n") for l in (gzip.open(path, "rt") if path.endswith(".gz") else open(path))]
+    per = 4 if lines and lines[0].startswith("@") else 2
+    return [(lines[i][1:].split()[0], lines[i + 1]) for i in range(0, len(lines) - 1, per)]
+for qn, qs in records(files[1]):
+    for tn, ts in records(files[0]):
+        if qn != tn:
+            print("\\t".join(map(str, [qn, len(qs), 0, len(qs), "+", tn, len(ts), 0, len(ts), 5000, 5000, 60])))
 """)
-    (bindir / "fpa").write_text(f"#!/bin/bash\necho \"fpa $@\" >> {log}\ncat\n")
-    (bindir / "yacrd").write_text(f"""#!/bin/bash
-echo "yacrd $@" >> {log}
-args=("$@"); for ((i=0;i<${{#args[@]}};i++)); do if [ "${{args[$i]}}" = "scrubb" ]; then in="${{args[$((i+2))]}}"; out="${{args[$((i+4))]}}"; fi; done
+    (bindir / "fpa").write_text("#!/bin/bash\ncat\n")
+    (bindir / "yacrd").write_text("""#!/bin/bash
+args=("$@"); for ((i=0;i<${#args[@]};i++)); do if [ "${args[$i]}" = "scrubb" ]; then in="${args[$((i+2))]}"; out="${args[$((i+4))]}"; fi; done
 cp "$in" "$out"
 """)
     for f in ("minimap2", "fpa", "yacrd"):
         os.chmod(bindir / f, 0o755)
     monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
     monkeypatch.setenv("VC_STUB_LOG", str(tmp_path / "polisher.log"))
-    reads = tmp_path / "reads.fastq"
-    recs, _ = simulate(str(reads), n_reads=6)
-    out = tmp_path / "out.fa"
+    monkeypatch.setenv("VC_STUB_TAG", "r")
+    return bindir
+
+
+@pytest.mark.parametrize("name", sorted(FIX["scenarios"]))
+def test_command_lines_and_hand_off_match_the_reference_script(name, tmp_path, monkeypatch, tool_stand_ins):
+    sc = FIX["scenarios"][name]
+    reads = tmp_path / ("reads.fastq" if sc["fastq"] else "reads.fasta")
+    with open(reads, "w") as f:
+        for n, s in sc["reads"]:
+            f.write(f"@{n}\n{s}\n+\n{'5' * len(s)}\n" if sc["fastq"] else f">{n}\n{s}\n")
     work = tmp_path / "work"
-    assert driver.main([str(reads), "-o", str(out), "--workdir", str(work), "--polisher", POL, "--scrub", "--platform", "ont", "-t", "2"]) == 0
-    lines = open(log).read().strip().split("\n")
-    scrubbed = str(work / "reads.scrubbed.fq")
-    tmp1 = str(work / "reads.corrected.tmp1.fa")
-    assert lines[0] == f"minimap2 -x ava-ont -g 500 -t 2 {reads} {reads}"                          # scripts/vechat:198
-    assert lines[1] == f"yacrd -i {work / 'scrub.paf'} -o {work / 'report.yacrd'} -c 4 -n 0.4 scrubb -i {reads} -o {scrubbed}"   # :199
-    rest = sorted(lines[2:])                                 # the members of a pipeline start together: their log order is not fixed
-    assert rest == sorted([f"minimap2 -x ava-ont --dual=yes {scrubbed} {scrubbed} -t 2",           # round 1, :36
-                           "fpa drop --same-name --internalmatch -",
-                           f"minimap2 -cx ava-ont --dual=yes {tmp1} {tmp1} -t 2",                  # round 2: base-level, :47
-                           "fpa drop --same-name --internalmatch -"])
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(driver, "COMMAND_LOG", [])
+    assert driver.main([str(reads)] + sc["argv"] + ["--workdir", str(work), "--polisher", POL]) == 0
+    ours = [_norm(c.replace(POL, "{RACON}")) for c in driver.COMMAND_LOG]
+    theirs = [_norm(c) for c in sc["commands"] if c.split()[0] in TOOL_HEADS]
+    assert ours == theirs
+    # the polisher really received those arguments (the log of the stand-in), in the reference's order
     calls = [json.loads(l) for l in open(tmp_path / "polisher.log")]
-    assert calls[0][-1] == scrubbed and calls[0][-3] == scrubbed                                   # the scrubbed reads are queries and targets
-    assert [l[1:] for l in open(out).read().split("\n")[0::2] if l] == [n for n, _ in recs]
+    assert [" ".join(["{RACON}"] + [os.path.basename(x) if x.startswith("/") else x for x in c]) for c in calls] == \
+           [" ".join(t.split(">")[0].split()) for t in theirs if t.startswith("{RACON}")]
+    outname = sc["argv"][sc["argv"].index("-o") + 1] if "-o" in sc["argv"] else "reads.corrected.fa"
+    assert open(tmp_path / outname).read() == sc["output"]
+    # what stays behind: the reference works in the current directory, this driver in --workdir
+    left = sorted(set(os.listdir(work)) | {outname, reads.name})
+    assert left == sorted(f for f in sc["left_behind"])
+
+
+def test_failing_overlapper_stops_the_round(tmp_path, monkeypatch, tool_stand_ins):
+    """a missing / failing minimap2 must not surface rounds later as an empty overlap set (the pipelines run under pipefail)."""
+    (tool_stand_ins / "minimap2").write_text("#!/bin/bash\nexit 7\n")
+    reads = tmp_path / "reads.fastq"
+    simulate(str(reads), n_reads=4)
+    with pytest.raises(RuntimeError, match="command failed"):
+        driver.main([str(reads), "-o", str(tmp_path / "o.fa"), "--workdir", str(tmp_path / "work"), "--polisher", POL])
+
+
+def test_split_reads_gzip_input(tmp_path, monkeypatch, tool_stand_ins):
+    """--split narrows the query file from a gzipped input as well (the reference's plain open() would fail there)."""
+    import gzip
+    sc = FIX["scenarios"]["split_fastq"]
+    reads = tmp_path / "reads.fastq.gz"
+    with gzip.open(reads, "wt") as f:
+        for n, s in sc["reads"]:
+            f.write(f"@{n}\n{s}\n+\n{'5' * len(s)}\n")
+    monkeypatch.chdir(tmp_path)
+    assert driver.main([str(reads)] + sc["argv"] + ["--workdir", str(tmp_path / "work"), "--polisher", POL]) == 0
+    assert open(tmp_path / "reads.corrected.fa").read() == sc["output"]
 
 
 def test_helpers(tmp_path):

@@ -90,7 +90,7 @@ def test_plumbing_reads_to_corrected_sequences(built, mode, key):
     wb.close()
 
 
-@pytest.mark.parametrize("flags,key", [(["-p"], "hap"), ([], "linear")])
+@pytest.mark.parametrize("flags,key", [(["-p", "-d", "0.2", "-s", "0.2"], "hap"), ([], "linear")])
 def test_command_line_from_files(built, tmp_path, capsys, flags, key):
     """reads.fastq.gz + overlaps.sam + targets.fastq -> corrected FASTA through `python -m vechat_amd.polish`."""
     from test_seqio import write_inputs
@@ -114,7 +114,7 @@ def test_command_line_distributed_path(built, tmp_path, capsys, monkeypatch):
     fx, wb = fixtures.load_plumbing()
     wb.close()
     rp, op, tp = write_inputs(fx, tmp_path, sam=True)
-    assert polish.main([str(rp), str(op), str(tp), "-p"]) == 0
+    assert polish.main([str(rp), str(op), str(tp), "-p", "-d", "0.2", "-s", "0.2"]) == 0
     out = capsys.readouterr().out.strip().split("\n")
     assert [[out[i][1:], out[i + 1]] for i in range(0, len(out), 2)] == fx["expected"]["hap"]["stitched"]
 

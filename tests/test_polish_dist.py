@@ -47,7 +47,7 @@ def _run(rank, world, port, argv, q):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("flags,key", [(["-p"], "hap"), ([], "linear")])
+@pytest.mark.parametrize("flags,key", [(["-p", "-d", "0.2", "-s", "0.2"], "hap"), ([], "linear")])
 def test_two_ranks_write_what_one_rank_writes(built, tmp_path, flags, key):
     fx, wb = fixtures.load_plumbing()
     wb.close()
@@ -72,3 +72,51 @@ def test_two_ranks_write_what_one_rank_writes(built, tmp_path, flags, key):
     assert results[1] == results[2]
     lines = results[2].strip().split("\n")
     assert [[lines[i][1:], lines[i + 1]] for i in range(0, len(lines), 2)] == fx["expected"][key]["stitched"]
+
+
+def _spawn(world, argv):
+    ctx = mp.get_context("spawn")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run, args=(r, world, port, argv, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict((r, (rc, text)) for r, rc, text in (q.get(timeout=240) for _ in range(world)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.timeout(300)
+def test_unpolished_targets_of_a_rank_without_overlaps(built, tmp_path):
+    """-u with one rank's targets keeping no overlap at all (such a rank used to send nothing, so the N-rank output lost
+    targets the single-rank run prints).  The reference builds windows for every target (polisher.cpp:389-411): a target without
+    overlaps comes out unpolished under -u, from whichever rank owns it."""
+    fx, wb = fixtures.load_plumbing()
+    wb.close()
+    rp, op, tp = write_inputs(fx, tmp_path, sam=True)
+    last = fx["sequences"][fx["n_targets"] - 1][0]
+    kept = [l for l in open(op) if l.startswith("@") or l.split("\t")[2] != last]      # no overlap lands on the last target
+    open(op, "w").writelines(kept)
+    argv = [str(rp), str(op), str(tp), "-u"]
+    one, two = _spawn(1, argv), _spawn(2, argv)
+    assert one[0][0] == 0 and all(rc == 0 for rc, _ in two.values())
+    assert two[1][1] == "" and one[0][1] == two[0][1]
+    names = [l[1:].split()[0] for l in two[0][1].split("\n") if l.startswith(">")]
+    assert len(names) == fx["n_targets"] and names[-1].startswith(last)            # the overlap-less target is there, last, unpolished
+    # without -u it is dropped by one rank and by two alike
+    one, two = _spawn(1, argv[:-1]), _spawn(2, argv[:-1])
+    assert one[0][1] == two[0][1] and len([l for l in two[0][1].split("\n") if l.startswith(">")]) == fx["n_targets"] - 1
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_rank_ends_every_rank(built, tmp_path):
+    """An exception on one rank before the gather must not leave the others waiting in it: error flags are exchanged first
+    and every rank returns non-zero."""
+    fx, wb = fixtures.load_plumbing()
+    wb.close()
+    rp, op, tp = write_inputs(fx, tmp_path, sam=True)
+    argv = [str(rp), str(op), str(tp), "-p", "-w", "0"]                                 # window length 0: the builder refuses it on every rank
+    got = _spawn(2, argv)
+    assert all(rc != 0 for rc, _ in got.values()) and all(text == "" for _, text in got.values())

@@ -109,6 +109,7 @@ struct vc_ctx {
                                   // (one round trip, no LDS, fewer instructions -- measured no faster)
     uint32_t dbg_stop_kind = 0, dbg_stop_index = 0;   // vc_debug_stop_after: leave the chunk's graphs as they are after that stage
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
+    uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
 
@@ -308,6 +309,7 @@ void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs) {
 // One launch when the batch's sequences fall into one width class or two adjacent ones (the usual case:
 // read pieces of a window differ by a few percent in length); otherwise one launch per class.
 int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, const Work* wk = nullptr) {
+    if (c->dup & 16u) { const uint32_t d = c->dup; c->dup = 0; (void)launch_fwd(c, st, a0, jobs, wk); c->dup = d; (void)hipMemsetAsync(a0.tie_n, 0, 4, st); }
     const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
     VcFwdArgs a = a0;
     a.do_init = 1;
@@ -386,6 +388,7 @@ struct Plan {
 
     // the backtrack of `njobs` alignments (gsz per window) whose graphs have at most `max_rows` rows
     void launch_trace(Work& wk, VcTraceArgs& ta, uint32_t njobs, uint32_t gsz, uint32_t max_rows) {
+        if (c->dup & 1u) { const uint32_t d = c->dup; c->dup = 0; launch_trace(wk, ta, njobs, gsz, max_rows); c->dup = d; }
         Timer t(c, KC_TRACE, wk.stream);
         if (!c->trace_wave) {
             hipLaunchKernelGGL(k_trace, dim3((njobs + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta);
@@ -418,7 +421,7 @@ struct Plan {
     int build_layer(Work& wk, uint32_t j) {
         const uint32_t ns = wk.ns;
         // full-span layers: rows from the incrementally kept order; partial-span layers: exact DFS on the Subgraph
-        { Timer t(c, KC_ROWS, wk.stream);
+        for (uint32_t rep = 0; rep < ((c->dup & 2u) ? 2u : 1u); ++rep) { Timer t(c, KC_ROWS, wk.stream);
           hipLaunchKernelGGL(k_rows, dim3(ns), dim3(64), rows_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing); }
         if (c->h_layer_partial[j]) {
             Timer t(c, KC_ROWS, wk.stream);
@@ -467,9 +470,9 @@ struct Plan {
         const bool pws = vc_prune_lds_bytes(NCl, ECl) > kLdsCap, tws = topo_lds_bytes(NCl, ECl, c->STK, c->MA) > kLdsCap;
         pa.ws = pws ? wk.d_big_ws : nullptr; pa.ws_stride = c->big_ws_stride;
         pa.min_conf = c->prm.min_confidence; pa.min_supp = c->prm.min_support;
-        { Timer t(c, KC_PRUNE, wk.stream); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), pws ? 0 : vc_prune_lds_bytes(NCl, ECl), wk.stream, pa); }
+        for (uint32_t rep = 0; rep < ((c->dup & 4u) ? 2u : 1u); ++rep) { Timer t(c, KC_PRUNE, wk.stream); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), pws ? 0 : vc_prune_lds_bytes(NCl, ECl), wk.stream, pa); }
         wk.cur ^= 1;
-        { Timer t(c, KC_TOPO, wk.stream);
+        for (uint32_t rep = 0; rep < ((c->dup & 8u) ? 2u : 1u); ++rep) { Timer t(c, KC_TOPO, wk.stream);
           hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tws ? 0 : topo_lds_bytes(NCl, ECl, c->STK, c->MA), wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NCl, ECl,
                              tws ? wk.d_big_ws : nullptr, c->big_ws_stride); }
         if (more) {
@@ -574,6 +577,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->device = p->device;
     c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 4;      // measured: 2 -> 22.6 k, 3 -> 23.0 k, 4 -> 23.4 k windows/s on config C
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
+    if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
     if (const char* ti = getenv("VC_TRACE_IMPL")) c->trace_impl = std::atoi(ti) >= 1 && std::atoi(ti) <= 3 ? std::atoi(ti) : 1;
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }

@@ -45,12 +45,18 @@ def fq_or_fa(path):
     raise ValueError(f"invalid input file, must be FASTA/FASTQ format: {path}")
 
 
+COMMAND_LOG = None       # tests set this to a list: every external command the driver issues is appended (tests/test_driver.py)
+
+
 def _sh(cmd, cwd):
     print(f"[vechat_amd.driver] {cmd}", file=sys.stderr)
+    if COMMAND_LOG is not None:
+        COMMAND_LOG.append(cmd)
     env = dict(os.environ)                                    # the default polisher is this package: make it importable from the work directory
     pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = pkg_parent + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
-    rc = subprocess.call(cmd, shell=True, cwd=cwd, env=env)
+    # pipefail: a missing or failing minimap2 must not end as an empty overlap.paf that only shows up rounds later
+    rc = subprocess.call(["/bin/bash", "-o", "pipefail", "-c", cmd], cwd=cwd, env=env)
     if rc != 0:
         raise RuntimeError(f"command failed ({rc}): {cmd}")
 
@@ -78,13 +84,18 @@ def split_lines(path, lines_per_chunk, suffix, workdir, prefix="reads_chunk"):
     return out
 
 
+def _open_text(path):
+    return gzip.open(path, "rt") if str(path).endswith(".gz") else open(path, "r")
+
+
 def extract_sub_sequences(sequences, overlap, chunk_targets, workdir):
     """scripts/vechat:99-171: with --split only the reads that share an overlap with a target of the chunk are handed to the
-    polisher (the unwrapped 4-line FASTQ / 2-line FASTA layout the reference assumes)."""
+    polisher (the unwrapped 4-line FASTQ / 2-line FASTA layout the reference assumes; gzip input is read transparently,
+    where the reference's plain open() would fail)."""
     mode = fq_or_fa(chunk_targets)
     per = 4 if mode == "fq" else 2
     names = set()
-    with open(chunk_targets) as fr:
+    with _open_text(chunk_targets) as fr:
         for i, line in enumerate(fr):
             if i % per == 0:
                 names.add(line[1:].rstrip().split()[0])
@@ -98,7 +109,7 @@ def extract_sub_sequences(sequences, overlap, chunk_targets, workdir):
     per_q = 4 if mode_q == "fq" else 2
     out = os.path.join(workdir, f"query_sequences.tmp.{mode_q}")
     keep = False
-    with open(sequences) as fr, open(out, "w") as fw:
+    with _open_text(sequences) as fr, open(out, "w") as fw:
         for i, line in enumerate(fr):
             if i % per_q == 0:
                 keep = line[1:].rstrip().split()[0] in wanted
@@ -137,6 +148,10 @@ def run_error_correction(a, sequences, chunk_targets, corrected_file, iteration,
     else:
         print("perform linear sequence based error correction", file=sys.stderr)
         flags = f"-f -u -t {a.threads}" if a.include_unpolished else f"-f  -t {a.threads}"   # scripts/vechat:82-84, 91-93
+    if a.cuda_banded_alignment:
+        # scripts/vechat:59-66,76-80,86-89: the accelerator switches reach the polisher only together with -b (the polisher
+        # here is always the accelerated one and accepts them for what they are: hints for another device)
+        flags += f" -b --cudaaligner-batches {a.cudaaligner_batches} -c {a.cudapoa_batches}"
     _sh(f"{pol} {flags} {shlex.quote(sub_reads)} {shlex.quote(overlap)} {shlex.quote(chunk_targets)} >{shlex.quote(corrected_file)}", workdir)
     for f in os.listdir(workdir):
         if f.startswith("query_sequences.tmp."):
@@ -173,13 +188,21 @@ def main(argv=None):
     ap.add_argument("--scrub", action="store_true", help="scrub chimeric reads first (minimap2 + yacrd)")
     ap.add_argument("-u", "--include-unpolished", action="store_true")
     ap.add_argument("--base", action="store_true", help="base-level alignment for the round-1 overlaps")
-    ap.add_argument("--min-identity", default=0.8, type=float)
+    # pass-through values stay the strings the user typed, as in the reference (they are only ever formatted into commands)
+    ap.add_argument("--min-identity", default="0.8")
     ap.add_argument("--linear", action="store_true", help="one round of linear (racon) correction instead of the two rounds")
-    ap.add_argument("-d", "--min-confidence", default=0.2, type=float)
-    ap.add_argument("-s", "--min-support", default=0.2, type=float)
-    ap.add_argument("--min-ovlplen-cns", default=1000, type=int)
-    ap.add_argument("--min-identity-cns", default=0.99, type=float)
-    ap.add_argument("-t", "--threads", default=1, type=int)
+    ap.add_argument("-d", "--min-confidence", default="0.2")
+    ap.add_argument("-s", "--min-support", default="0.2")
+    ap.add_argument("--min-ovlplen-cns", default="1000")
+    ap.add_argument("--min-identity-cns", default="0.99")
+    ap.add_argument("-t", "--threads", default="1")
+    # scripts/vechat:262-275: parsed by the reference's wrapper and never handed to vechat_racon -- accepted, same (no) effect
+    for flag, long, dflt in (("-w", "--window-length", 500), ("-q", "--quality-threshold", 10.0), ("-e", "--error-threshold", 0.3),
+                             ("-m", "--match", 5), ("-x", "--mismatch", -4), ("-g", "--gap", -8)):
+        ap.add_argument(flag, long, default=dflt, help="accepted like the reference's wrapper accepts it: not passed on to the polisher")
+    ap.add_argument("--cudaaligner-batches", default=0, help="passed on with -b (scripts/vechat:59-66)")
+    ap.add_argument("-c", "--cudapoa-batches", default=0, help="passed on with -b")
+    ap.add_argument("-b", "--cuda-banded-alignment", action="store_true", help="hand -b --cudaaligner-batches N -c N to the polisher")
     ap.add_argument("--gpus", default=1, type=int, help="GPUs of this node for the polisher (one process per GPU)")
     ap.add_argument("--master-port", default=29561, type=int)
     ap.add_argument("--workdir", default=".", help="where the round files live (the reference uses the current directory)")

@@ -24,6 +24,10 @@ from .seqio import align_missing, load_polisher_input, read_overlaps, read_seque
 from .windows import WindowBuilder
 
 
+class DeviceWindowError(RuntimeError):
+    """A window whose graph the device cannot hold even at the largest capacities."""
+
+
 def target_cost(index, overlaps):
     """Estimated work per target, SURVEY 8(e): windows x depth x length ~ the bases of the overlaps laid on it (+ its own)."""
     pos = {n: k for k, (n, _) in enumerate(index)}
@@ -40,8 +44,8 @@ def main(argv=None):
     ap.add_argument("sequences"); ap.add_argument("overlaps"); ap.add_argument("targets")
     ap.add_argument("-p", "--haplotype", action="store_true", help="haplotype-aware (variation graph) correction")
     ap.add_argument("-f", "--fragment-correction", action="store_true", help="accepted for compatibility: this command always runs fragment correction")
-    ap.add_argument("-d", "--min-confidence", type=float, default=0.2)
-    ap.add_argument("-s", "--min-support", type=float, default=0.2)
+    ap.add_argument("-d", "--min-confidence", type=float, default=0.22)          # src/main.cpp:56-57
+    ap.add_argument("-s", "--min-support", type=float, default=0.19)
     ap.add_argument("-k", "--num-prune", type=int, default=3)
     ap.add_argument("-w", "--window-length", type=int, default=500)
     ap.add_argument("-q", "--quality-threshold", type=float, default=10.0)
@@ -52,6 +56,17 @@ def main(argv=None):
     ap.add_argument("-t", "--threads", type=int, default=1, help="accepted for compatibility (the work runs on the GPU)")
     ap.add_argument("-u", "--include-unpolished", action="store_true")
     ap.add_argument("--no-trimming", action="store_true")
+    # the reference's accelerator switches (src/main.cpp:31-35,125-137; scripts/vechat:59-66 passes them with -b): this
+    # polisher is always the accelerated one, so they select nothing -- accepted so that an unchanged wrapper keeps working
+    ap.add_argument("-c", "--cudapoa-batches", nargs="?", const=1, default=0, type=int, help="accepted for compatibility")
+    ap.add_argument("-b", "--cuda-banded-alignment", action="store_true", help="accepted for compatibility")
+    ap.add_argument("--cudaaligner-batches", type=int, default=0, help="accepted for compatibility")
+    ap.add_argument("--cudaaligner-band-width", type=int, default=0, help="accepted for compatibility")
+    ap.add_argument("--keep-going", action="store_true", help="a window the device cannot hold (graph beyond the 16-bit id space) "
+                    "keeps its backbone and counts as unpolished; without this flag the command names such windows and exits 3")
+    ap.add_argument("--max-nodes", type=int, default=0, help="pin the per-window graph capacity (0: estimated from the batch)")
+    ap.add_argument("--no-capacity-retry", action="store_true", help="do not re-run overflowed windows with doubled capacities")
+    ap.add_argument("--streams", type=int, default=0, help="chunk streams on the device (0: default)")
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
 
@@ -81,44 +96,69 @@ def main(argv=None):
         overlaps = [o for o in overlaps if o.t_name in keep_t]
         keep_r = {o.q_name for o in overlaps} | keep_t
 
-    targets, reads = read_sequences(a.targets, keep_t), read_sequences(a.sequences, keep_r)
     text = b""
-    n_windows = n_polished = kept = n_aligned = 0
-    if targets and reads and overlaps:
-        wb = WindowBuilder(a.window_length, a.quality_threshold)
-        n_aligned = align_missing(targets, reads, overlaps, a.error_threshold, device)      # PAF / MHAP without a CIGAR (overlap.cpp:205-220)
-        try:
-            kept, _ = load_polisher_input(wb, targets, reads, overlaps, a.error_threshold)
-        except ValueError as e:
-            if not distributed or "empty overlap set" not in str(e):
-                raise
-            kept = 0
-        if kept:
-            batch, ids = wb.build()
-            ctx = HipContext(device=device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
-                             num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
-                             window_type=window_type)
-            cons, status = ctx.consensus(batch)
-            ctx.close()
-            # every valid window is computed on the device; what can remain is a graph beyond the 16-bit id space after the capacity
-            # retries (VC_WIN_OVERFLOW) or input the reference would throw on (VC_WIN_INVALID): such a window keeps its backbone
-            # and counts as unpolished, like a window the reference leaves untouched (polisher.cpp:520-547)
-            bad = [w for w in range(batch.n_windows) if int(status[w]) > capi.VC_WIN_UNPOLISHED]
-            if bad:
-                print(f"[vechat_amd] warning: {len(bad)} window(s) left unpolished (first: window {bad[0]}, status {int(status[bad[0]])})", file=sys.stderr)
-                status = status.copy()
-                for w in bad:
-                    cons[w] = batch.window(w)[0][0]
-                    status[w] = capi.VC_WIN_UNPOLISHED
-            text = b"".join(b">" + name.encode() + b"\n" + data + b"\n"
-                            for name, data in wb.stitch(cons, status, drop_unpolished=not a.include_unpolished, fragment_correction=True))
-            n_windows, n_polished = batch.n_windows, sum(int(s) == capi.VC_WIN_OK for s in status)
+    n_targets = n_windows = n_polished = kept = n_aligned = 0
+    failure = None                                                # (exit code, message): reported by every rank through the collective below
+    try:
+        targets, reads = read_sequences(a.targets, keep_t), read_sequences(a.sequences, keep_r)
+        n_targets = len(targets)
+        if not distributed and not (targets and reads and overlaps):
+            raise ValueError("empty overlap set")
+        if targets:
+            wb = WindowBuilder(a.window_length, a.quality_threshold)
+            if reads and overlaps:
+                n_aligned = align_missing(targets, reads, overlaps, a.error_threshold, device)   # PAF / MHAP without a CIGAR (overlap.cpp:205-220)
+            # A rank of a multi-GPU run may own targets that keep no overlap at all (skewed input, the round-2 filters).  The
+            # reference builds windows for EVERY target (polisher.cpp:389-411), so such targets still come out -- unpolished,
+            # i.e. only with -u -- exactly as the single-rank run emits them.
+            kept, _ = load_polisher_input(wb, targets, reads, overlaps, a.error_threshold, allow_empty=distributed)
+            if kept or a.include_unpolished:
+                batch, ids = wb.build()
+                ctx = HipContext(device=device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
+                                 num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
+                                 window_type=window_type, max_nodes=a.max_nodes, n_streams=a.streams)
+                cons, status = ctx.consensus(batch, retry_overflow=not a.no_capacity_retry)
+                ctx.close()
+                # Every valid window is computed on the device.  What can remain is a graph beyond the 16-bit id space after the
+                # capacity retries (VC_WIN_OVERFLOW) or input the reference would throw on (VC_WIN_INVALID).  The reference's
+                # accelerated polisher re-runs such windows on the CPU (cudapolisher.cpp:355-379); this command has no CPU path,
+                # so it refuses to print bytes the reference would not print: it names the windows and exits non-zero, unless
+                # --keep-going asks for their backbones to be kept as unpolished stretches.
+                bad = [w for w in range(batch.n_windows) if int(status[w]) > capi.VC_WIN_UNPOLISHED]
+                if bad:
+                    names = ", ".join(f"target {targets[ids[w][0]][0]} window {ids[w][1]} (status {int(status[w])})" for w in bad[:8])
+                    msg = f"{len(bad)} window(s) could not be computed on the device: {names}{' ...' if len(bad) > 8 else ''}"
+                    if not a.keep_going:
+                        raise DeviceWindowError(msg + "; rerun with --keep-going to emit them unpolished")
+                    print(f"[vechat_amd] warning: {msg}; kept as unpolished backbone (--keep-going)", file=sys.stderr)
+                    status = status.copy()
+                    for w in bad:
+                        cons[w] = batch.window(w)[0][0]
+                        status[w] = capi.VC_WIN_UNPOLISHED
+                text = b"".join(b">" + name.encode() + b"\n" + data + b"\n"
+                                for name, data in wb.stitch(cons, status, drop_unpolished=not a.include_unpolished, fragment_correction=True))
+                n_windows, n_polished = batch.n_windows, sum(int(s) == capi.VC_WIN_OK for s in status)
             wb.close()
-    elif not distributed:
-        raise ValueError("empty overlap set")
-    print(f"[vechat_amd] rank {rank}/{world}: {len(targets)} targets, {kept} overlaps ({n_aligned} aligned on the device), {n_windows} windows, "
+    except DeviceWindowError as e:
+        failure = (3, str(e))
+    except Exception as e:                                        # noqa: BLE001 -- a failing rank must still take part in the collective
+        if not distributed:
+            raise
+        failure = (1, f"{type(e).__name__}: {e}")
+    print(f"[vechat_amd] rank {rank}/{world}: {n_targets} targets, {kept} overlaps ({n_aligned} aligned on the device), {n_windows} windows, "
           f"{n_polished} polished", file=sys.stderr)
     if distributed:
+        # error flags first, so that no rank is left waiting in the gather for one that failed
+        codes = torch.tensor([failure[0] if failure else 0], dtype=torch.int64, device=dev)
+        all_codes = [torch.zeros_like(codes) for _ in range(world)]
+        dist.all_gather(all_codes, codes)
+        worst = max(int(c.item()) for c in all_codes)
+        if worst:
+            if failure:
+                print(f"[vechat_amd] rank {rank}: error: {failure[1]}", file=sys.stderr)
+            dist.barrier()
+            dist.destroy_process_group()
+            return worst
         payload = torch.from_numpy(np.frombuffer(text + b"\0", dtype=np.uint8).copy()[:-1]).to(dev)
         call, lall = gather_consensus(payload, torch.tensor([len(text)], dtype=torch.int64, device=dev), dst=0, force=True)
         dist.barrier()
@@ -126,6 +166,9 @@ def main(argv=None):
         if rank != 0:
             return 0
         text = call.cpu().numpy().tobytes()
+    elif failure:
+        print(f"[vechat_amd] error: {failure[1]}", file=sys.stderr)
+        return failure[0]
     sys.stdout.write(text.decode())
     sys.stdout.flush()
     return 0

@@ -210,12 +210,14 @@ def align_missing(targets, reads, overlaps, error_threshold=0.3, device=0, shard
     return n_ok
 
 
-def load_polisher_input(builder, targets, reads, overlaps, error_threshold=0.3):
+def load_polisher_input(builder, targets, reads, overlaps, error_threshold=0.3, allow_empty=False):
     """Feed a WindowBuilder the way Polisher::initialize fills its tables (fragment-correction mode, -f).
-    Returns (number of overlaps kept, window_type): window_type 0 = NGS (mean read length <= 1000), 1 = TGS."""
+    Returns (number of overlaps kept, window_type): window_type 0 = NGS (mean read length <= 1000), 1 = TGS.
+    allow_empty: one rank's share of a multi-GPU run may keep no overlap (or no read); its targets still get their
+    windows, like every target does in the reference (polisher.cpp:389-411)."""
     if not targets:
         raise ValueError("empty target sequences set")
-    if not reads:
+    if not reads and not allow_empty:
         raise ValueError("empty sequences set")
     _resolve_indices(targets, reads, overlaps)
     t_id, q_id = {}, {}
@@ -243,6 +245,6 @@ def load_polisher_input(builder, targets, reads, overlaps, error_threshold=0.3):
             raise ValueError("overlap without a CIGAR: run align_missing() first")
         builder.add_overlap(q, t, o.strand, o.q_begin, o.q_end, o.q_length, o.t_begin, o.t_end, o.cigar)
         kept += 1
-    if kept == 0:
+    if kept == 0 and not allow_empty:
         raise ValueError("empty overlap set")
-    return kept, 0 if total / float(len(reads)) <= 1000 else 1
+    return kept, 0 if total / float(max(len(reads), 1)) <= 1000 else 1
