@@ -170,25 +170,6 @@ def test_thread_per_alignment_backtrack_agrees(built, monkeypatch):
     c.close()
 
 
-@pytest.mark.parametrize("impl", ["2", "3"])
-def test_one_round_trip_backtrack_agrees(built, monkeypatch, impl):
-    """k_tracex (8 / 16 lanes per alignment, first-in-edge chains from VcDp::anc, no LDS): the alternative cooperative
-    backtrack kept beside k_tracew (VC_TRACE_IMPL).  NW and SW walks, partial spans, IUPAC bytes, rows with more in-edges
-    than a record holds, int32 (k_fwd_wide) jobs next to it."""
-    monkeypatch.setenv("VC_TRACE_IMPL", impl)
-    c = HipContext(device=0)
-    for seed, L, D, n, kw in [(1002, 500, 64, 4, {}), (13, 300, 20, 6, dict(n_haplotypes=2, snp_rate=0.02, frac_partial=0.3)),
-                              (17, 250, 20, 8, dict(fastq=0, backbone_fastq=1, frac_partial=0.25)),
-                              (1005, 1000, 128, 1, dict(profile=capi.ONT))]:
-        _check(c, capi.synth_batch(capi.synth_cfg(seed, L, D, **kw), 0, n), f"tracex{impl} seed{seed}")
-    gold = fixtures.load_windows()
-    batch = fixtures.fixture_batch(gold["windows"])
-    cons, status = c.consensus(batch)
-    c.close()
-    for w, win in enumerate(gold["windows"]):
-        assert cons[w].decode() == win["expected"]["hap"]["consensus"], win["name"]
-
-
 def test_tie_resolution_by_exact_dfs(built, monkeypatch):
     """End-cell ties are normally settled by the closure shortcut; force the exact-DFS fallback (which works
     out of an HBM workspace) on every tie and require the same bytes."""

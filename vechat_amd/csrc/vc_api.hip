@@ -15,7 +15,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -97,6 +100,7 @@ struct vc_ctx {
     uint32_t* d_lut_w = nullptr; double* d_lut_d = nullptr;
     unsigned long long* d_stat = nullptr;   // [VC_STAT_SLOTS][8] cells, rows, -, far-row reads, trace steps, speculated steps, rounds, -
 
+    bool packed = false;                 // stored DP rows of this batch: byte-packed (both score sets within the byte bound at the widest class) or raw
     uint32_t wcols = 0;                  // != 0: some alignment may need k_fwd_wide; columns of its int32 matrices (multiple of 512)
     uint32_t MA = 4;                     // entries per aligned list: max(4, distinct bytes in the batch - 1), even
     uint32_t ws_cpl = 0, ws_max_len = 0, cw_run = 0;   // width class / longest sequence the workspaces are sized for; chunk size of the current batch
@@ -105,13 +109,20 @@ struct vc_ctx {
     uint32_t big_ws_stride = 0;          // bytes per window of the HBM workspace for oversized graph images (0: all fit the LDS)
     std::vector<uint8_t> h_pre_status;   // per-window status decided at submit (outside the envelope), empty = none
     bool trace_wave = true;
-    int trace_impl = 1;           // 1: k_tracew (16 lanes, two round trips per round, LDS table); 2 / 3: k_tracex with 8 / 16 lanes per alignment
-                                  // (one round trip, no LDS, fewer instructions -- measured no faster)
     uint32_t dbg_stop_kind = 0, dbg_stop_index = 0;   // vc_debug_stop_after: leave the chunk's graphs as they are after that stage
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
     uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
+    // One host thread per chunk stream drives its chunks through the phases (vc_run starts them, vc_sync joins them): the one
+    // host wait of the path -- the pruned graphs' height before a re-alignment round -- then stalls that stream only, and a
+    // stream takes its next chunk as soon as it is done (no lockstep between streams, no barrier between groups of chunks).
+    bool host_threads = true;
+    std::thread workers[kMaxStreams];
+    bool workers_running = false;
+    std::atomic<uint32_t> next_chunk{0};
+    std::atomic<int> run_rc{0};
+    std::mutex mu;                       // err, event pool / records, launch counters
 
     void* h_stage[2] = {nullptr, nullptr};   // pinned staging for uploads from pageable caller memory
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
@@ -131,7 +142,7 @@ int fail(vc_ctx* c, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (c) c->err = buf; else g_create_error = buf;
+    if (c) { std::lock_guard<std::mutex> lk(c->mu); c->err = buf; } else g_create_error = buf;
     return code;
 }
 
@@ -152,7 +163,14 @@ int dalloc(vc_ctx* c, std::vector<void*>& list, T** out, size_t n) {
     return VC_OK;
 }
 
+void join_workers(vc_ctx* c) {
+    if (!c->workers_running) return;
+    for (uint32_t k = 0; k < c->n_streams; ++k) if (c->workers[k].joinable()) c->workers[k].join();
+    c->workers_running = false;
+}
+
 void sync_ctx(vc_ctx* c) {
+    join_workers(c);
     (void)hipStreamSynchronize(c->stream);
     for (uint32_t k = 0; k < c->n_streams; ++k) if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
 }
@@ -198,6 +216,7 @@ int alloc_graph(vc_ctx* c, VcGraph* g) {
     if ((rc = dalloc(c, c->chunk_allocs, &g->ord, CW * NC))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &g->pos, CW * NC))) return rc;
     if ((rc = dalloc(c, c->chunk_allocs, &g->visits, CW * NC))) return rc;
+    if ((rc = dalloc(c, c->chunk_allocs, &g->nrec, CW * NC))) return rc;
     return VC_OK;
 }
 
@@ -205,13 +224,11 @@ int alloc_work(vc_ctx* c, Work* wk) {
     const size_t CW = c->CW, NC = c->NC, EC = c->EC, PC = c->PC;
     int rc;
     if ((rc = alloc_graph(c, &wk->gr[0])) || (rc = alloc_graph(c, &wk->gr[1]))) return rc;
-    wk->dp.pstride = (uint32_t)NC + 8;
     if ((rc = dalloc(c, c->chunk_allocs, &wk->dp.nrows, CW)) || (rc = dalloc(c, c->chunk_allocs, &wk->dp.flags, CW)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rec, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.frec, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
-        (c->trace_impl >= 2 && ((rc = dalloc(c, c->chunk_allocs, &wk->dp.par, CW * (NC + 8))) || (rc = dalloc(c, c->chunk_allocs, &wk->dp.anc, CW * NC)))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_resolve_ws, (size_t)kResolveGrid * ((topo_lds_bytes(NC, c->EC, c->STK, c->MA) + 15u) & ~15u))) ||
         (c->big_ws_stride && (rc = dalloc(c, c->chunk_allocs, &wk->d_big_ws, (size_t)CW * c->big_ws_stride))) ||
@@ -261,18 +278,22 @@ int h2d(vc_ctx* c, void* dst, const void* src, size_t bytes) {
 struct Timer {
     vc_ctx* c; int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool timed = false;
     Timer(vc_ctx* c_, int cls_, hipStream_t st_) : c(c_), cls(cls_), st(st_) {
-        c->stats.launches[cls]++;
-        timed = c->prm.profile == 1 || (c->prm.profile == 2 && cls == KC_FWD);
-        if (!timed) return;
-        if (c->ev_next + 2 > c->ev_pool.size()) {
-            for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->stats.launches[cls]++;
+            timed = c->prm.profile == 1 || (c->prm.profile == 2 && cls == KC_FWD);
+            if (!timed) return;
+            if (c->ev_next + 2 > c->ev_pool.size()) {
+                for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
+            }
+            a = c->ev_pool[c->ev_next++]; b = c->ev_pool[c->ev_next++];
         }
-        a = c->ev_pool[c->ev_next++]; b = c->ev_pool[c->ev_next++];
         (void)hipEventRecord(a, st);
     }
     ~Timer() {
         if (!timed) return;
         (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lk(c->mu);
         c->ev_recs.push_back({cls, a, b});
     }
 };
@@ -302,8 +323,9 @@ void flush_events(vc_ctx* c) {
 }
 
 template <int CA, int CB>
-void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs) {
-    hipLaunchKernelGGL((k_fwd<CA, CB, kRing>), dim3(jobs), dim3(64), 0, st, a);
+void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs, bool packed) {
+    if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, kRing, true>), dim3(jobs), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_fwd<CA, CB, kRing, false>), dim3(jobs), dim3(64), 0, st, a);
 }
 
 // One launch when the batch's sequences fall into one width class or two adjacent ones (the usual case:
@@ -322,14 +344,14 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
     if (hi - lo == 1) {
         { Timer t(c, KC_FWD, st);
         switch (hi) {
-            case 1: launch_fwd_t<4, 6>(st, a, jobs); break;
-            case 2: launch_fwd_t<6, 8>(st, a, jobs); break;
-            case 3: launch_fwd_t<8, 10>(st, a, jobs); break;
-            case 4: launch_fwd_t<10, 12>(st, a, jobs); break;
-            case 5: launch_fwd_t<12, 16>(st, a, jobs); break;
-            case 6: launch_fwd_t<16, 20>(st, a, jobs); break;
-            case 7: launch_fwd_t<20, 24>(st, a, jobs); break;
-            case 8: launch_fwd_t<24, 32>(st, a, jobs); break;
+            case 1: launch_fwd_t<4, 6>(st, a, jobs, c->packed); break;
+            case 2: launch_fwd_t<6, 8>(st, a, jobs, c->packed); break;
+            case 3: launch_fwd_t<8, 10>(st, a, jobs, c->packed); break;
+            case 4: launch_fwd_t<10, 12>(st, a, jobs, c->packed); break;
+            case 5: launch_fwd_t<12, 16>(st, a, jobs, c->packed); break;
+            case 6: launch_fwd_t<16, 20>(st, a, jobs, c->packed); break;
+            case 7: launch_fwd_t<20, 24>(st, a, jobs, c->packed); break;
+            case 8: launch_fwd_t<24, 32>(st, a, jobs, c->packed); break;
         }
         }
         wide();
@@ -338,15 +360,15 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
     for (int i = lo; i <= hi; ++i) {
         Timer t(c, KC_FWD, st);
         switch (opts[i]) {
-            case 4:  launch_fwd_t<4, 4>(st, a, jobs); break;
-            case 6:  launch_fwd_t<6, 6>(st, a, jobs); break;
-            case 8:  launch_fwd_t<8, 8>(st, a, jobs); break;
-            case 10: launch_fwd_t<10, 10>(st, a, jobs); break;
-            case 12: launch_fwd_t<12, 12>(st, a, jobs); break;
-            case 16: launch_fwd_t<16, 16>(st, a, jobs); break;
-            case 20: launch_fwd_t<20, 20>(st, a, jobs); break;
-            case 24: launch_fwd_t<24, 24>(st, a, jobs); break;
-            case 32: launch_fwd_t<32, 32>(st, a, jobs); break;
+            case 4:  launch_fwd_t<4, 4>(st, a, jobs, c->packed); break;
+            case 6:  launch_fwd_t<6, 6>(st, a, jobs, c->packed); break;
+            case 8:  launch_fwd_t<8, 8>(st, a, jobs, c->packed); break;
+            case 10: launch_fwd_t<10, 10>(st, a, jobs, c->packed); break;
+            case 12: launch_fwd_t<12, 12>(st, a, jobs, c->packed); break;
+            case 16: launch_fwd_t<16, 16>(st, a, jobs, c->packed); break;
+            case 20: launch_fwd_t<20, 20>(st, a, jobs, c->packed); break;
+            case 24: launch_fwd_t<24, 24>(st, a, jobs, c->packed); break;
+            case 32: launch_fwd_t<32, 32>(st, a, jobs, c->packed); break;
         }
         a.do_init = 0;
     }
@@ -373,7 +395,7 @@ struct Plan {
         fa.sm = c->prm.sw_match; fa.sn = c->prm.sw_mismatch; fa.sg = c->prm.sw_gap;
         fa.hmat = wk.d_hmat; fa.c0 = wk.d_c0;
         fa.job_end = wk.d_job_end; fa.job_type = wk.d_job_type; fa.tie_rows = wk.d_tie_rows; fa.tie_cnt = wk.d_tie_cnt; fa.tie_list = wk.d_tie_list; fa.tie_n = wk.d_tie_n;
-        fa.stat = c->d_stat;
+        fa.stat = c->d_stat; fa.wcols = c->wcols;
         return fa;
     }
     VcTraceArgs trace_args(const Work& wk) const {
@@ -382,7 +404,7 @@ struct Plan {
         ta.m = c->prm.match; ta.n = c->prm.mismatch; ta.g = c->prm.gap;
         ta.sm = c->prm.sw_match; ta.sn = c->prm.sw_mismatch; ta.sg = c->prm.sw_gap;
         ta.wmat = wk.d_wmat; ta.wstride = (uint64_t)NC * c->wcols; ta.wcols = c->wcols; ta.c0w = wk.d_c0w; ta.only_wide = 0;
-        ta.stat = c->d_stat; ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC;
+        ta.stat = c->d_stat; ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC; ta.packed = c->packed ? 1 : 0;
         return ta;
     }
 
@@ -394,14 +416,8 @@ struct Plan {
             hipLaunchKernelGGL(k_trace, dim3((njobs + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta);
             return;
         }
-        if (c->trace_impl == 1) {
-            ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = std::min(max_rows, kTraceTabRows);
-            hipLaunchKernelGGL(k_tracew, dim3((njobs + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0), wk.stream, ta);
-        } else {
-            const uint32_t tg = c->trace_impl == 2 ? 8u : 4u;
-            if (tg == 8) hipLaunchKernelGGL(k_tracex<8>, dim3((njobs + tg - 1) / tg), dim3(64), 0, wk.stream, ta);
-            else hipLaunchKernelGGL(k_tracex<16>, dim3((njobs + tg - 1) / tg), dim3(64), 0, wk.stream, ta);
-        }
+        ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = std::min(max_rows, kTraceTabRows);
+        hipLaunchKernelGGL(k_tracew, dim3((njobs + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0), wk.stream, ta);
         if (c->wcols) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((njobs + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); ta.only_wide = 0; }
     }
 
@@ -414,15 +430,14 @@ struct Plan {
         }
         (void)hipMemsetAsync(wk.dp.nrows, 0, (size_t)ns * 4, wk.stream);      // skipped windows must not carry a stale height
         { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3(ns), dim3(64), 0, wk.stream, c->b, w0, ns); }
-        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), 0, wk.stream, c->b, wk.gr[0], w0, ns, NC, EC); }
+        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), 0, wk.stream, c->b, wk.gr[0], wk.dp, w0, ns, NC, EC, (uint32_t)kRing); }
     }
 
     // one layer of the build loop (window.cpp:239-298) for every window of the chunk
     int build_layer(Work& wk, uint32_t j) {
         const uint32_t ns = wk.ns;
-        // full-span layers: rows from the incrementally kept order; partial-span layers: exact DFS on the Subgraph
-        for (uint32_t rep = 0; rep < ((c->dup & 2u) ? 2u : 1u); ++rep) { Timer t(c, KC_ROWS, wk.stream);
-          hipLaunchKernelGGL(k_rows, dim3(ns), dim3(64), rows_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing); }
+        // the rows of a full-span layer were made at the tail of the kernel that last changed the graph (k_init / k_addaln);
+        // a partial-span layer aligns to a Subgraph
         if (c->h_layer_partial[j]) {
             Timer t(c, KC_ROWS, wk.stream);
             const uint32_t sub_lds = 8 * ((NC + 63) / 64) + 2 * NC + ((NC + 15) & ~15u) + 4 * (NC / 32 + 1) + 64;
@@ -446,7 +461,8 @@ struct Plan {
         launch_trace(wk, ta, ns, 1, NC);
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
-        aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16;
+        aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16; aa.ring = (uint32_t)kRing;
+        aa.make_rows = !(c->dbg_stop_kind == 1 && c->dbg_stop_index == j);
         { Timer t(c, KC_ADDALN, wk.stream); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, wk.stream, aa); }
         return VC_OK;
     }
@@ -496,7 +512,7 @@ struct Plan {
         uint32_t group = (uint32_t)std::min<uint64_t>(c->hmat_dwords / (stride * ns), c->rgroup_max);
         if (group == 0) group = 1;
         group = std::min(group, wk.nseq_max);
-        if (group >= 8) group &= ~7u;                          // whole waves of k_tracex share one jump table
+        if (group >= 8) group &= ~7u;                          // whole waves of k_tracew share one first-in-edge table
         VcFwdArgs fa = fwd_args(wk);
         VcTraceArgs ta = trace_args(wk);
         for (uint32_t k0 = 0; k0 < wk.nseq_max; k0 += group) {
@@ -548,7 +564,36 @@ struct Plan {
         wk.active = false;
         return VC_OK;
     }
+
+    // every phase of one chunk on its stream, in order (window.cpp:176-428 for each window of the chunk)
+    int run_chunk(Work& wk, uint32_t w0, uint32_t ns) {
+        int rc;
+        begin(wk, w0, ns);
+        for (uint32_t j = 1; j <= wk.layers; ++j) if ((rc = build_layer(wk, j))) return rc;
+        if (!wk.layers) { wk.active = false; return VC_OK; }
+        if (c->prm.mode == 1) return linear_tail(wk);
+        for (uint32_t r = 0; r < c->prm.num_prune; ++r) {
+            const bool more = r + 1 < c->prm.num_prune;
+            if ((rc = prune(wk, more))) return rc;
+            if (!more) break;
+            if ((rc = realign(wk))) return rc;
+        }
+        return finish(wk);
+    }
 };
+
+// host thread of chunk stream s: takes chunks off the batch until none is left
+void chunk_worker(vc_ctx* c, uint32_t s, Plan pl) {
+    if (hipSetDevice(c->device) != hipSuccess) { c->run_rc = fail(c, VC_ERR_HIP, "hipSetDevice failed in a chunk thread"); return; }
+    const uint32_t CW = c->cw_run, nw = c->b.n_windows;
+    for (;;) {
+        const uint32_t k = c->next_chunk.fetch_add(1);
+        if ((uint64_t)k * CW >= nw || c->run_rc.load() != VC_OK) break;
+        const uint32_t w0 = k * CW;
+        const int rc = pl.run_chunk(c->works[s], w0, std::min(CW, nw - w0));
+        if (rc) { c->run_rc = rc; break; }
+    }
+}
 
 }  // namespace
 
@@ -578,8 +623,8 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 4;      // measured: 2 -> 22.6 k, 3 -> 23.0 k, 4 -> 23.4 k windows/s on config C
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
+    if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
-    if (const char* ti = getenv("VC_TRACE_IMPL")) c->trace_impl = std::atoi(ti) >= 1 && std::atoi(ti) <= 3 ? std::atoi(ti) : 1;
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }
     // The chunk streams must run CONCURRENTLY.  HIP multiplexes streams of one priority onto a small pool of
     // hardware queues (GPU_MAX_HW_QUEUES, default 4) round-robin, so two of ours can land on the same queue
@@ -751,6 +796,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     if (have_ws && !c->prm.max_edges) EC = std::max(EC, c->EC);
     if (NC > 59968) return fail(c, VC_ERR_ARG, "max_nodes %u exceeds the 16-bit id space (59968)", NC);
     c->cpl = pick_cpl(std::min(max_len, kMaxColumns));                  // width classes of THIS batch (kernel selection)
+    c->packed = vc_row_packed(c->prm.match, c->prm.mismatch, c->prm.gap, (int)c->cpl) &&
+                vc_row_packed(c->prm.sw_match, c->prm.sw_mismatch, c->prm.sw_gap, (int)c->cpl);
     c->cpl_min = pick_cpl(std::min(min_len, kMaxColumns));
     const uint32_t cpl = pick_cpl(std::min(ws_max_len, kMaxColumns));   // width class the matrices are sized for
     const uint32_t lds_cap = kLdsCap;
@@ -769,7 +816,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint32_t S = c->n_streams;
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6)) / S;
     const uint64_t rowd = 64ull * (cpl / 2);
-    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2) + EC * 2ull + 32) +
+    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6 + 16) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2) + EC * 2ull + 32) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
     // Can any alignment of this batch leave the packed-int16 kernel's envelope (vc_fwd_body's check: the reference's int16
     // rule, simd impl:699-706, on the worst case the capacities allow)?  Then k_fwd_wide and its int32 matrices are needed.
@@ -801,7 +848,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         c->ws_max_len = ws_max_len;
         c->big_ws_stride = big;
         // re-alignment rounds work on pruned graphs (a quarter of NC rows, typically), so more alignments per window fit the
-        // same matrix space than full-height ones: the small per-job arrays are sized for up to 16 (two waves of k_tracex)
+        // same matrix space than full-height ones: the small per-job arrays are sized for up to 16
         c->rgroup_max = wcols ? group_max : std::min(std::max(group_max, 16u), std::max(max_nseq, 1u));
         c->jobs_cap = CW * c->rgroup_max;
         c->hmat_dwords = (uint64_t)CW * group_max * NC * rowd;
@@ -834,6 +881,8 @@ int vc_run(vc_ctx* c) {
     if (!c) return VC_ERR_ARG;
     if (!c->have_batch) return fail(c, VC_ERR_STATE, "vc_run before vc_submit");
     HIPCHK(c, hipSetDevice(c->device));
+    join_workers(c);
+    c->run_rc = VC_OK;
     const VcBatchDev& b = c->b;
     Plan pl{};
     pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
@@ -857,6 +906,15 @@ int vc_run(vc_ctx* c) {
     for (int i = 0; i < KC_N; ++i) { c->stats.ms[i] = 0; c->stats.busy_ms[i] = 0; c->stats.launches[i] = 0; }
 
     const uint32_t S = c->n_streams, CW = c->cw_run;
+    if (c->host_threads && c->dbg_stop_kind == 0) {
+        c->next_chunk = 0; c->run_rc = VC_OK;
+        for (uint32_t s = 0; s < S; ++s) c->works[s].active = false;
+        const uint32_t n_chunks = (b.n_windows + CW - 1) / CW;
+        for (uint32_t s = 0; s < S && s < n_chunks; ++s) c->workers[s] = std::thread(chunk_worker, c, s, pl);
+        c->workers_running = true;
+        c->ran = true;                      // vc_sync joins the threads and reports what they met
+        return VC_OK;
+    }
     for (uint32_t g0 = 0; g0 < b.n_windows; g0 += S * CW) {
         // S chunks advance in lockstep, each on its own stream
         uint32_t max_layers = 0;
@@ -905,13 +963,17 @@ int vc_run(vc_ctx* c) {
 int vc_sync(vc_ctx* c) {
     if (!c) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    join_workers(c);
     for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s]));
     if (c->prm.profile) flush_events(c);
+    if (c->run_rc.load() != VC_OK) { c->ran = false; return c->run_rc.load(); }
+    HIPCHK(c, hipGetLastError());
     return VC_OK;
 }
 
 static int fetch_lengths(vc_ctx* c) {
-    if (!c->ran) return fail(c, VC_ERR_STATE, "no finished run");
+    join_workers(c);
+    if (!c->ran || c->run_rc.load() != VC_OK) return fail(c, VC_ERR_STATE, "no finished run");
     for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s]));
     const uint32_t nw = c->b.n_windows;
     c->h_cons_len.resize(nw); c->h_status.resize(nw);
@@ -1048,6 +1110,21 @@ int vc_debug_stage_digest(vc_ctx* c, uint32_t w, int with_pairs, uint64_t* out) 
     return VC_OK;
 }
 
+// development (tools/gpu_rowstats.py): the row records (backtrack view, 4 dwords per row) that the next alignment of window w will
+// use, after a run stopped with vc_debug_stop_after; returns the number of rows through *nrows.  Single-chunk batches only.
+int vc_debug_rows(vc_ctx* c, uint32_t w, uint32_t* out, uint32_t cap_rows, uint32_t* nrows) {
+    if (!c || !out || !nrows || !c->have_batch || w >= c->b.n_windows || c->b.n_windows > c->cw_run) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    sync_ctx(c);
+    const Work& wk = c->works[0];
+    uint32_t n = 0;
+    HIPCHK(c, hipMemcpy(&n, wk.dp.nrows + w, 4, hipMemcpyDeviceToHost));
+    if (n > c->NC || n > cap_rows) return fail(c, VC_ERR_CAPACITY, "vc_debug_rows: %u rows", n);
+    HIPCHK(c, hipMemcpy(out, wk.dp.rec + (size_t)w * c->NC, (size_t)n * 16, hipMemcpyDeviceToHost));
+    *nrows = n;
+    return VC_OK;
+}
+
 #ifdef VC_LAB
 // development (tools/gpu_fwd_lab.py): build the first chunk up to `layer`, prepare that layer's rows, then time `reps`
 // launches of k_fwd alone with parts of its row loop switched off (VcFwdArgs::dbg).  Nothing downstream runs.
@@ -1070,7 +1147,6 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
     if (built_to != layer) {
         pl.begin(wk, 0, std::min(c->cw_run, c->b.n_windows));
         for (uint32_t j = 1; j < layer; ++j) if ((rc = pl.build_layer(wk, j))) return rc;
-        hipLaunchKernelGGL(k_rows, dim3(wk.ns), dim3(64), 0, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, wk.ns, pl.NC, pl.EC, (int)layer, (uint32_t)kRing);
         built_to = layer;
     }
     VcFwdArgs fa = pl.fwd_args(wk);
@@ -1111,10 +1187,6 @@ int vc_get_stats(vc_ctx* c, vc_stats* s) {
     c->stats.trace_steps = st[4]; c->stats.trace_spec = st[5]; c->stats.trace_rounds = st[6];
     c->stats.alignments = c->stats.launches[KC_FWD];
     c->stats.n_streams = c->n_streams;
-#ifdef VC_TX_PROF
-    std::fprintf(stderr, "[tx prof] backtrack waves %llu: shader cycles per wave %.0f, of which table prologue %.0f; rounds per wave-group %.1f\n",
-                 st[3], st[3] ? (double)st[2] / st[3] : 0.0, st[3] ? (double)st[7] / st[3] : 0.0, st[3] ? (double)st[6] / st[3] : 0.0);
-#endif
     *s = c->stats;
     return VC_OK;
 }

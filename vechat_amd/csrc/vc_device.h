@@ -22,6 +22,7 @@
 #define VC_RF_OVF   4u
 #define VC_RF_PREV  8u     // one of the predecessors is the row directly above (still in registers)
 #define VC_RF_SLOW  16u    // frec only: a listed predecessor is the virtual row 0 or lies beyond the LDS ring, or the list overflowed
+#define VC_RF_PLAIN 32u    // frec only: the row directly above is the ONLY predecessor (the commonest row: nothing to fetch)
 
 struct VcGraph {
     uint32_t* n_nodes;    // [CW]
@@ -40,6 +41,9 @@ struct VcGraph {
     uint16_t* ord;        // [CW*NC] a valid DP order of the nodes (aligned groups contiguous), kept incrementally
     uint16_t* pos;        // [CW*NC] inverse of ord
     uint16_t* visits;     // [CW*NC] sequences (len >= 2) whose path contains the node == Node::Coverage() (graph.cpp:38-56)
+    uint4*    nrec;       // [CW*NC] in-side of a node in one 16-byte record: x = code | in-degree << 16, then the tails of the first
+                          //   VC_INLINE_PRED in-edges as u16 NODE ids in list order.  Kept by k_init / k_addaln (build phase only);
+                          //   the row records of a full-span layer are made from it with three dependent loads per row
 };
 
 // Input of the alignment kernel for one graph, produced by k_topo in rank order.
@@ -53,11 +57,6 @@ struct VcDp {
     uint4*    frec;       // [CW*NC] the forward kernel's view of the same row (see vc_make_frec)
     uint16_t* rank2node;  // [CW*NC]
     uint16_t* ovf;        // [CW*EC]
-    uint16_t* par;        // [CW*pstride] row behind the first in-edge of DP row r (entry r, 1-based; entry 0 = 0xFFFF):
-                          //   0 = the virtual row 0, 0xFFFF = not listed inline (overflow list)
-    uint32_t  pstride;    // NC + 8
-    uint4*    anc;        // nullptr unless k_tracex is the backtrack in use.  [CW*NC] entry r-1: 8 x u16, the rows 1 .. 8 links behind row r along first in-edges
-                          //   (0 = the virtual row, after which the chain ends; 0xFFFF = the chain has ended)
 };
 
 struct VcBatchDev {

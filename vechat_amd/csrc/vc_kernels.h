@@ -109,6 +109,7 @@ __device__ __forceinline__ uint4 vc_make_frec(uint32_t code, uint32_t fl, uint32
         }
     }
     if (slow) f |= VC_RF_SLOW;
+    if (hasprev && nq == 0 && !slow) f |= VC_RF_PLAIN;
     const uint32_t bi = code == 'A' ? 0u : code == 'C' ? 1u : code == 'G' ? 2u : code == 'T' ? 3u : 4u;
     uint4 o;
     o.x = code | (f << 8) | (nq << 16) | (bi << 24);
@@ -116,38 +117,6 @@ __device__ __forceinline__ uint4 vc_make_frec(uint32_t code, uint32_t fl, uint32
     o.z = out[2] | ((uint32_t)out[3] << 16);
     o.w = out[4] | ((uint32_t)out[5] << 16);
     return o;
-}
-
-// First-in-edge chains for the backtrack.  ~85 % of the backtrack's moves are "diagonal through the first in-edge", so
-// k_tracex speculates along that chain.  The kernels that write the row records store the chain's parent of every row
-// (VcDp::par: the row behind the first in-edge; 0 = the virtual row 0, 0xFFFF = not listed inline) and then call
-// vc_anc_finish, which follows the parents eight links deep: VcDp::anc[r-1] = the rows 1 .. 8 links behind row r
-// (0xFFFF once the chain has ended), one 16-byte load for the backtrack instead of a table in LDS.
-__device__ __forceinline__ uint16_t vc_parent(uint32_t r1, uint32_t np, uint32_t d0, bool is_ovf) {
-    return (uint16_t)((np != 0 && !is_ovf && d0 <= r1) ? r1 - d0 : 0xFFFFu);
-}
-__device__ __forceinline__ void vc_anc_finish(uint16_t* par, uint4* anc, uint32_t nrows, int lane) {
-    if (lane == 0) par[0] = 0xFFFF;                    // the virtual row has no parent
-    __syncthreads();                                   // every row's parent is in memory (same workgroup: visible after the barrier)
-    constexpr int U = 4;                               // rows per lane per pass: independent chains in flight
-    for (uint32_t r0 = 1; r0 <= nrows; r0 += 64 * U) {
-        uint32_t cur[U], w[U][4];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { const uint32_t r = r0 + 64 * u + lane; cur[u] = r <= nrows ? r : 0xFFFFu; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                cur[u] = par[cur[u] == 0xFFFFu ? 0u : cur[u]];
-                if (k & 1) w[u][k >> 1] |= cur[u] << 16; else w[u][k >> 1] = cur[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t r = r0 + 64 * u + lane;
-            if (r <= nrows) anc[r - 1] = make_uint4(w[u][0], w[u][1], w[u][2], w[u][3]);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -189,11 +158,14 @@ __global__ __launch_bounds__(64) void k_avg(VcBatchDev b, uint32_t w0, uint32_t 
     if (lane == 0) b.win_avg[w] = avg;
 }
 
+__device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph& g, const VcDp& dp, uint32_t slot, uint32_t w,
+                                             uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t N);
+
 // ------------------------------------------------------------------------------------------------
 // k_init: backbone chain graph (AddAlignment with an empty alignment, graph.cpp:207-212)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, uint32_t w0, uint32_t nslots,
-                                             uint32_t NC, uint32_t EC) {
+__global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+                                             uint32_t NC, uint32_t EC, uint32_t ring) {
     uint32_t slot = blockIdx.x;
     if (slot >= nslots) return;
     uint32_t w = w0 + slot;
@@ -219,6 +191,7 @@ __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, uint32_t w
         g.al_cnt[nb + i] = 0;
         g.ord[nb + i] = (uint16_t)i; g.pos[nb + i] = (uint16_t)i;
         g.visits[nb + i] = L >= 2 ? 1 : 0;
+        g.nrec[nb + i] = make_uint4((uint32_t)b.bases[o0 + i] | (i > 0 ? 1u << 16 : 0u), i > 0 ? i - 1 : 0u, 0u, 0u);
         if (i + 1 < L) {
             uint32_t wgt = b.lut_w[b.quals[o0 + i]] + b.lut_w[b.quals[o0 + i + 1]];
             g.e_tn[eb + i] = i | ((uint32_t)VC_NONE16 << 16);
@@ -227,6 +200,8 @@ __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, uint32_t w
         }
     }
     if (lane == 0) { g.n_nodes[slot] = L; g.n_edges[slot] = L - 1; }
+    __syncthreads();
+    vc_rows_full(b, g, dp, slot, w, NC, EC, 1, ring, L);          // rows of the first layer's alignment
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -492,11 +467,9 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             dp.rec[nb + r] = rec;
             dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl, is_ovf, hasprev, r, ring);
-            if (dp.anc) dp.par[(uint64_t)slot * dp.pstride + r + 1] = vc_parent(r + 1, np, rec.y & 0xFFFF, is_ovf);
         }
         ovf_base += tot_ovf;
     }
-    if (dp.anc) vc_anc_finish(dp.par + (uint64_t)slot * dp.pstride, dp.anc + nb, nrows, lane);
     bad = __any(bad);
     if (lane == 0) {
         dp.nrows[slot] = nrows;
@@ -506,125 +479,129 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_rows: row records for a FULL-SPAN next layer from the incrementally maintained order VcGraph::ord
+// vc_rows_full (was k_rows): row records for a FULL-SPAN next layer from the incrementally maintained order VcGraph::ord
 // (no DFS).  H and the backtrack do not depend on which topological order the rows are visited in
 // (sisd :315-360 only needs predecessors first; ties in the backtrack follow in-edge LIST order),
 // so any valid order gives the reference's matrix.  The one place the reference's rank matters --
 // "first sink in rank order" among equal end scores (sisd :353-355) -- is settled by k_resolve,
 // which runs the exact DFS only for the ~1-2 % of alignments that actually tie.
 // ------------------------------------------------------------------------------------------------
+// Row records of a full-span layer.  The rows of such an alignment are the nodes in the kept order VcGraph::ord, so the record
+// of row r follows from the node's own record (code, in-degree, tails of the first in-edges in list order -- VcGraph::nrec,
+// kept by k_init / k_addaln), the tails' positions and the node's out-list head: three dependent loads per row instead of a
+// walk along the in-edge chain.  Writes the backtrack's view (VcDp::rec), the forward view (VcDp::frec) and rank2node.  A
+// list beyond VC_INLINE_PRED entries is walked through the in-edge chain into VcDp::ovf (rare).
+struct VcOtf {
+    const uint16_t* ord; const uint16_t* pos; const uint4* nrec; const uint16_t* out_first; const uint16_t* in_first; const uint32_t* e_tn;
+    uint4* rec; uint4* frec; uint16_t* rank2node; uint16_t* ovf;
+    uint32_t N, EC;
+};
+template <int U>
+__device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_t ring, uint32_t& ovf_base, int& bad) {
+    // U blocks of 64 rows at once, level by level: every load of a level is issued before the first result is used, so a lane
+    // has U (then 6 U) independent loads in flight instead of one chain
+    const uint32_t lane = (uint32_t)vc_lane();
+    uint32_t r[U], v[U], of[U], np[U];
+    bool act[U];
+    uint4 nr[U];
+    uint32_t pp[U][VC_INLINE_PRED];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { r[u] = r0 + 64 * u + lane; act[u] = r[u] < o.N; v[u] = act[u] ? (uint32_t)o.ord[r[u]] : 0u; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        nr[u] = make_uint4(0, 0, 0, 0); of[u] = 0;
+        if (act[u]) { nr[u] = o.nrec[v[u]]; of[u] = o.out_first[v[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        np[u] = nr[u].x >> 16;
+        const uint32_t pid[VC_INLINE_PRED] = {nr[u].y & 0xFFFF, nr[u].y >> 16, nr[u].z & 0xFFFF, nr[u].z >> 16, nr[u].w & 0xFFFF, nr[u].w >> 16};
+#pragma unroll
+        for (int k = 0; k < VC_INLINE_PRED; ++k) pp[u][k] = (act[u] && (uint32_t)k < np[u]) ? (uint32_t)o.pos[pid[k]] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t code = nr[u].x & 0xFF;
+        uint32_t npu = np[u];
+        uint16_t dl[VC_INLINE_PRED];
+        bool hasprev = false;
+#pragma unroll
+        for (int k = 0; k < VC_INLINE_PRED; ++k) {
+            dl[k] = 0;
+            if (act[u] && (uint32_t)k < npu) {
+                if (pp[u][k] >= r[u]) bad |= 2;                   // the kept order must stay topological
+                const uint32_t delta = r[u] - pp[u][k];
+                dl[k] = (uint16_t)delta;
+                hasprev |= delta == 1;
+            }
+        }
+        const bool is_ovf = npu > VC_INLINE_PRED;
+        if (__any(is_ovf)) {
+            uint32_t tot_ovf;
+            const uint32_t my_ovf = wave_excl_sum(is_ovf ? npu : 0u, tot_ovf) + ovf_base;
+            if (is_ovf) {
+                if (my_ovf + npu > o.EC) bad |= 1;
+                else {
+                    uint32_t k = 0;
+                    for (uint32_t e = o.in_first[v[u]]; e != VC_NONE16; ) {
+                        const uint32_t tn = o.e_tn[e];
+                        e = tn >> 16;
+                        const uint32_t delta = r[u] - o.pos[tn & 0xFFFF];
+                        o.ovf[my_ovf + k] = (uint16_t)delta;
+                        hasprev |= delta == 1;
+                        k++;
+                    }
+                }
+                dl[0] = (uint16_t)(my_ovf & 0xFFFF); dl[1] = (uint16_t)(my_ovf >> 16);
+                dl[2] = (uint16_t)(npu & 0xFFFF); dl[3] = (uint16_t)(npu >> 16);
+            }
+            ovf_base += tot_ovf;
+        }
+        if (act[u]) {
+            if (npu == 0) { npu = 1; dl[0] = (uint16_t)(r[u] + 1); }       // the virtual row 0 is `row` rows above
+            const uint32_t fl = (of[u] == VC_NONE16 ? VC_RF_SINK : 0u) | (is_ovf ? VC_RF_OVF : 0u) | (hasprev ? VC_RF_PREV : 0u);
+            uint4 rec;
+            rec.x = code | (fl << 8) | (min(npu, 255u) << 16);
+            rec.y = dl[0] | ((uint32_t)dl[1] << 16);
+            rec.z = dl[2] | ((uint32_t)dl[3] << 16);
+            rec.w = dl[4] | ((uint32_t)dl[5] << 16);
+            o.rec[r[u]] = rec;
+            o.rank2node[r[u]] = (uint16_t)v[u];
+            o.frec[r[u]] = vc_make_frec(code, fl, npu, dl, is_ovf, hasprev, r[u], ring);
+        }
+    }
+}
+
+// Runs at the tail of the kernel that last changed the graph (k_init for layer 1, k_addaln of layer j for layer j + 1): the wave
+// that has just written the graph prepares the rows of its next alignment, instead of a kernel of its own between k_addaln and
+// k_fwd (one launch and one queueing delay less per layer, and the graph arrays are still warm in the cache).
 #ifndef VC_ROWS_U
 #define VC_ROWS_U 4
 #endif
-__global__ __launch_bounds__(64) void k_rows(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                             uint32_t NC, uint32_t EC, int next_layer, uint32_t ring) {
-    VC_LATENCY_KERNEL_PRIO();
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t slot = blockIdx.x;
-    if (slot >= nslots) return;
-    const uint32_t w = w0 + slot;
-    if (b.status[w] != VC_WIN_OK) return;
+__device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph& g, const VcDp& dp, uint32_t slot, uint32_t w,
+                                             uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t N) {
     const int lane = vc_lane();
     const uint32_t s0 = b.win_seq_off[w], ns = b.win_seq_off[w + 1] - s0;
     if ((uint32_t)next_layer >= ns) return;
     {
         const uint32_t L = (uint32_t)(b.seq_off[s0 + 1] - b.seq_off[s0]);
-        if (!vc_full_span(b.seq_begin[s0 + next_layer], b.seq_end[s0 + next_layer], L)) return;   // k_topo's job
+        if (!vc_full_span(b.seq_begin[s0 + next_layer], b.seq_end[s0 + next_layer], L)) return;   // k_rows_sub's job
     }
-    const uint32_t N = g.n_nodes[slot];
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
-    int bad = 0, broken = 0;
+    VcOtf ot;
+    ot.ord = g.ord + nb; ot.pos = g.pos + nb; ot.nrec = g.nrec + nb; ot.out_first = g.out_first + nb; ot.in_first = g.in_first + nb;
+    ot.e_tn = g.e_tn + eb; ot.rec = dp.rec + nb; ot.frec = dp.frec + nb; ot.rank2node = dp.rank2node + nb; ot.ovf = dp.ovf + eb;
+    ot.N = N; ot.EC = EC;
     uint32_t ovf_base = 0;
-    // VC_ROWS_U blocks of 64 rows per iteration: the in-edge lists are chains of dependent loads, and the wave's only
-    // way to have more of them in flight is to walk several rows per lane at once
-    for (uint32_t r0 = 0; r0 < N; r0 += 64 * VC_ROWS_U) {
-        uint32_t rr[VC_ROWS_U], vv[VC_ROWS_U], np_[VC_ROWS_U], ee[VC_ROWS_U], of_[VC_ROWS_U], cd_[VC_ROWS_U];
-        bool act_[VC_ROWS_U], hp_[VC_ROWS_U];
-        uint16_t dl_[VC_ROWS_U][VC_INLINE_PRED];
-#pragma unroll
-        for (int u = 0; u < VC_ROWS_U; ++u) {
-            rr[u] = r0 + 64 * u + lane;
-            act_[u] = rr[u] < N;
-            vv[u] = act_[u] ? g.ord[nb + rr[u]] : 0;
-            np_[u] = 0; hp_[u] = false;
-#pragma unroll
-            for (int k = 0; k < VC_INLINE_PRED; ++k) dl_[u][k] = 0;
-        }
-#pragma unroll
-        for (int u = 0; u < VC_ROWS_U; ++u) {
-            ee[u] = act_[u] ? (uint32_t)g.in_first[nb + vv[u]] : (uint32_t)VC_NONE16;
-            of_[u] = act_[u] ? (uint32_t)g.out_first[nb + vv[u]] : 0u;
-            cd_[u] = act_[u] ? (uint32_t)g.code[nb + vv[u]] : 0u;
-        }
-        for (;;) {
-            bool any_ = false;
-#pragma unroll
-            for (int u = 0; u < VC_ROWS_U; ++u) any_ |= ee[u] != VC_NONE16;
-            if (!any_) break;
-            uint32_t tn[VC_ROWS_U], pt[VC_ROWS_U];
-#pragma unroll
-            for (int u = 0; u < VC_ROWS_U; ++u) tn[u] = ee[u] != VC_NONE16 ? g.e_tn[eb + ee[u]] : 0u;
-#pragma unroll
-            for (int u = 0; u < VC_ROWS_U; ++u) pt[u] = ee[u] != VC_NONE16 ? (uint32_t)g.pos[nb + (tn[u] & 0xFFFF)] : 0u;
-#pragma unroll
-            for (int u = 0; u < VC_ROWS_U; ++u) {
-                if (ee[u] != VC_NONE16) {
-                    if (pt[u] >= rr[u]) broken = 1;                  // the kept order must stay topological
-                    const uint32_t delta = rr[u] - pt[u];
-#pragma unroll
-                    for (int k = 0; k < VC_INLINE_PRED; ++k) if (np_[u] == (uint32_t)k) dl_[u][k] = (uint16_t)delta;
-                    np_[u]++;
-                    hp_[u] |= delta == 1;
-                    ee[u] = tn[u] >> 16;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < VC_ROWS_U; ++u) {
-            const uint32_t r = rr[u], v = vv[u];
-            uint32_t np = np_[u];
-            const bool is_ovf = np > VC_INLINE_PRED;
-            uint32_t tot_ovf;
-            const uint32_t my_ovf = wave_excl_sum(is_ovf ? np : 0u, tot_ovf) + ovf_base;
-            if (act_[u]) {
-                if (np == 0) { np = 1; dl_[u][0] = (uint16_t)(r + 1); }
-                if (is_ovf) {
-                    if (my_ovf + np > EC) bad = 1;
-                    else {
-                        uint32_t k = 0;
-                        for (uint32_t e = g.in_first[nb + v]; e != VC_NONE16; ) {
-                            const uint32_t tn = g.e_tn[eb + e];
-                            e = tn >> 16;
-                            const uint32_t delta = r - g.pos[nb + (tn & 0xFFFF)];
-                            dp.ovf[eb + my_ovf + k] = (uint16_t)delta;
-                            k++;
-                        }
-                    }
-                    dl_[u][0] = (uint16_t)(my_ovf & 0xFFFF); dl_[u][1] = (uint16_t)(my_ovf >> 16);
-                    dl_[u][2] = (uint16_t)(np & 0xFFFF); dl_[u][3] = (uint16_t)(np >> 16);
-                }
-                const uint32_t fl = (of_[u] == VC_NONE16 ? VC_RF_SINK : 0u) | (is_ovf ? VC_RF_OVF : 0u) | (hp_[u] ? VC_RF_PREV : 0u);
-                uint4 rec;
-                rec.x = cd_[u] | (fl << 8) | (min(np, 255u) << 16);
-                rec.y = dl_[u][0] | ((uint32_t)dl_[u][1] << 16);
-                rec.z = dl_[u][2] | ((uint32_t)dl_[u][3] << 16);
-                rec.w = dl_[u][4] | ((uint32_t)dl_[u][5] << 16);
-                dp.rec[nb + r] = rec;
-                dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl_[u], is_ovf, hp_[u], r, ring);
-                dp.rank2node[nb + r] = (uint16_t)v;
-                if (dp.anc) dp.par[(uint64_t)slot * dp.pstride + r + 1] = vc_parent(r + 1, np, rec.y & 0xFFFF, is_ovf);
-            }
-            ovf_base += tot_ovf;
-        }
-    }
-    if (dp.anc) vc_anc_finish(dp.par + (uint64_t)slot * dp.pstride, dp.anc + nb, N, lane);
-    bad = __any(bad);
-    broken = __any(broken);
-    if (broken) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 12, 0); return; }   // order invariant violated
+    int bad = 0;
+    // VC_ROWS_U blocks of 64 rows per iteration: more independent load chains in flight per lane
+    for (uint32_t r0 = 0; r0 < N; r0 += 64 * VC_ROWS_U) vc_otf_rows<VC_ROWS_U>(ot, r0, ring, ovf_base, bad);
+    bad = __any(bad & 1) | (__any(bad & 2) ? 2 : 0);
+    if (bad & 2) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 12, 0); return; }   // order invariant violated
     if (lane == 0) {
         dp.nrows[slot] = N;
-        dp.flags[slot] = (bad ? 1u : 0u) | 2u;
-        if (bad) b.errinfo[w] = (13u << 16) | (ovf_base & 0xFFFF);
+        dp.flags[slot] = ((bad & 1) ? 1u : 0u) | 2u;
+        if (bad & 1) b.errinfo[w] = (13u << 16) | (ovf_base & 0xFFFF);
     }
 }
 
@@ -784,11 +761,9 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
             dp.rec[nb + r] = rec;
             dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl, is_ovf, hasprev, r, ring);
             dp.rank2node[nb + r] = (uint16_t)v;
-            if (dp.anc) dp.par[(uint64_t)slot * dp.pstride + r + 1] = vc_parent(r + 1, np, rec.y & 0xFFFF, is_ovf);
         }
         ovf_base += tot_ovf;
     }
-    if (dp.anc) vc_anc_finish(dp.par + (uint64_t)slot * dp.pstride, dp.anc + nb, nrows, lane);
     for (uint32_t i = lane; i < NC / 32 + 1; i += 64) submask[(uint64_t)slot * (NC / 32 + 1) + i] = s_sub[i];
     bad = __any(bad);
     broken = __any(broken);
@@ -1004,6 +979,7 @@ struct VcFwdArgs {
     uint32_t* tie_list;            // [jobs] windows whose alignment ended in a tie (build phase)
     uint32_t* tie_n;               // [1]
     unsigned long long* stat;      // [4] cells, rows, -, far-row reads
+    uint32_t wcols;                // != 0: k_fwd_wide follows this launch and takes what the packed-int16 kernel declines
 #ifdef VC_LAB
     uint32_t dbg;                  // development (tools/gpu_fwd_lab.py): parts of the row loop switched off, timing only
 #endif
@@ -1092,8 +1068,9 @@ __device__ __forceinline__ int vc_packed_cell(const uint32_t* w, uint32_t cc, ui
 //     max_p (H[p][j-1] + P[j]) = (max_p H[p][j-1]) + P[j],   max_p (H[p][j] + g) = (max_p H[p][j]) + g,
 // so each additional in-edge costs one packed max per register instead of a full relaxation, and the
 // order of the in-edges is irrelevant here (it matters only to the backtrack, which follows it).
-template <int CPL, int RING, bool NWT>
+template <int CPL, int RING, bool NWT, bool PACKED>
 __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_raw) {
+    static_assert((RING & (RING - 1)) == 0, "ring slots are taken with a mask");
     constexpr int ND = CPL / 2;              // packed int16 dwords per lane per row
     constexpr int NDS = vc_nds(CPL);         // dwords per lane per row in the packed stored form
     uint32_t (*ring)[ND][64] = reinterpret_cast<uint32_t (*)[ND][64]>(ring_raw);
@@ -1139,6 +1116,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
             // outside the packed-int16 envelope: not an error -- the job keeps type 255 and k_fwd_wide (int32 lanes, any
             // length, like the reference's fallback to 32-bit lanes, simd impl:699-706) takes it
             if (len == 0 || nrows == 0 || (a.dp.flags[slot] & 1u)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 3, (a.dp.flags[slot] & 1u) ? 1 : 2); }
+            else if (a.wcols == 0) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 27, nrows); }    // the host planned no k_fwd_wide: say so, do not skip silently
             return;
         }
     }
@@ -1171,7 +1149,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     }
 
     uint32_t* const hrow0 = a.hmat + (uint64_t)job * a.hstride;
-    const bool packed = vc_row_packed(m, n, g, CPL);
+    constexpr bool packed = PACKED;           // the stored row form is a property of the launch (host: both score sets fit the byte bound)
     int16_t* const c0p_out = a.c0 + (uint64_t)job * a.NC;
     const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
 
@@ -1191,66 +1169,69 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     // block is fetched a block ahead
     uint4 myrec = make_uint4(0, 0, 0, 0), nextrec = make_uint4(0, 0, 0, 0);
     if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
-    uint32_t* hrow = hrow0;                                   // stored form of the current row
-    const uint32_t rowdw = packed ? NDS * 64 : ND * 64;
+    constexpr uint32_t rowdw = PACKED ? NDS * 64 : ND * 64;     // dwords per stored row
+    uint32_t voff = PACKED ? lane * NDS : lane;                 // my dword offset inside the stored matrix (one 32-bit add per row)
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+
+    // a row of the LDS ring merged into the running maximum; column 0 of the last 64 rows lives in c0vec
+    auto ring_merge = [&](uint32_t pr, int& c0m) __attribute__((always_inline)) {
+        const uint32_t* rp = ring_raw + (pr & (RING - 1)) * (ND * 64) + lane;
+        uint32_t hp[ND];
+#pragma unroll
+        for (int q = 0; q < ND; ++q) hp[q] = rp[q * 64];
+        const int c0p = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
+#pragma unroll
+        for (int q = 0; q < ND; ++q) acc[q] = pk_max(acc[q], hp[q]);
+        c0m = max(c0m, c0p);
+    };
+
     for (uint32_t i0 = 1; i0 <= nrows; i0 += 64) {              // blocks of 64 rows: one record fetch, one column-0 flush
       myrec = nextrec;
       {
           const uint32_t r = i0 - 1 + 64 + lane;
           if (r < nrows) nextrec = a.dp.frec[nb + r];
       }
-      const uint32_t cnt = min(64u, nrows - i0 + 1);
+      const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, nrows - i0 + 1));
       for (uint32_t ri = 0; ri < cnt; ++ri) {
         const uint32_t i = i0 + ri;
         const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
-        const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
-        const uint32_t x = r0 & 0xFF, fl = (r0 >> 8) & 0xFF, nq = (r0 >> 16) & 0xFF, bi = r0 >> 24;
 
-        // ---- element-wise maximum over the predecessor rows (and over their column 0)
-        int c0m;
-        if (fl & VC_RF_PREV) {
-            c0m = c0prev;                     // acc already holds row i-1
-        } else {
-            c0m = VC_INT_MIN;
+        // ---- element-wise maximum over the predecessor rows (and over their column 0).  The commonest row has the row
+        // above as its only predecessor: acc and c0prev are that maximum already
+        int c0m = c0prev;
+        if (!(r0 & (VC_RF_PLAIN << 8))) {
+            if (!(r0 & (VC_RF_PREV << 8))) {
+                c0m = VC_INT_MIN;
 #pragma unroll
-            for (int q = 0; q < ND; ++q) acc[q] = 0x80008000u;
-        }
-        if (nq && !VC_LABF(4)) {
-            // a row of the LDS ring; column 0 of the last 64 rows lives in c0vec
-            auto ringrow = [&](uint32_t delta, uint32_t (&hp)[ND], int& c0p) __attribute__((always_inline)) {
-                const uint32_t pr = i - delta, rs = pr % RING;
-#pragma unroll
-                for (int q = 0; q < ND; ++q) hp[q] = ring[rs][q][lane];
-                c0p = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
-            };
-            auto merge = [&](const uint32_t (&hp)[ND], int c0p) __attribute__((always_inline)) {
-#pragma unroll
-                for (int q = 0; q < ND; ++q) acc[q] = pk_max(acc[q], hp[q]);
-                c0m = max(c0m, c0p);
-            };
-            uint32_t hA[ND], hB[ND];
-            int cA = 0, cB = 0;
-            if (VC_LABF(256) && (fl & VC_RF_SLOW)) {
-            } else if (!(fl & VC_RF_SLOW)) {
-                // usual case: every listed predecessor sits in the LDS ring
-                ringrow(r1 & 0xFFFF, hA, cA);
-                if (nq > 1) ringrow(r1 >> 16, hB, cB);
-                merge(hA, cA);
-                if (nq > 1) {
-                    merge(hB, cB);
-                    if (nq > 2) {
-                        const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
-                        const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
-                        for (uint32_t p = 2; p < nq; ++p) {
-                            const uint32_t wsel = p < 4 ? r2 : r3;
-                            ringrow((p & 1) ? (wsel >> 16) : (wsel & 0xFFFF), hA, cA);
-                            merge(hA, cA);
+                for (int q = 0; q < ND; ++q) acc[q] = 0x80008000u;
+            }
+            const uint32_t nq = (r0 >> 16) & 0xFF;
+            if (!(r0 & (VC_RF_SLOW << 8))) {
+                // every listed predecessor sits in the LDS ring: straight-line, one test per further in-edge
+                if (nq) {
+                    const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
+                    ring_merge(i - (r1 & 0xFFFF), c0m);
+                    if (nq > 1) {
+                        ring_merge(i - (r1 >> 16), c0m);
+                        if (nq > 2) {
+                            const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
+                            ring_merge(i - (r2 & 0xFFFF), c0m);
+                            if (nq > 3) {
+                                ring_merge(i - (r2 >> 16), c0m);
+                                if (nq > 4) {
+                                    const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
+                                    ring_merge(i - (r3 & 0xFFFF), c0m);
+                                    if (nq > 5) ring_merge(i - (r3 >> 16), c0m);
+                                }
+                            }
                         }
                     }
                 }
             } else {
                 // general path: the virtual row 0 analytically, a recent row from the LDS ring, an older one
                 // back from the stored matrix in HBM; long lists come from VcDp::ovf
+                const uint32_t fl = (r0 >> 8) & 0xFF;
+                const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
                 const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
                 const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
                 const uint32_t nlist = (fl & VC_RF_OVF) ? r2 : nq;
@@ -1264,15 +1245,16 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
                         delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
                     }
                     const uint32_t pr = i - delta;
-                    if (pr == 0) {
+                    if (pr == 0) {                                                   // H[0][j] = j*g (NW) / 0 (SW); column 0: 0
 #pragma unroll
-                        for (int q = 0; q < ND; ++q) hA[q] = nw ? 0u : njg[q];       // H[0][j] = j*g (NW) / 0 (SW)
-                        cA = 0;
+                        for (int q = 0; q < ND; ++q) acc[q] = pk_max(acc[q], nw ? 0u : njg[q]);
+                        c0m = max(c0m, 0);
                     } else if (delta <= (uint32_t)RING) {
-                        ringrow(delta, hA, cA);
+                        ring_merge(pr, c0m);
                     } else {
+                        uint32_t hA[ND];
                         __threadfence_block();                                        // my own earlier stores must have landed
-                        if (packed) {
+                        if (PACKED) {
                             const uint32_t* hr = hrow0 + (uint64_t)(pr - 1) * (NDS * 64) + lane * NDS;
                             uint32_t wv[NDS];
 #pragma unroll
@@ -1284,10 +1266,13 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
                             for (int q = 0; q < ND; ++q) hA[q] = hr[q * 64 + lane];
                         }
                         far_reads++;
+                        int cA;
                         if (delta <= 64) cA = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
                         else cA = (int)__builtin_amdgcn_readfirstlane((int)c0p_out[pr - 1]);
+#pragma unroll
+                        for (int q = 0; q < ND; ++q) acc[q] = pk_max(acc[q], hA[q]);
+                        c0m = max(c0m, cA);
                     }
-                    merge(hA, cA);
                 }
             }
         }
@@ -1298,6 +1283,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         uint32_t P[ND];
 #pragma unroll
         for (int q = 0; q < ND; ++q) P[q] = __builtin_amdgcn_alignbit(acc[q], q == 0 ? left : acc[q - 1], 16);
+        const uint32_t bi = r0 >> 24;
         if (bi < 2) {
             if (bi == 0) {
 #pragma unroll
@@ -1313,6 +1299,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
 #pragma unroll
             for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfT[q]);
         } else {
+            const uint32_t x = r0 & 0xFF;
 #pragma unroll
             for (int q = 0; q < ND; ++q)
                 P[q] = pk_add(P[q], ((uint32_t)(((sbp[q] & 0xFFFFu) == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)(((sbp[q] >> 16) == x) ? mt : nt) << 16));
@@ -1343,9 +1330,8 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         for (int q = 0; q < ND; ++q) acc[q] = pk_max(P[q], cc);
 
         // ---- end cell
-        if (VC_LABF(16)) {
-        } else if (nw) {
-            if (fl & VC_RF_SINK) {                           // sisd :353-355 (same column: tilted compare is exact)
+        if (nw) {
+            if (r0 & (VC_RF_SINK << 8)) {                    // sisd :353-355 (same column: tilted compare is exact)
                 uint32_t hv = acc[0];
 #pragma unroll
                 for (int q = 1; q < ND; ++q) hv = (c_e / 2 == (uint32_t)q) ? acc[q] : hv;
@@ -1372,20 +1358,19 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
 
         // ---- keep the row: registers (acc), LDS ring, HBM
         c0prev = col0;
-        c0vec = ((uint32_t)lane == ri) ? col0 : c0vec;
-        const uint32_t ws = i % RING;
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(c0vec) : "s"(col0), "s"(ri));      // lane ri keeps this row's column 0
         // one wave per workgroup: LDS operations of a wave retire in order, so no s_barrier (and no
         // vmcnt(0) drain of the H stores) is needed -- only keep the compiler from reordering
         __builtin_amdgcn_wave_barrier();
-        if (!VC_LABF(2)) {
+        {
+            uint32_t* wp = ring_raw + (i & (RING - 1)) * (ND * 64) + lane;
 #pragma unroll
-        for (int q = 0; q < ND; ++q) ring[ws][q][lane] = acc[q];
+            for (int q = 0; q < ND; ++q) wp[q * 64] = acc[q];
         }
-        if (VC_LABF(1)) {
-        } else if (packed) {
+        if (PACKED) {
             uint32_t wv[NDS];
             vc_pack_row<ND, NDS>(acc, wv);
-            uint32_t* hr = hrow + lane * NDS;
+            uint32_t* hr = hrow0 + voff;
             if (NDS == 2) *reinterpret_cast<uint2*>(hr) = make_uint2(wv[0], wv[1]);
             else if (NDS == 4) *reinterpret_cast<uint4*>(hr) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
             else if (NDS == 3) { struct __attribute__((packed, aligned(4))) u3 { uint32_t a, b, c; }; *reinterpret_cast<u3*>(hr) = u3{wv[0], wv[1], wv[2]}; }
@@ -1396,18 +1381,18 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         } else {
             // full 256-B rows on purpose: masking the lanes past the sequence end was measured SLOWER
             // (partial cache-line writes), although it would save 20 % of the bytes
+            uint32_t* hr = hrow0 + voff;
 #pragma unroll
-            for (int q = 0; q < ND; ++q) hrow[q * 64 + lane] = acc[q];
+            for (int q = 0; q < ND; ++q) hr[q * 64] = acc[q];
         }
-        hrow += rowdw;
+        voff += rowdw;
         __builtin_amdgcn_wave_barrier();
       }
       if ((uint32_t)lane < cnt) c0p_out[i0 - 1 + lane] = (int16_t)c0vec;   // column 0 of the block just completed
       __threadfence_block();
     }
-#ifndef VC_TX_PROF
+    (void)lane4;
     if (lane == 0 && far_reads) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
-#endif
 
     // publish the end cell
     uint32_t end = 0;
@@ -1450,7 +1435,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     if (lane == 0) a.job_end[job] = end;
 }
 
-template <int CPL, int RING>
+template <int CPL, int RING, bool PACKED>
 __device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_raw) {
     // alignment type of this job (uniform per wave)
     bool nw = a.mode == 0;
@@ -1464,13 +1449,13 @@ __device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_ra
             nw = (k == 0) || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L);
         }
     }
-    if (nw) vc_fwd_body<CPL, RING, true>(a, ring_raw);
-    else vc_fwd_body<CPL, RING, false>(a, ring_raw);
+    if (nw) vc_fwd_body<CPL, RING, true, PACKED>(a, ring_raw);
+    else vc_fwd_body<CPL, RING, false, PACKED>(a, ring_raw);
 }
 
 // CA <= CB: the two adjacent width classes of a batch share one launch (register and LDS budget of the
 // wider one); each alignment takes the narrowest body that holds its sequence.  CA == CB: single class.
-template <int CA, int CB, int RING>
+template <int CA, int CB, int RING, bool PACKED>
 __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     __shared__ uint32_t ring_raw[RING * (CB / 2) * 64];
     if (CA != CB) {
@@ -1481,9 +1466,9 @@ __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
         uint32_t cls = CB;
         if (k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + k + 1] - a.b.seq_off[s0 + k]));
-        if (cls == (uint32_t)CA) { vc_fwd_any<CA, RING>(a, ring_raw); return; }
+        if (cls == (uint32_t)CA) { vc_fwd_any<CA, RING, PACKED>(a, ring_raw); return; }
     }
-    vc_fwd_any<CB, RING>(a, ring_raw);
+    vc_fwd_any<CB, RING, PACKED>(a, ring_raw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1694,6 +1679,7 @@ struct VcTraceArgs {
     uint32_t k0;
     unsigned long long* stat;   // [VC_STAT_SLOTS][8], see vc_ctx::d_stat
     const int* wmat; uint64_t wstride; uint32_t wcols; const int* c0w;   // matrices of k_fwd_wide (job types 2, 3)
+    int packed;                 // stored row form of this launch's k_fwd (byte-packed rows or raw int16 pairs)
     int only_wide;              // k_trace: take only those jobs (k_tracew walked the rest)
     int shared_table;           // k_tracew: the VC_TG alignments of a wave share a window (group % VC_TG == 0)
     uint32_t tab_rows;          // k_tracew: rows the LDS table is sized for (>= every graph's height in this launch)
@@ -1730,7 +1716,7 @@ __global__ void k_trace(VcTraceArgs a) {
     const uint16_t* hm = (const uint16_t*)hm32;
     const int16_t* c0 = a.c0 + (uint64_t)job * a.NC;
     const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[a.b.win_seq_off[w] + k + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
-    const bool packed = vc_row_packed(m, n, g, (int)cpl);
+    const bool packed = a.packed != 0;
     // k_fwd stores the tilted matrix T[r][col] = H[r][col] - col*g; the tests of sisd :392-448 become
     // diagonal T == T' + (score - g), vertical T == T' + g, horizontal T == T', SW stop T == -col*g
     auto Hat = [&](uint32_t r, uint32_t col) -> int {     // T[r][col] incl. the virtual row 0 / column 0
@@ -1878,7 +1864,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     const uint16_t* hm = (const uint16_t*)hm32;
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
     const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
-    const bool packed = vc_row_packed(m, n, g, (int)cpl);
+    const bool packed = a.packed != 0;
     const uint32_t nrows = valid ? min(a.dp.nrows[slot], a.tab_rows) : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
     // horizontal T == T', SW stop T == -col*g.  (The runtime division by cpl stays: a multiply-high in its place made the
@@ -2087,318 +2073,6 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_tracex<TL>: the cooperative backtrack, 64 / TL alignments per wave, TL lanes each, ONE memory round trip per round, no
-// LDS (it runs beside the forward kernel of another chunk, which fills a CU's LDS).  The walk of
-// sisd_alignment_engine.cpp:362-459 is a chain of dependent lookups; ~85 % of its moves are "diagonal through the first
-// in-edge".  Per round, for the current cell (gi, gj):
-//   * lane p of the group evaluates in-edge p of row gi completely -- the row behind it, its record, the diagonal cell
-//     (pr, gj-1) and the vertical cell (pr, gj); the last lane also fetches the horizontal cell (gi, gj-1).  Ballots then
-//     give the reference's decision exactly: first diagonal match in list order, else first vertical match in list order,
-//     else horizontal (rows whose in-edges sit in the overflow list loop over it before a vertical move is accepted);
-//   * at the same time lane t >= 1 speculates that the t moves before it are all "diagonal through the first in-edge":
-//     its row is the t-th link of that chain (VcDp::anc of row gi, carried with the row's record), and it fetches the
-//     diagonal cell behind ITS first in-edge together with that row's record and chain, plus the two cells that settle a
-//     row with a single in-edge (vertical through it, horizontal);
-//   * all loads of a round are issued together; afterwards the longest prefix of confirmed speculations is accepted (each
-//     is exactly the reference's first test at that cell), and if the first unconfirmed position lies on a row with one
-//     in-edge its vertical / horizontal move is taken in the same round; otherwise the general move decided above.
-// Compared with k_tracew (two round trips per round, a per-alignment table in LDS, eight serial table lookups): 45 % fewer
-// wave instructions at TL = 8 (PMC), no LDS, no table-building prologue -- and measured no faster (the
-// backtrack is bound by its scattered 128-byte reads), which is why k_tracew remains the default.
-// ------------------------------------------------------------------------------------------------
-#define VC_TX_SPECW 8
-
-// One stored cell, branch-free: the loads are issued for every lane (idle lanes read dword 0 of a matrix), the special
-// rows / columns are patched in afterwards, so that all loads of a round are in flight together.
-template <bool PACKED>
-struct VcCellRd {
-    const uint32_t* hm32;
-    uint32_t cpl, cmagic, rowdw, nds;          // rowdw: dwords per stored row
-    uint32_t ash, aidx;                        // packed rows: dword index and shift of the lane's int16 anchor
-    __device__ __forceinline__ void issue(uint32_t r, uint32_t col, uint32_t& w1, uint32_t& w2, uint32_t& cc) const {
-        const uint32_t r1 = r ? r - 1 : 0u, ci = col ? col - 1 : 0u;
-        const uint32_t lc = __umulhi(ci, cmagic);
-        cc = ci - lc * cpl;
-        if (PACKED) {
-            const uint32_t o = r1 * rowdw + lc * nds;
-            w1 = hm32[o + (cc >> 2)];
-            w2 = hm32[o + aidx];
-        } else {
-            w1 = hm32[r1 * rowdw + (cc >> 1) * 64 + lc];
-            w2 = 0;
-        }
-    }
-    __device__ __forceinline__ int decode(uint32_t w1, uint32_t w2, uint32_t cc) const {
-        if (PACKED) {
-            const uint32_t an = (w2 >> ash) & 0xFFFFu;
-            const uint32_t b = (w1 >> ((cc & 3) * 8)) & 0xFFu;
-            return (int)(short)an + (int)((b - an) & 0xFFu);
-        }
-        return (int)(short)(w1 >> ((cc & 1) * 16));
-    }
-};
-
-template <int TL, bool PACKED>
-__device__ __forceinline__ void vc_tracex_body(const VcTraceArgs& a, bool valid, uint32_t job, uint32_t slot, uint32_t k, uint32_t type) {
-    const int lane = vc_lane();
-    const uint32_t grp = (uint32_t)lane / TL, gl = (uint32_t)lane % TL, gbase = grp * TL;
-    const uint32_t w = a.w0 + slot;
-    const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
-    uint32_t* out = a.pairs + pj * a.PC;
-    const uint32_t end = valid ? a.job_end[job] : 0u;
-    const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
-    const bool nw = type == 1;
-    const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
-    const uint32_t sq = a.b.win_seq_off[w] + (valid ? k : 0);
-    const uint64_t so = a.b.seq_off[sq];
-    const uint8_t* seq = a.b.bases + so;
-    const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
-    const uint4* recs = a.dp.rec + nb;
-    const uint4* ancs = a.dp.anc + nb;
-    const uint16_t* ovfp = a.dp.ovf + eb;
-    VcCellRd<PACKED> rd;
-    {
-        const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so));
-        rd.hm32 = a.hmat + (uint64_t)(valid ? job : 0) * a.hstride;
-        rd.cpl = cpl ? cpl : 4u; rd.cmagic = vc_magic(rd.cpl);
-        rd.nds = (uint32_t)vc_nds((int)rd.cpl);
-        rd.rowdw = PACKED ? rd.nds * 64 : (rd.cpl / 2) * 64;
-        rd.aidx = rd.cpl >> 2; rd.ash = (rd.cpl & 2) * 8;
-    }
-    const uint4 zero4 = make_uint4(0, 0, 0, 0), none4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    auto gmask = [&](unsigned long long mm) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(mm >> gbase) & ((1u << TL) - 1u); };
-    auto bcast = [&](uint32_t v, uint32_t l) __attribute__((always_inline)) -> uint32_t { return (uint32_t)__shfl((int)v, (int)l, 64); };
-    auto bcast4 = [&](const uint4& v, uint32_t l) __attribute__((always_inline)) -> uint4 { return make_uint4(bcast(v.x, l), bcast(v.y, l), bcast(v.z, l), bcast(v.w, l)); };
-    // element e (0..7) of a chain: the row e+1 links behind
-    auto anc_at = [&](const uint4& c, uint32_t e) __attribute__((always_inline)) -> uint32_t {
-        const uint32_t lo = (e & 2) ? c.y : c.x, hi = (e & 2) ? c.w : c.z;
-        const uint32_t d = (e & 4) ? hi : lo;
-        return (e & 1) ? (d >> 16) : (d & 0xFFFFu);
-    };
-    // a cell including the virtual row 0 and column 0 (setup and rare paths only: it branches)
-    auto Tslow = [&](uint32_t r, uint32_t col) -> int {
-        if (r == 0) return nw ? 0 : -(int)col * g;
-        if (col == 0) return nw ? (int)c0[r - 1] : 0;
-        uint32_t w1, w2, cc;
-        rd.issue(r, col, w1, w2, cc);
-        return rd.decode(w1, w2, cc);
-    };
-
-    bool walking = valid && end != 0;
-    uint32_t gi = end >> 16, gj = end & 0xFFFF, gnout = 0, nspec_ok = 0, nrounds = 0;
-    bool govf = false, gbroken = false;
-    int gT = 0;
-    uint4 grec = zero4, ganc = none4;
-    if (walking) {
-        gT = Tslow(gi, gj);
-        if (gi) { grec = recs[gi - 1]; ganc = ancs[gi - 1]; }
-    }
-    const int mg = m - g, ng = n - g;
-    for (;;) {
-        if (walking && (nw ? (gi == 0 && gj == 0) : (gT == -(int)gj * g))) walking = false;
-        if (!__any(walking)) break;
-        nrounds += (walking && gl == 0) ? 1u : 0u;
-        const bool rowovf = ((grec.x >> 8) & VC_RF_OVF) != 0;                      // in-edges in VcDp::ovf: the loop further down
-        const bool slow = walking && gi != 0 && rowovf;
-        const uint32_t np = (walking && gi != 0 && !rowovf) ? ((grec.x >> 16) & 0xFF) : 0u;     // <= VC_INLINE_PRED < TL
-        const uint32_t code_i = grec.x & 0xFF;
-        // ---- in-edge p = gl of row gi: the row behind it
-        const bool actg = gl < np;
-        const uint32_t wsel = gl < 2 ? grec.y : (gl < 4 ? grec.z : grec.w);
-        const uint32_t pr = actg ? gi - ((gl & 1) ? (wsel >> 16) : (wsel & 0xFFFF)) : 0u;
-        // ---- speculated positions: lane t at (row t links down the first-in-edge chain, gj - t), moving on to row t + 1 links down
-        const bool specable = np != 0 && gj > gl && gl < VC_TX_SPECW;
-        const uint32_t a_me = anc_at(ganc, gl ? gl - 1 : 0u), a_nx = anc_at(ganc, gl < 8 ? gl : 7u);
-        const uint32_t my_i = gl ? a_me : gi;
-        const uint32_t my_in = gl ? a_nx : pr;                                     // lane 0: in-edge 0 itself
-        const bool ok = specable && (gl == 0 || (a_me != 0 && a_me != 0xFFFFu && a_nx != 0xFFFFu));
-        const uint32_t nspec = (uint32_t)__ffs((int)~gmask(__ballot(ok))) - 1;    // leading ones
-        const bool lb = gl < nspec;
-        const bool sl_ = lb && gl != 0;                                            // lanes with a speculated position of their own
-        const uint32_t jk = gj - gl;                                               // column of position gl (lb lanes)
-        // ---- all loads of the round, unconditional (idle requests read row 0 / column 0 addresses and are patched below)
-        //   V: vertical candidate (pr, gj); the last lane of the group reads the horizontal cell (gi, gj - 1) here
-        //   D: diagonal candidate (pr, gj - 1)
-        //   S: speculated diagonal (my_in, jk - 1)   SV: vertical at my position (my_in, jk)   SH: horizontal there (my_i, jk - 1)
-        const bool hl = gl == TL - 1;
-        const uint32_t vr = hl ? (walking ? gi : 0u) : pr, vc = hl ? (gj ? gj - 1 : 0u) : (actg ? gj : 0u);
-        const uint32_t dr = pr, dc = (actg && gj) ? gj - 1 : 0u;
-        const uint32_t sr = sl_ ? my_in : 0u, sc = sl_ ? jk - 1 : 0u;
-        const uint32_t svc = sl_ ? jk : 0u;
-        const uint32_t hr = sl_ ? my_i : 0u;
-        uint32_t v1, v2, vcc, d1w, d2w, dcc, s1, s2, scc, sv1, sv2, svcc, sh1, sh2, shcc;
-        rd.issue(vr, vc, v1, v2, vcc);
-        rd.issue(dr, dc, d1w, d2w, dcc);
-        rd.issue(sr, sc, s1, s2, scc);
-#ifndef VC_TX_NOLOCAL
-        rd.issue(sr, svc, sv1, sv2, svcc);
-        rd.issue(hr, sc, sh1, sh2, shcc);
-#else
-        sv1 = sv2 = svcc = sh1 = sh2 = shcc = 0;
-#endif
-        const uint32_t ri1 = pr ? pr - 1 : 0u, ri2 = sr ? sr - 1 : 0u;
-        const uint4 rr_l = recs[ri1], ra_l = ancs[ri1];
-        const uint4 rn_l = recs[ri2], na_l = ancs[ri2];
-        const uint32_t bs_l = seq[sl_ ? jk - 1 : 0u];
-        const uint32_t bs0 = seq[(walking && gj) ? gj - 1 : 0u];
-        int vcell = rd.decode(v1, v2, vcc), dcell = rd.decode(d1w, d2w, dcc), tv = rd.decode(s1, s2, scc);
-        int svcell = rd.decode(sv1, sv2, svcc), shcell = rd.decode(sh1, sh2, shcc);
-        // column 0 of a real row is not in the matrix (NW: VcFwdArgs::c0, SW: 0): rare, patched with one more load
-        const bool vz = vr != 0 && vc == 0 && (hl ? (walking && gj == 1) : actg);   // horizontal into column 0 / vertical along column 0
-        const bool dz = dr != 0 && dc == 0 && actg && gj == 1;
-        const bool sz = sr != 0 && sc == 0 && sl_, hz_ = hr != 0 && sc == 0 && sl_; // S / SH (same column) at column 0
-        if (__any(vz || dz || sz || hz_)) {
-            const int cv = (nw && vz) ? (int)c0[vr - 1] : 0, cd = (nw && dz) ? (int)c0[dr - 1] : 0, cs = (nw && sz) ? (int)c0[sr - 1] : 0;
-            const int ch = (nw && hz_) ? (int)c0[hr - 1] : 0;
-            if (vz) vcell = cv;
-            if (dz) dcell = cd;
-            if (sz) tv = cs;
-            if (hz_) shcell = ch;
-        }
-        if (vr == 0) vcell = nw ? 0 : -(int)vc * g;                                // the virtual row 0
-        if (dr == 0) dcell = nw ? 0 : -(int)dc * g;
-        if (sr == 0) { tv = nw ? 0 : -(int)sc * g; svcell = nw ? 0 : -(int)svc * g; }
-        uint4 rr = pr ? rr_l : zero4, ranc = pr ? ra_l : none4;
-        uint4 rnext = sr ? rn_l : zero4, nanc = sr ? na_l : none4;
-        uint32_t bs = bs_l;
-        if (gl == 0) { bs = bs0; rnext = rr; nanc = ranc; tv = dcell; }            // position 0's speculated move IS the diagonal through in-edge 0
-        const int hzv = (int)bcast((uint32_t)vcell, gbase + TL - 1);
-        // ---- the confirmed prefix
-        const uint32_t sh_x = (uint32_t)vc_row_shr1((int)rnext.x, 0);              // record of MY position's row: the left lane fetched it (all lanes take part)
-        const int sh_tv = vc_row_shr1(tv, 0);
-        const uint32_t codek = gl ? (sh_x & 0xFFu) : code_i;                       // code of position gl's row
-        const int tprev = gl ? sh_tv : gT;                                         // T at position gl
-        const bool stop_here = !nw && gl != 0 && tprev == -(int)jk * g;            // SW: the walk ends at this position
-        const bool okc = lb && !stop_here && tprev == tv + ((bs == codek) ? mg : ng);
-        const uint32_t f = (uint32_t)__ffs((int)~gmask(__ballot(okc))) - 1;
-        // a row with a single in-edge at the first unconfirmed position: vertical through that in-edge, else horizontal
-#ifdef VC_TX_NOLOCAL
-        const bool single = false;
-#else
-        const bool single = sl_ && gl == f && !stop_here && ((sh_x >> 8) & VC_RF_OVF) == 0 && ((sh_x >> 16) & 0xFF) == 1;
-#endif
-        const bool locv = single && tprev == svcell + g, loch = single && !locv && tprev == shcell;
-        const uint32_t lv = gmask(__ballot(locv)), lh = gmask(__ballot(loch));
-        // ---- the general decision at (gi, gj), in the reference's order
-        const int sc0 = (bs0 == code_i) ? mg : ng;
-        const uint32_t dm = gmask(__ballot(actg && gj != 0 && gT == dcell + sc0));
-        const uint32_t vm = gmask(__ballot(actg && !hl && gT == vcell + g));
-        const bool hmatch = gj != 0 && gT == hzv;
-        // 1 confirmed prefix, 2 diagonal, 3 vertical, 4 horizontal, 5 no move explains the cell, 6 prefix + vertical, 7 prefix + horizontal
-        uint32_t kind = 0, srcl = 0;
-        if (walking) {
-            if (f) { kind = lv ? 6u : (lh ? 7u : 1u); srcl = lv ? f : f - 1; }
-            else if (dm) { kind = 2; srcl = (uint32_t)__ffs((int)dm) - 1; }
-            else if (vm) { kind = 3; srcl = (uint32_t)__ffs((int)vm) - 1; }
-            else if (hmatch) kind = 4;
-            else kind = 5;
-        }
-        // what the group continues from, offered by every lane for its own candidate: row, record + chain, T
-        uint32_t xi = 0; int xT = 0; uint4 xrec = zero4, xanc = none4;
-        if (kind == 1 || kind == 7) { xi = my_in; xT = tv; xrec = rnext; xanc = nanc; }       // lane f-1: the row it moved on to (7: T comes from lane f)
-        else if (kind == 6) { xi = my_in; xT = svcell; xrec = rnext; xanc = nanc; }           // lane f: the row behind its in-edge, same column
-        else if (kind == 2) { xi = pr; xT = dcell; xrec = rr; xanc = ranc; }
-        else if (kind == 3) { xi = pr; xT = vcell; xrec = rr; xanc = ranc; }
-        // rows whose in-edges live in the overflow list (more than VC_INLINE_PRED): TL of them per pass; a diagonal match
-        // anywhere beats every vertical one, the first vertical match beats the horizontal move
-        if (__any(slow)) {
-            const uint32_t npf = slow ? grec.z : 0u;
-            bool have_v = false, found_d = false;
-            for (uint32_t base = 0; __any(slow && !found_d && base < npf); base += TL) {
-                const uint32_t p = base + gl;
-                const bool act2 = slow && !found_d && p < npf;
-                uint32_t pr2 = 0; uint4 rr2 = zero4, ra2 = none4; int d2 = 0, v2c = 0;
-                if (act2) {
-                    pr2 = gi - (uint32_t)ovfp[grec.y + p];
-                    if (pr2) { rr2 = recs[pr2 - 1]; ra2 = ancs[pr2 - 1]; }
-                    v2c = Tslow(pr2, gj);
-                    if (gj != 0) d2 = Tslow(pr2, gj - 1);
-                }
-                const uint32_t dm2 = gmask(__ballot(act2 && gj != 0 && gT == d2 + sc0));
-                const uint32_t vm2 = gmask(__ballot(act2 && gT == v2c + g));
-                if (slow && !found_d) {
-                    if (dm2) {
-                        found_d = true; kind = 2; srcl = (uint32_t)__ffs((int)dm2) - 1;
-                        if (gl == srcl) { xi = pr2; xT = d2; xrec = rr2; xanc = ra2; }
-                    } else if (vm2 && !have_v) {
-                        have_v = true; kind = 3; srcl = (uint32_t)__ffs((int)vm2) - 1;
-                        if (gl == srcl) { xi = pr2; xT = v2c; xrec = rr2; xanc = ra2; }
-                    }
-                }
-            }
-        }
-        if (kind == 5) { gbroken = true; walking = false; kind = 0; }
-        const uint32_t nmov = (kind == 1 ? f : (kind >= 6 ? f + 1 : (kind != 0 ? 1u : 0u)));
-        if (nmov && gnout + nmov > a.PC) { govf = true; walking = false; kind = 0; }
-        const uint32_t src = gbase + srcl;
-        const uint32_t b_i = bcast(xi, src);
-        const int b_T = (int)bcast((uint32_t)xT, src);
-        const int b_hT = (int)bcast((uint32_t)shcell, gbase + f);                 // kind 7: the horizontal cell lane f read
-        const uint4 b_rec = bcast4(xrec, src), b_anc = bcast4(xanc, src);
-        if (kind == 1 || kind >= 6) {
-            if (gl < f) out[gnout + gl] = (my_i << 16) | jk;
-            if (kind == 6 && gl == f) out[gnout + f] = my_i << 16;                 // vertical: row only
-            if (kind == 7 && gl == f) out[gnout + f] = jk;                         // horizontal: column only
-            gnout += nmov; nspec_ok += f;
-            gi = b_i; gT = kind == 7 ? b_hT : b_T; grec = b_rec; ganc = b_anc;
-            gj -= kind == 6 ? f : nmov;
-        } else if (kind == 2) {
-            if (gl == 0) out[gnout] = (gi << 16) | gj;
-            gnout++;
-            gi = b_i; gj -= 1; gT = b_T; grec = b_rec; ganc = b_anc;
-        } else if (kind == 3) {
-            if (gl == 0) out[gnout] = gi << 16;
-            gnout++;
-            gi = b_i; gT = b_T; grec = b_rec; ganc = b_anc;
-        } else if (kind == 4) {
-            if (gl == 0) out[gnout] = gj;
-            gnout++;
-            gj -= 1; gT = hzv;
-        }
-    }
-    if (valid && gl == 0) {
-        if (gbroken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, gi); gnout = 0; }
-        if (govf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, gnout); gnout = 0; }
-        a.npairs[pj] = gnout;
-    }
-    {   // statistics: summed over the wave first, then one of VC_STAT_SLOTS counter sets
-        uint32_t s0 = (valid && gl == 0) ? gnout : 0u, s1x = (valid && gl == 0) ? nspec_ok : 0u, s2x = (valid && gl == 0) ? nrounds : 0u;
-#pragma unroll
-        for (int o = TL; o < 64; o <<= 1) { s0 += (uint32_t)__shfl_xor((int)s0, o, 64); s1x += (uint32_t)__shfl_xor((int)s1x, o, 64); s2x += (uint32_t)__shfl_xor((int)s2x, o, 64); }
-        if (lane == 0) {
-            unsigned long long* st = vc_stat_slot(a.stat);
-            atomicAdd(st + 4, (unsigned long long)s0); atomicAdd(st + 5, (unsigned long long)s1x); atomicAdd(st + 6, (unsigned long long)s2x);
-        }
-    }
-}
-
-template <int TL>
-__global__ __launch_bounds__(64) void k_tracex(VcTraceArgs a) {
-    VC_LATENCY_KERNEL_PRIO();
-    constexpr uint32_t TG = 64 / TL;
-    const uint32_t grp = (uint32_t)vc_lane() / TL;
-    const uint32_t njobs = a.nslots * a.group;
-    const uint32_t job = blockIdx.x * TG + grp;
-    bool valid = job < njobs;
-    const uint32_t slot = valid ? job / a.group : 0, k = valid ? a.k0 + job % a.group : 0;
-    const uint32_t w = a.w0 + slot;
-    const uint32_t type = valid ? (uint32_t)a.job_type[job] : 255u;
-    valid = valid && type < 2;                                // 255: nothing to walk; 2, 3: k_fwd_wide's, walked by k_trace
-    if (valid && a.b.status[w] != VC_WIN_OK) valid = false;
-    if (!__any(valid)) return;
-    // stored form of the alignment's matrix (vc_row_packed): one form per wave almost always; a mixed wave walks twice
-    bool packed = false;
-    if (valid) {
-        const uint32_t sq = a.b.win_seq_off[w] + k;
-        const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - a.b.seq_off[sq]));
-        const bool nw = type == 1;
-        packed = vc_row_packed(nw ? a.m : a.sm, nw ? a.n : a.sn, nw ? a.g : a.sg, (int)cpl);
-    }
-    if (__any(valid && packed)) vc_tracex_body<TL, true>(a, valid && packed, job, slot, k, type);
-    if (__any(valid && !packed)) vc_tracex_body<TL, false>(a, valid && !packed, job, slot, k, type);
-}
-
-// ------------------------------------------------------------------------------------------------
 // k_addaln: Graph::AddAlignment (graph.cpp:182-299) for the layer just aligned, wave-parallel.
 // The reference walks the alignment serially; every decision it takes depends only on the graph
 // BEFORE the call (a path visits a node, and an aligned group, at most once), so node/edge ids are
@@ -2412,6 +2086,8 @@ struct VcAddArgs {
     uint32_t w0, nslots, NC, EC, layer;
     const uint32_t* pairs; const uint32_t* npairs; uint32_t PC;
     uint16_t* scratch;            // [CW * (4*PC + NC)]
+    uint32_t ring;                // rows k_fwd keeps in LDS (the row records of the NEXT layer are made at the end of this kernel)
+    int make_rows;                // 0: leave the row records of THIS layer in place (vc_debug_stop_after looks at them)
 };
 
 __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
@@ -2530,6 +2206,7 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
         }
         a.g.al_cnt[nb + curr] = (uint8_t)mycnt;
         a.g.visits[nb + curr] = 0;
+        a.g.nrec[nb + curr] = make_uint4((uint32_t)a.b.bases[so + col - 1], 0u, 0u, 0u);
     }
     if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 7, 0); return; }
     __syncthreads();      // pass B's stores are complete before pass C touches the same nodes
@@ -2593,6 +2270,18 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
                 if (il == VC_NONE16) a.g.in_first[nb + curr] = (uint16_t)e;
                 else a.g.e_tn[eb + il] = (a.g.e_tn[eb + il] & 0xFFFF) | (e << 16);
                 a.g.in_last[nb + curr] = (uint16_t)e;
+                // node record: the tail joins the head's inline predecessor list (a path meets a node once, so a node gains
+                // at most one in-edge per call and no two lanes touch the same record)
+                uint4 nr = a.g.nrec[nb + curr];
+                const uint32_t k = nr.x >> 16;
+                if (k == 0) nr.y = prev;
+                else if (k == 1) nr.y |= prev << 16;
+                else if (k == 2) nr.z = prev;
+                else if (k == 3) nr.z |= prev << 16;
+                else if (k == 4) nr.w = prev;
+                else if (k == 5) nr.w |= prev << 16;
+                nr.x += 1u << 16;
+                a.g.nrec[nb + curr] = nr;
             }
         }
         enew += tot;
@@ -2645,6 +2334,8 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
         a.g.pos[nb + N0 + t] = (uint16_t)np_;
     }
     if (lane == 0) { a.g.n_nodes[slot] = N0 + nnew; a.g.n_edges[slot] = E0 + enew; }
+    __syncthreads();
+    if (a.make_rows) vc_rows_full(a.b, a.g, a.dp, slot, w, a.NC, a.EC, (int)a.layer + 1, a.ring, N0 + nnew);   // the next layer's rows (full-span layers)
 }
 
 // ------------------------------------------------------------------------------------------------
