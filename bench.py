@@ -177,9 +177,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=100000, help="distinct windows per GPU per step (BASELINE config C: 100 000)")
-    ap.add_argument("--layers", type=int, default=64)
-    ap.add_argument("--length", type=int, default=500)
+    ap.add_argument("--config", default=None, choices=["C", "D", "E", "W"],
+                    help="BASELINE.json configuration: C = 100 000 windows of 500 bp x 64 reads on one GPU (default at --gpus 1..7); D = 1 M such windows "
+                         "over 8 GPUs (125 000 per rank; default at --gpus 8); E = 50 000 ONT windows of 1 kb x 128 reads over the ranks; "
+                         "W = 3 kb x 12 reads, the int32 wide-column kernel (k_fwd_wide)")
+    ap.add_argument("--windows", type=int, default=0, help="distinct windows per GPU per step (0: what --config says)")
+    ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--length", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -199,6 +203,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    # the BASELINE.json configuration this run measures (configs[2] / [3] / [4]); explicit --windows / --layers / --length override it
+    cfg_name = a.config or ("D" if world == 8 else "C")
+    profile = capi.PACBIO
+    if cfg_name == "E":
+        dflt = (max(1, 50000 // world), 128, 1000); profile = capi.ONT
+    elif cfg_name == "W":
+        dflt = (2048, 12, 3000)
+    elif cfg_name == "D":
+        dflt = (1000000 // world, 64, 500)
+    else:
+        dflt = (100000, 64, 500)
+    a.windows, a.layers, a.length = a.windows or dflt[0], a.layers or dflt[1], a.length or dflt[2]
     if os.environ.get("VC_BENCH_STUB") == "1":
         return stub_main(a, world)
     rank = int(os.environ.get("RANK", "0"))
@@ -213,7 +229,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    cfg = capi.synth_cfg(1002, a.length, a.layers, profile=capi.PACBIO)
+    cfg = capi.synth_cfg(1002, a.length, a.layers, profile=profile)
     batch = capi.synth_batch(cfg, rank * a.windows, a.windows)
     ctx = HipContext(device=local, profile=2, chunk_windows=a.chunk, n_streams=a.streams)   # profile 2: HIP events around k_fwd only
     ctx.submit(batch)                                   # H2D: inputs resident before the timed region
@@ -223,7 +239,10 @@ def main():
     d_status = torch.zeros(n, dtype=torch.uint8, device=dev)
     d_cons = torch.zeros(n * (a.length + 256), dtype=torch.uint8, device=dev)
 
+    times = {"compute_s": 0.0, "gather_s": 0.0}
+
     def step():
+        t_a = time.perf_counter()
         ctx.run()
         ctx.sync()
         rc = ctx.lib.vc_collect_device(ctx.h, d_cons.data_ptr(), d_cons.numel(), d_off.data_ptr(), d_status.data_ptr())
@@ -231,7 +250,13 @@ def main():
             raise RuntimeError(ctx.lib.vc_last_error(ctx.h).decode())
         lens = d_off[1:] - d_off[:-1]
         total = int(d_off[-1].item())
-        return gather_consensus(d_cons[:total], lens, dst=0, force=force_dist)
+        t_b = time.perf_counter()
+        out = gather_consensus(d_cons[:total], lens, dst=0, force=force_dist)
+        if world > 1 or force_dist:
+            torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        times["compute_s"] += t_b - t_a; times["gather_s"] += t_c - t_b
+        return out
 
     def fence():
         if world > 1 or force_dist:
@@ -240,6 +265,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    times["compute_s"] = times["gather_s"] = 0.0
     fence()
     t0 = time.perf_counter()
     fwd_ms, fwd_busy_ms, fwd_launches, cells, rows = 0.0, 0.0, 0, 0, 0
@@ -252,8 +278,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # every rank's own rate (its windows over its own compute time) and its share of the gather, for the scaling record
+        mine = torch.tensor([a.windows * a.steps / max(times["compute_s"], 1e-9), times["gather_s"] / a.steps * 1e3], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu().numpy()
     dt = float(t.item())
 
     out_line = None
@@ -300,9 +332,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": f"synthetic windows {a.length} bp x {a.layers} reads, PacBio 15% error, FASTQ weights, haplotype mode "
-                                   f"d=0.2 s=0.2 k=3; {a.windows} distinct windows per GPU per step (BASELINE config C"
-                                   f"{'; x' + str(world) + ' GPUs = config D shape' if world > 1 else ''})",
+            "config": {"workload": f"synthetic windows {a.length} bp x {a.layers} reads, {'ONT' if profile == capi.ONT else 'PacBio 15% error'}, FASTQ weights, "
+                                   f"haplotype mode d=0.2 s=0.2 k=3; {a.windows} distinct windows per GPU per step x {world} GPU(s) = "
+                                   f"{a.windows * world} windows per step (BASELINE config {cfg_name})",
+                       "baseline_config": cfg_name, "windows_per_step": a.windows * world,
                        "windows_per_gpu_per_step": a.windows, "backbone_len": a.length, "reads_per_window": a.layers,
                        "chunk_windows": s["chunk_windows"], "streams": s["n_streams"], "max_nodes": s["max_nodes"], "max_edges": s["max_edges"]},
             "corrected_bases_per_s": bases * world / dt if world == 1 else bases / dt,
@@ -310,7 +343,13 @@ def main():
             "windows_not_ok": int((status > 1).sum()),
             "roofline": roof,
         }
-        if world == 1 and not a.no_extras:
+        if world > 1 or force_dist:
+            line["world_size"] = dist.get_world_size()           # as RCCL reports it
+            line["gather_ms"] = times["gather_s"] / a.steps * 1e3
+            if per_rank is not None:
+                line["per_rank_windows_per_s"] = {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max())}
+                line["per_rank_gather_ms"] = {"min": float(per_rank[:, 1].min()), "max": float(per_rank[:, 1].max())}
+        if world == 1 and not a.no_extras and cfg_name == "C":
             # separate pass with every kernel class bracketed by events: the breakdown, not part of `value`
             ctx.lib.vc_set_profile(ctx.h, 1)
             ctx.run(); ctx.sync()
@@ -319,7 +358,7 @@ def main():
             line["kernel_ms_note"] = "separate profiled pass (vc_params.profile = 1); sums exceed ms_per_step because chunk streams overlap"
             ctx.lib.vc_set_profile(ctx.h, 2)
     ctx_params = ctx.params
-    if rank == 0 and world == 1 and not a.no_extras and not a.ab:
+    if rank == 0 and world == 1 and not a.no_extras and not a.ab and cfg_name == "C":
         cons_np = cons_all.cpu().numpy()
         off = np.concatenate([[0], np.cumsum(lens_all.cpu().numpy())])
         ctx.close()                                     # its workspaces go back before the two e2e contexts plan theirs
@@ -330,7 +369,8 @@ def main():
                                      f"two contexts / two host threads alternating over batches of {E2E_BATCH} windows",
                        "identical_to_resident_run": all(cons_np[off[w]:off[w + 1]].tobytes() == cons_e2e[w] for w in range(0, n, 97))}
         line["configs"] = {"B": short_config(local, 1001, 500, 32, 10000, capi.PACBIO),
-                           "E": short_config(local, 1005, 1000, 128, 4096, capi.ONT)}
+                           "E": short_config(local, 1005, 1000, 128, 4096, capi.ONT),
+                           "W": short_config(local, 1007, 3000, 12, 1024, capi.PACBIO)}      # every alignment on k_fwd_wide (int32, column tiles)
     if rank == 0 and world == 1 and not a.no_cpu:
         cb, ref_out = cpu_baseline(batch, ctx_params, a.cpu_seconds)
         cons_np = cons_all.cpu().numpy()

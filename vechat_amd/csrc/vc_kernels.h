@@ -1170,7 +1170,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     uint4 myrec = make_uint4(0, 0, 0, 0), nextrec = make_uint4(0, 0, 0, 0);
     if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
     constexpr uint32_t rowdw = PACKED ? NDS * 64 : ND * 64;     // dwords per stored row
-    uint32_t voff = PACKED ? lane * NDS : lane;                 // my dword offset inside the stored matrix (one 32-bit add per row)
+    uint32_t voff = (PACKED ? lane * NDS : lane) * 4u;          // my BYTE offset inside the stored matrix (one 32-bit add per row; < 4 GB per job)
     const uint32_t lane4 = (uint32_t)lane * 4u;
 
     // a row of the LDS ring merged into the running maximum; column 0 of the last 64 rows lives in c0vec
@@ -1358,7 +1358,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
 
         // ---- keep the row: registers (acc), LDS ring, HBM
         c0prev = col0;
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(c0vec) : "s"(col0), "s"(ri));      // lane ri keeps this row's column 0
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(c0vec) : "s"(col0), "s"(ri) : "m0");      // lane ri keeps this row's column 0
         // one wave per workgroup: LDS operations of a wave retire in order, so no s_barrier (and no
         // vmcnt(0) drain of the H stores) is needed -- only keep the compiler from reordering
         __builtin_amdgcn_wave_barrier();
@@ -1370,7 +1370,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         if (PACKED) {
             uint32_t wv[NDS];
             vc_pack_row<ND, NDS>(acc, wv);
-            uint32_t* hr = hrow0 + voff;
+            uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + voff);
             if (NDS == 2) *reinterpret_cast<uint2*>(hr) = make_uint2(wv[0], wv[1]);
             else if (NDS == 4) *reinterpret_cast<uint4*>(hr) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
             else if (NDS == 3) { struct __attribute__((packed, aligned(4))) u3 { uint32_t a, b, c; }; *reinterpret_cast<u3*>(hr) = u3{wv[0], wv[1], wv[2]}; }
@@ -1381,11 +1381,11 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         } else {
             // full 256-B rows on purpose: masking the lanes past the sequence end was measured SLOWER
             // (partial cache-line writes), although it would save 20 % of the bytes
-            uint32_t* hr = hrow0 + voff;
+            uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + voff);
 #pragma unroll
             for (int q = 0; q < ND; ++q) hr[q * 64] = acc[q];
         }
-        voff += rowdw;
+        voff += rowdw * 4u;
         __builtin_amdgcn_wave_barrier();
       }
       if ((uint32_t)lane < cnt) c0p_out[i0 - 1 + lane] = (int16_t)c0vec;   // column 0 of the block just completed
