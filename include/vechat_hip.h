@@ -101,6 +101,8 @@ typedef struct vc_stats {
     uint32_t max_nodes, max_edges, chunk_windows, n_streams;   /* what the context actually used */
     double   busy_ms[16];    /* per class: time during which at least one launch of it was running (the chunk streams overlap,  */
                              /* so a class's launches overlap each other and `ms` counts such time once per launch)             */
+    uint64_t band_redo;      /* alignments whose backtrack left the stored band and were run again with whole rows              */
+    uint64_t device_bytes;   /* device memory this context holds (workspaces + batch buffers)                                   */
 } vc_stats;
 
 /* -- lifecycle: stands in for createCUDABatch / ~CUDABatchProcessor (cudabatch.hpp:26,33) ------ */

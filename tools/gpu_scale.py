@@ -23,7 +23,7 @@ for rep in range(2):
     for k in ("cells", "dp_rows", "trace_steps"):
         acc[k] += s[k]
     km = {k: round(v['ms'], 1) for k, v in s['kernels'].items()}
-    print(f"rep {rep}: {n/(t1-t0):.1f} win/s ({t1-t0:.3f}s) cells={s['cells']:.3e} GCUPS={s['cells']/(t1-t0)/1e9:.1f} rows={s['dp_rows']:.3e} far={s['far_row_reads']} trace steps/spec/rounds={s['trace_steps']}/{s['trace_spec']}/{s['trace_rounds']} NC={s['max_nodes']} EC={s['max_edges']} CW={s['chunk_windows']}x{s['n_streams']} ms={km}", flush=True)
+    print(f"rep {rep}: {n/(t1-t0):.1f} win/s ({t1-t0:.3f}s) cells={s['cells']:.3e} GCUPS={s['cells']/(t1-t0)/1e9:.1f} rows={s['dp_rows']:.3e} far={s['far_row_reads']} redo={s['band_redo']} trace steps/spec/rounds={s['trace_steps']}/{s['trace_spec']}/{s['trace_rounds']} NC={s['max_nodes']} EC={s['max_edges']} CW={s['chunk_windows']}x{s['n_streams']} ms={km}", flush=True)
 cons, status = ctx.collect()
 import collections
 print("status histogram", collections.Counter(int(x) for x in status), "errinfo sample", [e for e in ctx.errinfo() if e != (0, 0)][:5])

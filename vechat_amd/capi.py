@@ -63,6 +63,7 @@ class VcStats(C.Structure):
         ("names", (C.c_char * 24) * 16),
         ("max_nodes", C.c_uint32), ("max_edges", C.c_uint32), ("chunk_windows", C.c_uint32), ("n_streams", C.c_uint32),
         ("busy_ms", C.c_double * 16),
+        ("band_redo", C.c_uint64), ("device_bytes", C.c_uint64),
     ]
 
 

@@ -39,7 +39,16 @@ const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace"
 #ifndef VC_RING
 #define VC_RING 8
 #endif
-constexpr int kRing = VC_RING;      // DP rows kept in LDS per alignment (k_topo / k_rows mark rows needed from farther away)
+constexpr int kRing = VC_RING;      // build phase: DP rows kept in LDS per alignment (the row builders mark rows needed from farther away)
+#ifndef VC_RING_PRUNED
+#define VC_RING_PRUNED 4
+#endif
+#ifndef VC_KEPT
+#define VC_KEPT 6
+#endif
+constexpr int kKept = VC_KEPT;      // build phase: slots of the kept-row ring (0: plain ring of kRing rows); see vc_frec_kept
+constexpr int kRingPruned = VC_RING_PRUNED;   // re-alignment rounds and the final alignment: a pruned graph is nearly a chain, four rows hold
+                                              // its non-adjacent predecessors, and the smaller ring lets a fifth / sixth wave onto each SIMD
 constexpr int kMaxStreams = 8;
 constexpr uint32_t kTraceTabRows = 8188;           // rows covered by k_tracew's first-in-edge table (4 tables x 2 B x 8192 = 64 KB); later rows are walked without speculation
 constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may ask for (160 KB per CU minus room for static __shared__)
@@ -57,6 +66,8 @@ struct Work {
     VcDp dp{};
     int* d_wmat = nullptr; int* d_c0w = nullptr;         // k_fwd_wide: [jobs_cap * NC * wcols] tilted int32 scores, [jobs_cap * NC] column 0
     uint32_t* d_hmat = nullptr; int16_t* d_c0 = nullptr; uint8_t* d_resolve_ws = nullptr;
+    uint32_t* d_bmat = nullptr; uint32_t* d_band_par = nullptr;     // banded matrix store: [hmat_dwords / 4] band rows, [jobs_cap * 2] band of a job
+    uint32_t* d_redo_list = nullptr; uint32_t* d_redo_n = nullptr;  // jobs whose backtrack left the band (re-run with whole rows)
     uint8_t* d_big_ws = nullptr;        // [CW * big_ws_stride] graph images that do not fit the LDS (k_topo / k_prune_lcc / k_consensus)
     uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
     uint16_t* d_tie_rows = nullptr; uint32_t* d_tie_cnt = nullptr; uint32_t* d_tie_list = nullptr; uint32_t* d_tie_n = nullptr;
@@ -100,6 +111,8 @@ struct vc_ctx {
     uint32_t* d_lut_w = nullptr; double* d_lut_d = nullptr;
     unsigned long long* d_stat = nullptr;   // [VC_STAT_SLOTS][8] cells, rows, -, far-row reads, trace steps, speculated steps, rounds, -
 
+    bool band = false;                   // banded matrix store (vc_band_start): packed rows, row builders that mark the rows read back, cooperative backtrack
+    uint32_t kept = 0;                   // slots of the build phase's kept-row ring for this batch (0: plain ring); needs 15-bit row distances
     bool packed = false;                 // stored DP rows of this batch: byte-packed (both score sets within the byte bound at the widest class) or raw
     uint32_t wcols = 0;                  // != 0: some alignment may need k_fwd_wide; columns of its int32 matrices (multiple of 512)
     uint32_t MA = 4;                     // entries per aligned list: max(4, distinct bytes in the batch - 1), even
@@ -107,6 +120,8 @@ struct vc_ctx {
     uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, rgroup_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
     uint32_t big_ws_stride = 0;          // bytes per window of the HBM workspace for oversized graph images (0: all fit the LDS)
+    bool big_ws_topo = false;            // the workspace also backs k_topo's optimistic LDS image of the first pruned graphs
+    uint32_t max_backbone = 0;           // longest backbone of the batch
     std::vector<uint8_t> h_pre_status;   // per-window status decided at submit (outside the envelope), empty = none
     bool trace_wave = true;
     uint32_t dbg_stop_kind = 0, dbg_stop_index = 0;   // vc_debug_stop_after: leave the chunk's graphs as they are after that stage
@@ -230,6 +245,10 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, c->hmat_dwords / 4 + 64)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_band_par, (size_t)c->jobs_cap * 2)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_list, c->jobs_cap)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_n, 4)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_resolve_ws, (size_t)kResolveGrid * ((topo_lds_bytes(NC, c->EC, c->STK, c->MA) + 15u) & ~15u))) ||
         (c->big_ws_stride && (rc = dalloc(c, c->chunk_allocs, &wk->d_big_ws, (size_t)CW * c->big_ws_stride))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_c0, (size_t)c->jobs_cap * NC)) ||
@@ -324,8 +343,16 @@ void flush_events(vc_ctx* c) {
 
 template <int CA, int CB>
 void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs, bool packed) {
-    if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, kRing, true>), dim3(jobs), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_fwd<CA, CB, kRing, false>), dim3(jobs), dim3(64), 0, st, a);
+    if (a.mode == 0 && a.kept) {
+        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, (kKept ? kKept : 1), true, true>), dim3(jobs), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_fwd<CA, CB, (kKept ? kKept : 1), false, true>), dim3(jobs), dim3(64), 0, st, a);
+    } else if (a.mode == 0) {
+        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, kRing, true, false>), dim3(jobs), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_fwd<CA, CB, kRing, false, false>), dim3(jobs), dim3(64), 0, st, a);
+    } else {
+        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, kRingPruned, true, false>), dim3(jobs), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_fwd<CA, CB, kRingPruned, false, false>), dim3(jobs), dim3(64), 0, st, a);
+    }
 }
 
 // One launch when the batch's sequences fall into one width class or two adjacent ones (the usual case:
@@ -344,14 +371,20 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
     if (hi - lo == 1) {
         { Timer t(c, KC_FWD, st);
         switch (hi) {
+#ifndef VC_FAST_BUILD          // development builds (-DVC_FAST_BUILD) carry only the width classes of the benchmark
             case 1: launch_fwd_t<4, 6>(st, a, jobs, c->packed); break;
             case 2: launch_fwd_t<6, 8>(st, a, jobs, c->packed); break;
+#endif
             case 3: launch_fwd_t<8, 10>(st, a, jobs, c->packed); break;
+#ifndef VC_FAST_BUILD
             case 4: launch_fwd_t<10, 12>(st, a, jobs, c->packed); break;
             case 5: launch_fwd_t<12, 16>(st, a, jobs, c->packed); break;
             case 6: launch_fwd_t<16, 20>(st, a, jobs, c->packed); break;
             case 7: launch_fwd_t<20, 24>(st, a, jobs, c->packed); break;
             case 8: launch_fwd_t<24, 32>(st, a, jobs, c->packed); break;
+#else
+            default: return fail(c, VC_ERR_ARG, "development build: width classes 8 / 10 only");
+#endif
         }
         }
         wide();
@@ -360,15 +393,21 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
     for (int i = lo; i <= hi; ++i) {
         Timer t(c, KC_FWD, st);
         switch (opts[i]) {
+#ifndef VC_FAST_BUILD
             case 4:  launch_fwd_t<4, 4>(st, a, jobs, c->packed); break;
             case 6:  launch_fwd_t<6, 6>(st, a, jobs, c->packed); break;
+#endif
             case 8:  launch_fwd_t<8, 8>(st, a, jobs, c->packed); break;
             case 10: launch_fwd_t<10, 10>(st, a, jobs, c->packed); break;
+#ifndef VC_FAST_BUILD
             case 12: launch_fwd_t<12, 12>(st, a, jobs, c->packed); break;
             case 16: launch_fwd_t<16, 16>(st, a, jobs, c->packed); break;
             case 20: launch_fwd_t<20, 20>(st, a, jobs, c->packed); break;
             case 24: launch_fwd_t<24, 24>(st, a, jobs, c->packed); break;
             case 32: launch_fwd_t<32, 32>(st, a, jobs, c->packed); break;
+#else
+            default: return fail(c, VC_ERR_ARG, "development build: width classes 8 / 10 only");
+#endif
         }
         a.do_init = 0;
     }
@@ -395,7 +434,8 @@ struct Plan {
         fa.sm = c->prm.sw_match; fa.sn = c->prm.sw_mismatch; fa.sg = c->prm.sw_gap;
         fa.hmat = wk.d_hmat; fa.c0 = wk.d_c0;
         fa.job_end = wk.d_job_end; fa.job_type = wk.d_job_type; fa.tie_rows = wk.d_tie_rows; fa.tie_cnt = wk.d_tie_cnt; fa.tie_list = wk.d_tie_list; fa.tie_n = wk.d_tie_n;
-        fa.stat = c->d_stat; fa.wcols = c->wcols;
+        fa.stat = c->d_stat; fa.wcols = c->wcols; fa.kept = c->kept;
+        fa.bmat = wk.d_bmat; fa.band_par = wk.d_band_par; fa.band = c->band ? 1 : 0; fa.redo_list = nullptr; fa.redo_n = nullptr;
         return fa;
     }
     VcTraceArgs trace_args(const Work& wk) const {
@@ -404,7 +444,9 @@ struct Plan {
         ta.m = c->prm.match; ta.n = c->prm.mismatch; ta.g = c->prm.gap;
         ta.sm = c->prm.sw_match; ta.sn = c->prm.sw_mismatch; ta.sg = c->prm.sw_gap;
         ta.wmat = wk.d_wmat; ta.wstride = (uint64_t)NC * c->wcols; ta.wcols = c->wcols; ta.c0w = wk.d_c0w; ta.only_wide = 0;
-        ta.stat = c->d_stat; ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC; ta.packed = c->packed ? 1 : 0;
+        ta.stat = c->d_stat; ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC; ta.packed = c->packed ? 1 : 0; ta.kept = 0;
+        ta.bmat = wk.d_bmat; ta.band_par = wk.d_band_par; ta.band = c->band ? 1 : 0; ta.redo_list = nullptr; ta.redo_n = nullptr;
+        ta.redo_out = wk.d_redo_list; ta.redo_out_n = wk.d_redo_n;
         return ta;
     }
 
@@ -421,6 +463,18 @@ struct Plan {
         if (c->wcols) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((njobs + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); ta.only_wide = 0; }
     }
 
+    // banded store: the alignments whose backtrack needed a cell outside the band (a few per thousand) run once more with
+    // whole rows, and are walked from there; both launches find their jobs on the list the first backtrack left
+    int redo(Work& wk, VcFwdArgs fa, VcTraceArgs ta, uint32_t njobs, uint32_t max_rows) {
+        if (!c->band || fa.mode == 2) return VC_OK;
+        fa.redo_list = wk.d_redo_list; fa.redo_n = wk.d_redo_n; fa.band = 0;
+        int rc = launch_fwd(c, wk.stream, fa, njobs, nullptr);
+        if (rc) return rc;
+        ta.redo_list = wk.d_redo_list; ta.redo_n = wk.d_redo_n; ta.band = 0;
+        launch_trace(wk, ta, njobs, 1, max_rows);         // listed jobs are of any window: no shared first-in-edge table
+        return VC_OK;
+    }
+
     void begin(Work& wk, uint32_t w0, uint32_t ns) {
         wk.w0 = w0; wk.ns = ns; wk.cur = 0; wk.layers = 0; wk.nseq_max = 0; wk.active = true; wk.pruned_known = false;
         for (uint32_t w = w0; w < w0 + ns; ++w) {
@@ -430,7 +484,7 @@ struct Plan {
         }
         (void)hipMemsetAsync(wk.dp.nrows, 0, (size_t)ns * 4, wk.stream);      // skipped windows must not carry a stale height
         { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3(ns), dim3(64), 0, wk.stream, c->b, w0, ns); }
-        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), 0, wk.stream, c->b, wk.gr[0], wk.dp, w0, ns, NC, EC, (uint32_t)kRing); }
+        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), c->kept ? vc_kept_lds_bytes(NC) : 0, wk.stream, c->b, wk.gr[0], wk.dp, w0, ns, NC, EC, (uint32_t)kRing, c->kept); }
     }
 
     // one layer of the build loop (window.cpp:239-298) for every window of the chunk
@@ -440,13 +494,14 @@ struct Plan {
         // a partial-span layer aligns to a Subgraph
         if (c->h_layer_partial[j]) {
             Timer t(c, KC_ROWS, wk.stream);
-            const uint32_t sub_lds = 8 * ((NC + 63) / 64) + 2 * NC + ((NC + 15) & ~15u) + 4 * (NC / 32 + 1) + 64;
-            hipLaunchKernelGGL(k_rows_sub, dim3(ns), dim3(64), sub_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing, wk.d_submask);
+            const uint32_t sub_lds = std::max(8 * ((NC + 63) / 64) + 2 * NC + ((NC + 15) & ~15u) + 4 * (NC / 32 + 1) + 64, c->kept ? vc_kept_lds_bytes(NC) : 0u);
+            hipLaunchKernelGGL(k_rows_sub, dim3(ns), dim3(64), sub_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing, wk.d_submask, c->kept);
         }
         VcFwdArgs fa = fwd_args(wk);
         fa.group = 1; fa.k0 = j; fa.mode = 0; fa.hstride = (uint64_t)NC * rowd;
         fa.tie_over = wk.d_pairs; fa.tie_over_stride = PC;      // the pair list of the job is written only after k_resolve
         HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
+        if (c->band) HIPCHK(c, hipMemsetAsync(wk.d_redo_n, 0, 4, wk.stream));
         int rc = launch_fwd(c, wk.stream, fa, ns, &wk);
         if (rc) return rc;
         { Timer t(c, KC_RESOLVE, wk.stream);
@@ -457,12 +512,13 @@ struct Plan {
                              wk.d_resolve_ws, (topo_lds + 15u) & ~15u, c->force_dfs ? 1 : 0); }
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
-        ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j;
+        ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j; ta.kept = c->kept;
         launch_trace(wk, ta, ns, 1, NC);
+        if ((rc = redo(wk, fa, ta, ns, NC))) return rc;
         VcAddArgs aa{};
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
         aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16; aa.ring = (uint32_t)kRing;
-        aa.make_rows = !(c->dbg_stop_kind == 1 && c->dbg_stop_index == j);
+        aa.make_rows = !(c->dbg_stop_kind == 1 && c->dbg_stop_index == j); aa.kept = c->kept;
         { Timer t(c, KC_ADDALN, wk.stream); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, wk.stream, aa); }
         return VC_OK;
     }
@@ -488,9 +544,20 @@ struct Plan {
         pa.min_conf = c->prm.min_confidence; pa.min_supp = c->prm.min_support;
         for (uint32_t rep = 0; rep < ((c->dup & 4u) ? 2u : 1u); ++rep) { Timer t(c, KC_PRUNE, wk.stream); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), pws ? 0 : vc_prune_lds_bytes(NCl, ECl), wk.stream, pa); }
         wk.cur ^= 1;
-        for (uint32_t rep = 0; rep < ((c->dup & 8u) ? 2u : 1u); ++rep) { Timer t(c, KC_TOPO, wk.stream);
-          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tws ? 0 : topo_lds_bytes(NCl, ECl, c->STK, c->MA), wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NCl, ECl,
-                             tws ? wk.d_big_ws : nullptr, c->big_ws_stride); }
+        {
+            // before the first re-alignment round the host does not know how small the pruned graphs are: size the LDS image
+            // for what they usually are (a chain plus bubbles: ~1.2 nodes and ~1.5 edges per backbone base) and give every
+            // workgroup its HBM workspace for the exception
+            uint32_t NCt = NCl, ECt = ECl;
+            if (!wk.pruned_known && c->big_ws_topo) {
+                NCt = std::min(NC, (uint32_t)((c->max_backbone * 5 / 4 + 127) & ~63u));
+                ECt = std::min(EC, (uint32_t)((c->max_backbone * 2 + 127) & ~63u));
+            }
+            const bool tw = topo_lds_bytes(NCt, ECt, c->STK, c->MA) > kLdsCap;
+            for (uint32_t rep = 0; rep < ((c->dup & 8u) ? 2u : 1u); ++rep) { Timer t(c, KC_TOPO, wk.stream);
+              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tw ? 0 : topo_lds_bytes(NCt, ECt, c->STK, c->MA), wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRingPruned, NCt, ECt,
+                                 (tw || c->big_ws_topo) ? wk.d_big_ws : nullptr, c->big_ws_stride, tw ? 1 : 0); }
+        }
         if (more) {
             HIPCHK(c, hipMemsetAsync(wk.d_maxn, 0, 8, wk.stream));
             hipLaunchKernelGGL(k_max_u32, dim3((ns + 255) / 256), dim3(256), 0, wk.stream, wk.dp.nrows, ns, wk.d_maxn);
@@ -518,11 +585,13 @@ struct Plan {
         for (uint32_t k0 = 0; k0 < wk.nseq_max; k0 += group) {
             const uint32_t gsz = std::min(group, wk.nseq_max - k0);
             fa.group = gsz; fa.k0 = k0; fa.mode = 1; fa.hstride = stride;
+            if (c->band) HIPCHK(c, hipMemsetAsync(wk.d_redo_n, 0, 4, wk.stream));
             int rc = launch_fwd(c, wk.stream, fa, ns * gsz, &wk);
             if (rc) return rc;
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
             launch_trace(wk, ta, ns * gsz, gsz, maxn);
+            if ((rc = redo(wk, fa, ta, ns * gsz, maxn))) return rc;
         }
         VcAddwArgs wa{};
         wa.b = c->b; wa.g = wk.gr[wk.cur]; wa.dp = wk.dp; wa.w0 = wk.w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
@@ -535,8 +604,8 @@ struct Plan {
     int linear_tail(Work& wk) {
         const uint32_t ns = wk.ns;
         { Timer t(c, KC_TOPO, wk.stream);
-          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds > kLdsCap ? 0 : topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRing, NC, EC,
-                             topo_lds > kLdsCap ? wk.d_big_ws : nullptr, c->big_ws_stride); }
+          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds > kLdsCap ? 0 : topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRingPruned, NC, EC,
+                             topo_lds > kLdsCap ? wk.d_big_ws : nullptr, c->big_ws_stride, topo_lds > kLdsCap ? 1 : 0); }
         VcConsArgs ca{};
         ca.b = c->b; ca.g = wk.gr[wk.cur]; ca.dp = wk.dp; ca.w0 = wk.w0; ca.nslots = ns; ca.NC = NC; ca.EC = EC;
         ca.trim = c->prm.trim; ca.window_type = c->prm.window_type;
@@ -550,11 +619,11 @@ struct Plan {
     int finish(Work& wk) {
         const uint32_t ns = wk.ns;
         VcFwdArgs fa = fwd_args(wk);
-        fa.group = 1; fa.k0 = 0; fa.mode = 2; fa.hstride = (uint64_t)NC * rowd;
+        fa.group = 1; fa.k0 = 0; fa.mode = 2; fa.hstride = (uint64_t)NC * rowd; fa.band = 0;
         int rc = launch_fwd(c, wk.stream, fa, ns, &wk);
         if (rc) return rc;
         VcTraceArgs ta = trace_args(wk);
-        ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride;
+        ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride; ta.band = 0;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
         launch_trace(wk, ta, ns, 1, NC);
         VcFinishArgs fn{};
@@ -694,7 +763,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint64_t nseq = hb->win_seq_off[nw];
     const uint64_t nbytes = hb->seq_off[nseq];
     // validation (what createWindow / add_layer enforce, window.cpp:22-27,56-67)
-    uint32_t max_layers = 0, max_len = 0, max_nseq = 0, min_len = 0xFFFFFFFFu;
+    uint32_t max_layers = 0, max_len = 0, max_nseq = 0, min_len = 0xFFFFFFFFu, max_backbone = 0;
     uint64_t need_nodes = 0;
     std::vector<uint8_t> layer_partial;
     std::vector<uint8_t> pre(nw, 0);          // windows outside the device envelope: reported, not run
@@ -704,6 +773,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         if (s1 <= s0) return fail(c, VC_ERR_ARG, "window %u has no backbone", w);
         const uint64_t L = hb->seq_off[s0 + 1] - hb->seq_off[s0];
         if (L == 0 || L >= 65535) return fail(c, VC_ERR_ARG, "window %u: backbone length %llu unsupported", w, (unsigned long long)L);
+        max_backbone = std::max<uint32_t>(max_backbone, (uint32_t)L);
         if (!hb->seq_has_qual[s0]) return fail(c, VC_ERR_ARG, "window %u: backbone needs a quality string (dummy '!' for FASTA targets)", w);
         uint64_t sum = 0;
         for (uint32_t s = s0; s < s1; ++s) {
@@ -806,6 +876,9 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     if (topo_lds_bytes(NC, EC, c->STK, MA) > lds_cap) big = std::max(big, topo_lds_bytes(NC, EC, c->STK, MA));
     if (vc_prune_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_prune_lds_bytes(NC, EC));
     if (c->prm.mode == 1 && vc_cons_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_cons_lds_bytes(NC, EC));
+    c->big_ws_topo = c->prm.mode == 0;                    // k_topo's LDS image of the first pruned graphs is sized optimistically: its fallback lives here
+    if (c->big_ws_topo) big = std::max(big, topo_lds_bytes(NC, EC, c->STK, MA));
+    c->max_backbone = max_backbone;
     big = (big + 255u) & ~255u;
     const uint32_t PC = NC + ws_max_len + 8;
 
@@ -828,7 +901,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         if (wc < -31744 || (mm - gg) * (64ll * cpl + 1) >= 32767 || (sw && nn >= 0)) maybe_wide = true;
     }
     const uint32_t wcols = maybe_wide ? ((ws_max_len + 64 * VC_WIDE_CPL - 1) / (64 * VC_WIDE_CPL)) * (64 * VC_WIDE_CPL) : 0;
-    const uint64_t per_job = NC * rowd * 4 + NC * 2 + 8 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
+    const uint64_t per_job = NC * rowd * 5 + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);
     if (CW == 0) CW = 1;
@@ -860,6 +933,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         c->chunk_bytes = f0 > f1 ? f0 - f1 : 0;
     }
     b.cons_cap = NC;
+    c->kept = (kKept && NC < 32768 && !getenv("VC_PLAIN_RING")) ? (uint32_t)kKept : 0u;
+    c->band = c->packed && c->kept && c->trace_wave && !getenv("VC_NO_BAND");
     if ((rc = salloc(c, 12, &b.cons, (size_t)nw * b.cons_cap))) return rc;
     HIPCHK(c, hipMemsetAsync(b.status, 0, nw, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, nw * 4, c->stream));
@@ -888,13 +963,19 @@ int vc_run(vc_ctx* c) {
     pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
     pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK, c->MA);
     pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
-    pl.add_lds = 2 * c->PC + 2 * (c->PC - c->NC) + 64;
+    pl.add_lds = std::max(2 * c->PC + 2 * (c->PC - c->NC) + 64, c->kept ? vc_kept_lds_bytes(c->NC) : 0u);
     pl.rows_lds = 0;
     pl.cons_lds = vc_cons_lds_bytes(c->NC, c->EC);
     pl.rowd = 64ull * (c->ws_cpl / 2);
     HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.topo_lds, kLdsCap)));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.prune_lds, kLdsCap)));
+    if (pl.add_lds > kLdsCap) return fail(c, VC_ERR_ARG, "a layer of %u bases on graphs of %u nodes needs %u bytes of LDS in k_addaln (limit %u)", c->ws_max_len, c->NC, pl.add_lds, kLdsCap);
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
+    if (c->kept) {
+        const uint32_t sub_lds = std::max(8 * ((c->NC + 63) / 64) + 2 * c->NC + ((c->NC + 15) & ~15u) + 4 * (c->NC / 32 + 1) + 64, vc_kept_lds_bytes(c->NC));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vc_kept_lds_bytes(c->NC)));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_rows_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sub_lds));
+    }
     if (c->prm.mode == 1)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.cons_lds, kLdsCap)));
     HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64 * VC_STAT_SLOTS, c->stream));
@@ -1135,7 +1216,7 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
     pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
     pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK, c->MA);
     pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
-    pl.add_lds = 2 * c->PC + 2 * (c->PC - c->NC) + 64;
+    pl.add_lds = std::max(2 * c->PC + 2 * (c->PC - c->NC) + 64, c->kept ? vc_kept_lds_bytes(c->NC) : 0u);
     pl.rows_lds = 0; pl.cons_lds = 0;
     pl.rowd = 64ull * (c->ws_cpl / 2);
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
@@ -1185,6 +1266,12 @@ int vc_get_stats(vc_ctx* c, vc_stats* s) {
     c->stats.cells = st[0]; c->stats.dp_rows = st[1];
     c->stats.far_row_reads = st[3];
     c->stats.trace_steps = st[4]; c->stats.trace_spec = st[5]; c->stats.trace_rounds = st[6];
+    c->stats.band_redo = st[7];
+    {
+        uint64_t held = c->chunk_bytes;
+        for (auto& sl : c->slots) held += sl.cap;
+        c->stats.device_bytes = held;
+    }
     c->stats.alignments = c->stats.launches[KC_FWD];
     c->stats.n_streams = c->n_streams;
     *s = c->stats;

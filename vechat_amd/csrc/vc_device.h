@@ -15,6 +15,7 @@
 
 #define VC_NONE16   0xFFFFu
 #define VC_INLINE_PRED 6       // predecessors stored inline in a row record
+#define VC_BAND_LANES 16       // banded matrix store: lanes of a DP row that are written (around the rank diagonal); see vc_band_start
 #define VC_MAXTIE   16         // NW end-cell ties remembered for the exact-rank resolver
 
 // row record flags
@@ -22,6 +23,8 @@
 #define VC_RF_OVF   4u
 #define VC_RF_PREV  8u     // one of the predecessors is the row directly above (still in registers)
 #define VC_RF_SLOW  16u    // frec only: a listed predecessor is the virtual row 0 or lies beyond the LDS ring, or the list overflowed
+#define VC_RF_KEEP  64u    // frec only (kept-row ring): a later row reads this row back from the LDS ring; bits 27..29 of the word hold its slot
+#define VC_RF_FULL  128u   // frec only (banded matrix store): a later row reads this row back from the stored matrix: store it whole
 #define VC_RF_PLAIN 32u    // frec only: the row directly above is the ONLY predecessor (the commonest row: nothing to fetch)
 
 struct VcGraph {

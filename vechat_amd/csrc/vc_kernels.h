@@ -159,13 +159,14 @@ __global__ __launch_bounds__(64) void k_avg(VcBatchDev b, uint32_t w0, uint32_t 
 }
 
 __device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph& g, const VcDp& dp, uint32_t slot, uint32_t w,
-                                             uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t N);
+                                             uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t N, uint32_t kept, uint8_t* lds);
 
 // ------------------------------------------------------------------------------------------------
 // k_init: backbone chain graph (AddAlignment with an empty alignment, graph.cpp:207-212)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                             uint32_t NC, uint32_t EC, uint32_t ring) {
+                                             uint32_t NC, uint32_t EC, uint32_t ring, uint32_t kept) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];          // kept != 0: vc_kept_lds_bytes(NC)
     uint32_t slot = blockIdx.x;
     if (slot >= nslots) return;
     uint32_t w = w0 + slot;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, VcDp dp, u
     }
     if (lane == 0) { g.n_nodes[slot] = L; g.n_edges[slot] = L - 1; }
     __syncthreads();
-    vc_rows_full(b, g, dp, slot, w, NC, EC, 1, ring, L);          // rows of the first layer's alignment
+    vc_rows_full(b, g, dp, slot, w, NC, EC, 1, ring, L, kept, smem);          // rows of the first layer's alignment
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,7 +346,7 @@ __device__ int vc_topo_dfs(const VcTopoLds& ls, uint32_t N, uint32_t STK, bool m
 
 __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                              uint32_t NC, uint32_t EC, uint32_t STK, int next_layer, int only_masked, uint32_t ring,
-                                             uint32_t NCl, uint32_t ECl, uint8_t* ws, uint32_t ws_stride) {
+                                             uint32_t NCl, uint32_t ECl, uint8_t* ws, uint32_t ws_stride, int ws_only) {
     // ws != nullptr: the graph image does not fit the 160 KB LDS; work from this workgroup's HBM workspace
     // instead (same layout, same code; slower, but the window is computed rather than rejected).
     // NC/EC: strides of the graph arrays in HBM; NCl/ECl: capacity the LDS image was sized for (the host
@@ -370,8 +371,13 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
     const uint32_t N = g.n_nodes[slot], E = g.n_edges[slot];
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
 
-    if (N > NCl || E > ECl) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 24, N); return; }
-    const VcTopoLds t = vc_topo_carve(ws ? ws + (size_t)blockIdx.x * ws_stride : smem, NCl, ECl, STK, g.ma);
+    // The LDS image is sized optimistically (NCl / ECl: what the host expects of a pruned graph); a graph that outgrows it
+    // works from this workgroup's HBM workspace instead, laid out for the full capacities -- decided per window, so that
+    // the common small graph does not reserve (and block for others) the LDS of the rare large one.
+    const bool big = N > NCl || E > ECl;
+    if (big && (!ws || N > NC || E > EC)) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 24, N); return; }
+    if (big) { NCl = NC; ECl = EC; }
+    const VcTopoLds t = vc_topo_carve((big || ws_only) ? ws + (size_t)blockIdx.x * ws_stride : smem, NCl, ECl, STK, g.ma);
     uint16_t* s_in_first = t.in_first; uint32_t* s_etn = t.etn; uint16_t* s_al = t.al;
     uint8_t* s_flag = t.flag; uint16_t* s_rank = t.rank;
     vc_topo_load(g, nb, eb, N, E, t, lane);
@@ -471,6 +477,27 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
         ovf_base += tot_ovf;
     }
     bad = __any(bad);
+    // banded matrix store (vc_band_start): rows that a later row reads back from the stored matrix are written whole --
+    // the predecessors beyond the LDS ring and everything on a long list (the forward pass reads those as the records say)
+    __syncthreads();
+    for (uint32_t r = lane; r < nrows && !bad; r += 64) {
+        const uint4 q = dp.frec[nb + r];
+        const uint32_t fl = (q.x >> 8) & 0xFF;
+        if (!(fl & VC_RF_SLOW)) continue;
+        if (fl & VC_RF_OVF) {
+            const uint32_t o0 = q.y, cnt = q.z;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t d = dp.ovf[eb + o0 + k];
+                if (d > ring && d <= r) atomicOr(reinterpret_cast<uint32_t*>(&dp.frec[nb + r - d]), VC_RF_FULL << 8);
+            }
+        } else {
+            const uint32_t nq = (q.x >> 16) & 0xFF;
+            const uint32_t dl[VC_INLINE_PRED] = {q.y & 0xFFFF, q.y >> 16, q.z & 0xFFFF, q.z >> 16, q.w & 0xFFFF, q.w >> 16};
+#pragma unroll
+            for (int k = 0; k < VC_INLINE_PRED; ++k)
+                if ((uint32_t)k < nq && dl[k] > ring && dl[k] <= r) atomicOr(reinterpret_cast<uint32_t*>(&dp.frec[nb + r - dl[k]]), VC_RF_FULL << 8);
+        }
+    }
     if (lane == 0) {
         dp.nrows[slot] = nrows;
         dp.flags[slot] = bad ? 1u : 0u;
@@ -497,7 +524,7 @@ struct VcOtf {
     uint32_t N, EC;
 };
 template <int U>
-__device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_t ring, uint32_t& ovf_base, int& bad) {
+__device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_t ring, uint32_t& ovf_base, int& bad, bool plain_frec) {
     // U blocks of 64 rows at once, level by level: every load of a level is issued before the first result is used, so a lane
     // has U (then 6 U) independent loads in flight instead of one chain
     const uint32_t lane = (uint32_t)vc_lane();
@@ -567,9 +594,121 @@ __device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             o.rec[r[u]] = rec;
             o.rank2node[r[u]] = (uint16_t)v[u];
-            o.frec[r[u]] = vc_make_frec(code, fl, npu, dl, is_ovf, hasprev, r[u], ring);
+            if (plain_frec) o.frec[r[u]] = vc_make_frec(code, fl, npu, dl, is_ovf, hasprev, r[u], ring);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kept-row ring (build phase).  In a grown graph a row has ~1.5 predecessors that are not the row above, up to ~12 rows
+// back, but only ~70 % of the rows are ever read back that way.  So k_fwd keeps in LDS only the rows some later row will ask
+// for, in a ring of K SLOTS: K = 6 slots hold what a plain ring needs 8 rows for (96 % of such reads at the last layers),
+// and the smaller ring is what lets a fifth / sixth wave onto each SIMD.  The forward records are made here, after the
+// backtrack's records of all rows exist: mark the rows that are read back (distance 2..64, inline lists), count them
+// (kix[r] = kept rows before row r), and give every such predecessor its slot kix[p] % K -- it is still there when the
+// reader comes iff kix[reader] - kix[p] <= K.  A forward entry (u16) is then 0x8000 | slot << 8 | distance for a row in the
+// ring, or the plain distance (< 32768) for one that has to come back from the stored matrix; the word with the flags
+// carries VC_RF_KEEP and the row's own slot in bits 27..29.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t vc_kept_lds_bytes(uint32_t NC) { return 8u * (NC / 32 + 2) + 2u * (NC + 2) + 16u; }
+
+__device__ __forceinline__ void vc_frec_kept(const uint4* rec, uint4* frec, uint16_t* ovf, uint32_t nrows, uint32_t K, uint8_t* lds) {
+    const uint32_t lane = (uint32_t)vc_lane();
+    uint32_t* s_keep = reinterpret_cast<uint32_t*>(lds);                           // bit per row
+    uint32_t* s_full = s_keep + (nrows / 32 + 2);                                   // bit per row: read back from the stored matrix (VC_RF_FULL)
+    uint16_t* s_kix = reinterpret_cast<uint16_t*>(s_full + (nrows / 32 + 2));       // [nrows + 1] kept rows before row r
+    for (uint32_t i = lane; i < 2 * (nrows / 32 + 2); i += 64) s_keep[i] = 0;
+    __syncthreads();
+    // which rows are read back
+    for (uint32_t r = lane; r < nrows; r += 64) {
+        const uint4 q = rec[r];
+        const uint32_t fl = (q.x >> 8) & 0xFF, np = (q.x >> 16) & 0xFF;
+        if (fl & VC_RF_OVF) {                                                      // a long list (VcDp::ovf): its rows are read back all the same
+            const uint32_t o0 = q.y, cnt = q.z;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t d = ovf[o0 + k];
+                if (d >= 2 && d <= 64 && d <= r) atomicOr(&s_keep[(r - d) >> 5], 1u << ((r - d) & 31));
+            }
+            continue;
+        }
+        const uint32_t dl[VC_INLINE_PRED] = {q.y & 0xFFFF, q.y >> 16, q.z & 0xFFFF, q.z >> 16, q.w & 0xFFFF, q.w >> 16};
+#pragma unroll
+        for (int k = 0; k < VC_INLINE_PRED; ++k)
+            if ((uint32_t)k < np && dl[k] >= 2 && dl[k] <= 64 && dl[k] <= r) atomicOr(&s_keep[(r - dl[k]) >> 5], 1u << ((r - dl[k]) & 31));
+    }
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t r0 = 0; r0 < nrows; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        const bool kp = r < nrows && ((s_keep[r >> 5] >> (r & 31)) & 1u);
+        const unsigned long long m = __ballot(kp);
+        if (r <= nrows) s_kix[r] = (uint16_t)(base + __popcll(m & ((1ull << lane) - 1ull)));
+        base += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) s_kix[nrows] = (uint16_t)base;
+    __syncthreads();
+    for (uint32_t r = lane; r < nrows; r += 64) {
+        const uint4 q = rec[r];
+        const uint32_t code = q.x & 0xFF, fl = (q.x >> 8) & 0xFF, np = (q.x >> 16) & 0xFF;
+        const bool is_ovf = (fl & VC_RF_OVF) != 0, hasprev = (fl & VC_RF_PREV) != 0;
+        const uint32_t dl[VC_INLINE_PRED] = {q.y & 0xFFFF, q.y >> 16, q.z & 0xFFFF, q.z >> 16, q.w & 0xFFFF, q.w >> 16};
+        uint32_t f = fl & (VC_RF_SINK | VC_RF_OVF | VC_RF_PREV);
+        uint32_t out[VC_INLINE_PRED];
+#pragma unroll
+        for (int k = 0; k < VC_INLINE_PRED; ++k) out[k] = 0;
+        uint32_t nq = 0;
+        bool slow = is_ovf;
+        const uint32_t kr = s_kix[r];
+        if (is_ovf) {
+            out[0] = dl[0]; out[1] = dl[1]; out[2] = dl[2]; out[3] = dl[3];           // offset into VcDp::ovf, number of entries there
+            nq = min(np, 255u);
+            // the list itself takes the forward form (the backtrack reads distances from it: it masks the mark off)
+            const uint32_t o0 = q.y, cnt = q.z;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t d = ovf[o0 + k] & 0x7FFFu;
+                bool hit = false;
+                if (d >= 2 && d <= 64 && d <= r) {
+                    const uint32_t kp = s_kix[r - d];
+                    if (kr - kp <= K) { hit = true; ovf[o0 + k] = (uint16_t)(0x8000u | ((kp % K) << 8) | d); }
+                }
+                if (!hit && d >= 2 && d <= r) atomicOr(&s_full[(r - d) >> 5], 1u << ((r - d) & 31));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VC_INLINE_PRED; ++k) {
+                if ((uint32_t)k < np && !(hasprev && dl[k] == 1)) {
+                    const uint32_t d = dl[k];
+                    uint32_t e = d;
+                    bool hit = false;
+                    if (d >= 2 && d <= 64 && d <= r) {
+                        const uint32_t kp = s_kix[r - d];
+                        if (kr - kp <= K) { hit = true; e = 0x8000u | ((kp % K) << 8) | d; }
+                    }
+                    if (!hit) {
+                        slow = true;                                                 // (the host uses this form below 32768 rows only: d < 0x8000)
+                        if (d <= r) atomicOr(&s_full[(r - d) >> 5], 1u << ((r - d) & 31));     // that row comes back from the stored matrix
+                    }
+#pragma unroll
+                    for (int t = 0; t < VC_INLINE_PRED; ++t) if (nq == (uint32_t)t) out[t] = e;
+                    nq++;
+                }
+            }
+        }
+        if (slow) f |= VC_RF_SLOW;
+        if (hasprev && nq == 0 && !slow) f |= VC_RF_PLAIN;
+        const bool keep = (s_keep[r >> 5] >> (r & 31)) & 1u;
+        if (keep) f |= VC_RF_KEEP;
+        const uint32_t bi = code == 'A' ? 0u : code == 'C' ? 1u : code == 'G' ? 2u : code == 'T' ? 3u : 4u;
+        uint4 o;
+        o.x = code | (f << 8) | (nq << 16) | (bi << 24) | ((keep ? kr % K : 0u) << 27);
+        o.y = out[0] | (out[1] << 16);
+        o.z = out[2] | (out[3] << 16);
+        o.w = out[4] | (out[5] << 16);
+        frec[r] = o;
+    }
+    __syncthreads();
+    for (uint32_t r = lane; r < nrows; r += 64)
+        if ((s_full[r >> 5] >> (r & 31)) & 1u) frec[r].x |= VC_RF_FULL << 8;
 }
 
 // Runs at the tail of the kernel that last changed the graph (k_init for layer 1, k_addaln of layer j for layer j + 1): the wave
@@ -578,8 +717,9 @@ __device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_
 #ifndef VC_ROWS_U
 #define VC_ROWS_U 4
 #endif
+// kept != 0: forward records for k_fwd's kept-row ring of `kept` slots (vc_frec_kept; `lds` = vc_kept_lds_bytes(NC) of scratch)
 __device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph& g, const VcDp& dp, uint32_t slot, uint32_t w,
-                                             uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t N) {
+                                             uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t N, uint32_t kept, uint8_t* lds) {
     const int lane = vc_lane();
     const uint32_t s0 = b.win_seq_off[w], ns = b.win_seq_off[w + 1] - s0;
     if ((uint32_t)next_layer >= ns) return;
@@ -595,7 +735,8 @@ __device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph&
     uint32_t ovf_base = 0;
     int bad = 0;
     // VC_ROWS_U blocks of 64 rows per iteration: more independent load chains in flight per lane
-    for (uint32_t r0 = 0; r0 < N; r0 += 64 * VC_ROWS_U) vc_otf_rows<VC_ROWS_U>(ot, r0, ring, ovf_base, bad);
+    for (uint32_t r0 = 0; r0 < N; r0 += 64 * VC_ROWS_U) vc_otf_rows<VC_ROWS_U>(ot, r0, ring, ovf_base, bad, kept == 0);
+    if (kept) { __syncthreads(); vc_frec_kept(ot.rec, ot.frec, ot.ovf, N, kept, lds); }
     bad = __any(bad & 1) | (__any(bad & 2) ? 2 : 0);
     if (bad & 2) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 12, 0); return; }   // order invariant violated
     if (lane == 0) {
@@ -616,7 +757,7 @@ __device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph&
 // LDS carve: member bits 8*nW | rowidx 2*NC | node-id bitmap 4*(NC/32+1)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                                 uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask) {
+                                                 uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask, uint32_t kept) {
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t slot = blockIdx.x;
@@ -768,6 +909,10 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
     bad = __any(bad);
     broken = __any(broken);
     if (broken) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 22, 0); return; }
+    if (kept) {                                               // forward records for the kept-row ring (the LDS of the sweep is free now)
+        __syncthreads();
+        vc_frec_kept(dp.rec + nb, dp.frec + nb, dp.ovf + eb, nrows, kept, smem);
+    }
     if (lane == 0) {
         dp.nrows[slot] = nrows;
         dp.flags[slot] = (bad ? 1u : 0u) | 2u | 4u;            // incremental order, masked
@@ -958,6 +1103,18 @@ __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp
 //            backtrack (k_trace) re-derives every move from H exactly as sisd:362-459 does
 // mode: 0 build (NW), 1 re-alignment (NW for backbone/full-span else SW), 2 final SW of the backbone
 // ------------------------------------------------------------------------------------------------
+// Banded matrix store.  The backtrack of a global alignment stays close to the rank diagonal -- row i meets column
+// i * len / rows -- so k_fwd writes, per row, only the VC_BAND_LANES lanes around it (192 instead of 768 bytes at 10 cells
+// per lane: the stored matrix is 62 % of all the bytes this path moves through HBM, and HBM is what bounds it), into a
+// compact band matrix [row][VC_BAND_LANES][NDS].  Rows that a later row reads back from the stored matrix (VC_RF_FULL, set
+// by the row builders) are also written whole, as before.  A backtrack that needs a cell outside the band gives up and
+// puts its alignment on a redo list: k_fwd runs again for those (whole rows), and the backtrack walks them from there.
+// Both kernels take the band of a row from the same two numbers per alignment (VcFwdArgs::band_par): first row and slope.
+__device__ __forceinline__ uint32_t vc_band_start(uint32_t i, uint32_t rb, uint32_t ql) {
+    const uint32_t t = i > rb ? (uint32_t)(((unsigned long long)(i - rb) * ql) >> 16) : 0u;     // lane of the diagonal at row i
+    return min(max(t, (uint32_t)(VC_BAND_LANES / 2 - 1)) - (VC_BAND_LANES / 2 - 1), 64u - VC_BAND_LANES);
+}
+
 struct VcFwdArgs {
     VcBatchDev b;
     VcDp dp;
@@ -980,6 +1137,12 @@ struct VcFwdArgs {
     uint32_t* tie_n;               // [1]
     unsigned long long* stat;      // [4] cells, rows, -, far-row reads
     uint32_t wcols;                // != 0: k_fwd_wide follows this launch and takes what the packed-int16 kernel declines
+    uint32_t kept;                 // build phase: slots of the kept-row ring the forward records were made for (0: plain ring)
+    uint32_t* bmat;                // band matrix of a job: bmat + job * (hstride / 4)
+    uint32_t* band_par;            // [jobs * 2] first row and slope (lanes per row, 16.16) of the job's band
+    int band;                      // 1: global alignments store the band (+ whole rows where VC_RF_FULL asks for them)
+    const uint32_t* redo_list;     // != nullptr: this launch re-runs the listed jobs with whole rows (the backtrack left the band)
+    const uint32_t* redo_n;
 #ifdef VC_LAB
     uint32_t dbg;                  // development (tools/gpu_fwd_lab.py): parts of the row loop switched off, timing only
 #endif
@@ -1068,19 +1231,23 @@ __device__ __forceinline__ int vc_packed_cell(const uint32_t* w, uint32_t cc, ui
 //     max_p (H[p][j-1] + P[j]) = (max_p H[p][j-1]) + P[j],   max_p (H[p][j] + g) = (max_p H[p][j]) + g,
 // so each additional in-edge costs one packed max per register instead of a full relaxation, and the
 // order of the in-edges is irrelevant here (it matters only to the backtrack, which follows it).
-template <int CPL, int RING, bool NWT, bool PACKED>
+template <int CPL, int RING, bool NWT, bool PACKED, bool KEPT>
 __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_raw) {
-    static_assert((RING & (RING - 1)) == 0, "ring slots are taken with a mask");
+    // KEPT: the LDS ring holds RING SLOTS for the rows a later row reads back (vc_frec_kept gave every such row its slot);
+    // otherwise the last RING rows, slot = row % RING
+    static_assert(KEPT || (RING & (RING - 1)) == 0, "ring slots are taken with a mask");
     constexpr int ND = CPL / 2;              // packed int16 dwords per lane per row
     constexpr int NDS = vc_nds(CPL);         // dwords per lane per row in the packed stored form
     uint32_t (*ring)[ND][64] = reinterpret_cast<uint32_t (*)[ND][64]>(ring_raw);
     const int lane = vc_lane();
-    const uint32_t job = blockIdx.x;
+    const bool redo = a.redo_list != nullptr;                 // second pass over the alignments whose backtrack left the band
+    if (redo && blockIdx.x >= *a.redo_n) return;
+    const uint32_t job = redo ? a.redo_list[blockIdx.x] : blockIdx.x;
     const uint32_t slot = job / a.group;
     if (slot >= a.nslots) return;
     const uint32_t k = a.k0 + job % a.group;
     const uint32_t w = a.w0 + slot;
-    if (a.do_init && lane == 0) { a.job_type[job] = 255; a.job_end[job] = 0; a.tie_cnt[job] = 0; }
+    if (a.do_init && lane == 0 && !redo) { a.job_type[job] = 255; a.job_end[job] = 0; a.tie_cnt[job] = 0; }
     if (a.b.status[w] != VC_WIN_OK) return;
     const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
     if (k >= ns) return;
@@ -1120,12 +1287,13 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
             return;
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && !redo) {
         a.job_type[job] = nw ? 1 : 0;
         unsigned long long* st = vc_stat_slot(a.stat);
         atomicAdd(st + 0, (unsigned long long)nrows * len);
         atomicAdd(st + 1, (unsigned long long)nrows);
     }
+    if (lane == 0 && redo) atomicAdd(vc_stat_slot(a.stat) + 7, 1ull);
 
     // tilted match/mismatch profile (score - g) of my columns for the four usual bases (packed pairs);
     // other row bytes are compared on the fly.  Columns beyond the sequence end never match.
@@ -1150,6 +1318,12 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
 
     uint32_t* const hrow0 = a.hmat + (uint64_t)job * a.hstride;
     constexpr bool packed = PACKED;           // the stored row form is a property of the launch (host: both score sets fit the byte bound)
+    // banded store: global alignments only (a local alignment may end and start anywhere), byte-packed rows only
+    const bool band = NWT && PACKED && a.band && !redo;
+    uint32_t* const brow0 = a.bmat + (uint64_t)job * (a.hstride / 4);
+    const uint32_t band_rb = 0, band_ql = (uint32_t)((((unsigned long long)len << 16) / nrows) / CPL);
+    if (band && lane == 0) { a.band_par[2 * job] = band_rb; a.band_par[2 * job + 1] = band_ql; }
+    int bvec = 0;                             // lane t: first band lane of row (block * 64 + t + 1)
     int16_t* const c0p_out = a.c0 + (uint64_t)job * a.NC;
     const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
 
@@ -1171,119 +1345,37 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
     constexpr uint32_t rowdw = PACKED ? NDS * 64 : ND * 64;     // dwords per stored row
     uint32_t voff = (PACKED ? lane * NDS : lane) * 4u;          // my BYTE offset inside the stored matrix (one 32-bit add per row; < 4 GB per job)
-    const uint32_t lane4 = (uint32_t)lane * 4u;
+    uint32_t boff = 0;                                          // byte offset of the current row inside the band matrix
 
     // a row of the LDS ring merged into the running maximum; column 0 of the last 64 rows lives in c0vec
-    auto ring_merge = [&](uint32_t pr, int& c0m) __attribute__((always_inline)) {
-        const uint32_t* rp = ring_raw + (pr & (RING - 1)) * (ND * 64) + lane;
+    auto ring_slot_merge = [&](uint32_t slot, uint32_t c0lane, int& c0m) __attribute__((always_inline)) {
+        const uint32_t* rp = ring_raw + slot * (ND * 64) + lane;
         uint32_t hp[ND];
 #pragma unroll
         for (int q = 0; q < ND; ++q) hp[q] = rp[q * 64];
-        const int c0p = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
+        const int c0p = __builtin_amdgcn_readlane(c0vec, c0lane);
+        // in place (tied operand): at the join behind the predecessor handling acc is then ONE value on every path, and the
+        // compiler has no copies to insert there (it did: ten v_mov per row that is not "plain")
 #pragma unroll
-        for (int q = 0; q < ND; ++q) acc[q] = pk_max(acc[q], hp[q]);
+        for (int q = 0; q < ND; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc[q]) : "v"(hp[q]));
         c0m = max(c0m, c0p);
     };
+    // a listed predecessor known to sit in the ring: `e` is its forward entry (plain ring: the distance; kept-row ring:
+    // 0x8000 | slot << 8 | distance)
+    auto ring_merge = [&](uint32_t i, uint32_t e, int& c0m) __attribute__((always_inline)) {
+        if (KEPT) ring_slot_merge((e >> 8) & 7u, (i - (e & 0x7Fu) - 1u) & 63u, c0m);
+        else ring_slot_merge((i - e) & (RING - 1), (i - e - 1u) & 63u, c0m);
+    };
 
-    for (uint32_t i0 = 1; i0 <= nrows; i0 += 64) {              // blocks of 64 rows: one record fetch, one column-0 flush
-      myrec = nextrec;
-      {
-          const uint32_t r = i0 - 1 + 64 + lane;
-          if (r < nrows) nextrec = a.dp.frec[nb + r];
-      }
-      const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, nrows - i0 + 1));
-      for (uint32_t ri = 0; ri < cnt; ++ri) {
-        const uint32_t i = i0 + ri;
-        const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
-
-        // ---- element-wise maximum over the predecessor rows (and over their column 0).  The commonest row has the row
-        // above as its only predecessor: acc and c0prev are that maximum already
-        int c0m = c0prev;
-        if (!(r0 & (VC_RF_PLAIN << 8))) {
-            if (!(r0 & (VC_RF_PREV << 8))) {
-                c0m = VC_INT_MIN;
-#pragma unroll
-                for (int q = 0; q < ND; ++q) acc[q] = 0x80008000u;
-            }
-            const uint32_t nq = (r0 >> 16) & 0xFF;
-            if (!(r0 & (VC_RF_SLOW << 8))) {
-                // every listed predecessor sits in the LDS ring: straight-line, one test per further in-edge
-                if (nq) {
-                    const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
-                    ring_merge(i - (r1 & 0xFFFF), c0m);
-                    if (nq > 1) {
-                        ring_merge(i - (r1 >> 16), c0m);
-                        if (nq > 2) {
-                            const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
-                            ring_merge(i - (r2 & 0xFFFF), c0m);
-                            if (nq > 3) {
-                                ring_merge(i - (r2 >> 16), c0m);
-                                if (nq > 4) {
-                                    const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
-                                    ring_merge(i - (r3 & 0xFFFF), c0m);
-                                    if (nq > 5) ring_merge(i - (r3 >> 16), c0m);
-                                }
-                            }
-                        }
-                    }
-                }
-            } else {
-                // general path: the virtual row 0 analytically, a recent row from the LDS ring, an older one
-                // back from the stored matrix in HBM; long lists come from VcDp::ovf
-                const uint32_t fl = (r0 >> 8) & 0xFF;
-                const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
-                const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
-                const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
-                const uint32_t nlist = (fl & VC_RF_OVF) ? r2 : nq;
-                for (uint32_t p = 0; p < nlist; ++p) {
-                    uint32_t delta;
-                    if (fl & VC_RF_OVF) {
-                        delta = ovfp[r1 + p];
-                        if ((fl & VC_RF_PREV) && delta == 1) continue;
-                    } else {
-                        const uint32_t wsel = p < 2 ? r1 : (p < 4 ? r2 : r3);
-                        delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
-                    }
-                    const uint32_t pr = i - delta;
-                    if (pr == 0) {                                                   // H[0][j] = j*g (NW) / 0 (SW); column 0: 0
-#pragma unroll
-                        for (int q = 0; q < ND; ++q) acc[q] = pk_max(acc[q], nw ? 0u : njg[q]);
-                        c0m = max(c0m, 0);
-                    } else if (delta <= (uint32_t)RING) {
-                        ring_merge(pr, c0m);
-                    } else {
-                        uint32_t hA[ND];
-                        __threadfence_block();                                        // my own earlier stores must have landed
-                        if (PACKED) {
-                            const uint32_t* hr = hrow0 + (uint64_t)(pr - 1) * (NDS * 64) + lane * NDS;
-                            uint32_t wv[NDS];
-#pragma unroll
-                            for (int t = 0; t < NDS; ++t) wv[t] = hr[t];
-                            vc_unpack_row<ND, NDS>(wv, hA);
-                        } else {
-                            const uint32_t* hr = hrow0 + (uint64_t)(pr - 1) * (ND * 64);
-#pragma unroll
-                            for (int q = 0; q < ND; ++q) hA[q] = hr[q * 64 + lane];
-                        }
-                        far_reads++;
-                        int cA;
-                        if (delta <= 64) cA = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
-                        else cA = (int)__builtin_amdgcn_readfirstlane((int)c0p_out[pr - 1]);
-#pragma unroll
-                        for (int q = 0; q < ND; ++q) acc[q] = pk_max(acc[q], hA[q]);
-                        c0m = max(c0m, cA);
-                    }
-                }
-            }
-        }
-
+    // the DP of one row once the predecessor maximum stands in acc / c0m (two call sites: common rows, general-path rows)
+    auto row_tail = [&](const uint32_t r0, const int c0m, const uint32_t i, const uint32_t ri) __attribute__((always_inline)) {
         // ---- this row: diagonal (cell j-1 of the maximum: shift right by one int16; the hole is filled by
         // the left lane's last cell, lane 0 takes column 0) and vertical candidates
         const uint32_t left = (uint32_t)VC_DPP_SHR((int)acc[ND - 1], (int)((uint32_t)c0m << 16), 0x138, 0xF);
         uint32_t P[ND];
 #pragma unroll
         for (int q = 0; q < ND; ++q) P[q] = __builtin_amdgcn_alignbit(acc[q], q == 0 ? left : acc[q - 1], 16);
-        const uint32_t bi = r0 >> 24;
+        const uint32_t bi = (r0 >> 24) & 7u;
         if (bi < 2) {
             if (bi == 0) {
 #pragma unroll
@@ -1362,21 +1454,31 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         // one wave per workgroup: LDS operations of a wave retire in order, so no s_barrier (and no
         // vmcnt(0) drain of the H stores) is needed -- only keep the compiler from reordering
         __builtin_amdgcn_wave_barrier();
-        {
-            uint32_t* wp = ring_raw + (i & (RING - 1)) * (ND * 64) + lane;
+        if (VC_LABF(2)) {
+        } else if (!KEPT || (r0 & (VC_RF_KEEP << 8))) {             // kept-row ring: only rows a later row reads back, in the slot the row builder chose
+            uint32_t* wp = ring_raw + (KEPT ? ((r0 >> 27) & 7u) : (i & (RING - 1))) * (ND * 64) + lane;
 #pragma unroll
             for (int q = 0; q < ND; ++q) wp[q * 64] = acc[q];
         }
-        if (PACKED) {
+        if (VC_LABF(1)) {                                    // development (tools/gpu_fwd_lab.py): time the row loop without its stores
+        } else if (PACKED) {
             uint32_t wv[NDS];
             vc_pack_row<ND, NDS>(acc, wv);
-            uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + voff);
-            if (NDS == 2) *reinterpret_cast<uint2*>(hr) = make_uint2(wv[0], wv[1]);
-            else if (NDS == 4) *reinterpret_cast<uint4*>(hr) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-            else if (NDS == 3) { struct __attribute__((packed, aligned(4))) u3 { uint32_t a, b, c; }; *reinterpret_cast<u3*>(hr) = u3{wv[0], wv[1], wv[2]}; }
-            else {
+            auto put = [&](uint32_t* hr) __attribute__((always_inline)) {
+                if (NDS == 2) *reinterpret_cast<uint2*>(hr) = make_uint2(wv[0], wv[1]);
+                else if (NDS == 4) *reinterpret_cast<uint4*>(hr) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                else if (NDS == 3) { struct __attribute__((packed, aligned(4))) u3 { uint32_t a, b, c; }; *reinterpret_cast<u3*>(hr) = u3{wv[0], wv[1], wv[2]}; }
+                else {
 #pragma unroll
-                for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
+                    for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
+                }
+            };
+            // whole row: always without the band; with it only where a later row reads the row back (VC_RF_FULL)
+            if (!band || (r0 & (VC_RF_FULL << 8))) put(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + voff));
+            if (band) {
+                const uint32_t bl = (uint32_t)lane - (uint32_t)__builtin_amdgcn_readlane(bvec, ri);
+                if (bl < (uint32_t)VC_BAND_LANES) put(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(brow0) + boff + bl * (NDS * 4u)));
+                boff += VC_BAND_LANES * NDS * 4u;
             }
         } else {
             // full 256-B rows on purpose: masking the lanes past the sequence end was measured SLOWER
@@ -1387,13 +1489,124 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         }
         voff += rowdw * 4u;
         __builtin_amdgcn_wave_barrier();
+    };
+
+    for (uint32_t i0 = 1; i0 <= nrows; i0 += 64) {              // blocks of 64 rows: one record fetch, one column-0 flush
+      myrec = nextrec;
+      {
+          const uint32_t r = i0 - 1 + 64 + lane;
+          if (r < nrows) nextrec = a.dp.frec[nb + r];
+      }
+      if (band) bvec = (int)vc_band_start(i0 + (uint32_t)lane, band_rb, band_ql);
+      const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, nrows - i0 + 1));
+      for (uint32_t ri = 0; ri < cnt; ++ri) {
+        const uint32_t i = i0 + ri;
+        const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
+
+        // ---- element-wise maximum over the predecessor rows (and over their column 0).  The commonest row has the row
+        // above as its only predecessor: acc and c0prev are that maximum already
+        int c0m = c0prev;
+        if (r0 & (VC_RF_SLOW << 8)) {
+            // ---- rows whose list needs the general path (~3 %) take their own copy of the row body: no join with the
+            // common path in front of the DP, so the compiler keeps acc in place there (it used to shuffle it through
+            // ten copies per row)
+            if (!(r0 & (VC_RF_PREV << 8))) {
+                c0m = VC_INT_MIN;
+#pragma unroll
+                for (int q = 0; q < ND; ++q) asm volatile("v_mov_b32 %0, %1" : "+v"(acc[q]) : "s"(0x80008000u));
+            }
+            const uint32_t nq = (r0 >> 16) & 0xFF;
+            {
+                // general path: the virtual row 0 analytically, a recent row from the LDS ring, an older one
+                // back from the stored matrix in HBM; long lists come from VcDp::ovf
+                const uint32_t fl = (r0 >> 8) & 0xFF;
+                const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
+                const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
+                const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
+                const uint32_t nlist = (fl & VC_RF_OVF) ? r2 : nq;
+                for (uint32_t p = 0; p < nlist; ++p) {
+                    uint32_t delta;
+                    if (fl & VC_RF_OVF) {
+                        delta = ovfp[r1 + p];
+                        if ((fl & VC_RF_PREV) && delta == 1) continue;
+                        if (KEPT && (delta & 0x8000u)) { ring_merge(i, delta, c0m); continue; }
+                    } else {
+                        const uint32_t wsel = p < 2 ? r1 : (p < 4 ? r2 : r3);
+                        delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
+                        if (KEPT && (delta & 0x8000u)) { ring_merge(i, delta, c0m); continue; }      // this one is in the ring
+                    }
+                    const uint32_t pr = i - delta;
+                    if (pr == 0) {                                                   // H[0][j] = j*g (NW) / 0 (SW); column 0: 0
+#pragma unroll
+                        for (int q = 0; q < ND; ++q) { const uint32_t z = nw ? 0u : njg[q]; asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc[q]) : "v"(z)); }
+                        c0m = max(c0m, 0);
+                    } else if (!KEPT && delta <= (uint32_t)RING) {
+                        ring_merge(i, delta, c0m);
+                    } else {
+                        uint32_t hA[ND];
+                        __threadfence_block();                                        // my own earlier stores must have landed
+                        if (PACKED) {
+                            const uint32_t* hr = hrow0 + (uint64_t)(pr - 1) * (NDS * 64) + lane * NDS;
+                            uint32_t wv[NDS];
+#pragma unroll
+                            for (int t = 0; t < NDS; ++t) wv[t] = hr[t];
+                            vc_unpack_row<ND, NDS>(wv, hA);
+                        } else {
+                            const uint32_t* hr = hrow0 + (uint64_t)(pr - 1) * (ND * 64);
+#pragma unroll
+                            for (int q = 0; q < ND; ++q) hA[q] = hr[q * 64 + lane];
+                        }
+                        far_reads++;
+                        int cA;
+                        if (delta <= 64) cA = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
+                        else cA = (int)__builtin_amdgcn_readfirstlane((int)c0p_out[pr - 1]);
+#pragma unroll
+                        for (int q = 0; q < ND; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc[q]) : "v"(hA[q]));
+                        c0m = max(c0m, cA);
+                    }
+                }
+            }
+            row_tail(r0, c0m, i, ri);
+            continue;
+        }
+        if (!(r0 & (VC_RF_PLAIN << 8))) {
+            if (!(r0 & (VC_RF_PREV << 8))) {
+                c0m = VC_INT_MIN;
+#pragma unroll
+                for (int q = 0; q < ND; ++q) asm volatile("v_mov_b32 %0, %1" : "+v"(acc[q]) : "s"(0x80008000u));
+            }
+            const uint32_t nq = (r0 >> 16) & 0xFF;
+            {
+                // every listed predecessor sits in the LDS ring: straight-line, one test per further in-edge
+                if (nq) {
+                    const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
+                    ring_merge(i, r1 & 0xFFFF, c0m);
+                    if (nq > 1) {
+                        ring_merge(i, r1 >> 16, c0m);
+                        if (nq > 2) {
+                            const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
+                            ring_merge(i, r2 & 0xFFFF, c0m);
+                            if (nq > 3) {
+                                ring_merge(i, r2 >> 16, c0m);
+                                if (nq > 4) {
+                                    const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
+                                    ring_merge(i, r3 & 0xFFFF, c0m);
+                                    if (nq > 5) ring_merge(i, r3 >> 16, c0m);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        row_tail(r0, c0m, i, ri);
       }
       if ((uint32_t)lane < cnt) c0p_out[i0 - 1 + lane] = (int16_t)c0vec;   // column 0 of the block just completed
       __threadfence_block();
     }
-    (void)lane4;
-    if (lane == 0 && far_reads) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
+    if (lane == 0 && far_reads && !redo) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
 
+    if (redo) return;                                       // the end cell, ties and counters stand from the first pass
     // publish the end cell
     uint32_t end = 0;
     if (nw) {
@@ -1435,12 +1648,13 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     if (lane == 0) a.job_end[job] = end;
 }
 
-template <int CPL, int RING, bool PACKED>
+template <int CPL, int RING, bool PACKED, bool KEPT>
 __device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_raw) {
     // alignment type of this job (uniform per wave)
     bool nw = a.mode == 0;
     if (a.mode == 1) {
-        const uint32_t job = blockIdx.x, slot = job / a.group;
+        if (a.redo_list && blockIdx.x >= *a.redo_n) return;
+        const uint32_t job = a.redo_list ? a.redo_list[blockIdx.x] : blockIdx.x, slot = job / a.group;
         if (slot >= a.nslots) return;
         const uint32_t w = a.w0 + slot, k = a.k0 + job % a.group;
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
@@ -1449,26 +1663,27 @@ __device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_ra
             nw = (k == 0) || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L);
         }
     }
-    if (nw) vc_fwd_body<CPL, RING, true, PACKED>(a, ring_raw);
-    else vc_fwd_body<CPL, RING, false, PACKED>(a, ring_raw);
+    if (nw) vc_fwd_body<CPL, RING, true, PACKED, KEPT>(a, ring_raw);
+    else vc_fwd_body<CPL, RING, false, PACKED, KEPT>(a, ring_raw);
 }
 
 // CA <= CB: the two adjacent width classes of a batch share one launch (register and LDS budget of the
 // wider one); each alignment takes the narrowest body that holds its sequence.  CA == CB: single class.
-template <int CA, int CB, int RING, bool PACKED>
+template <int CA, int CB, int RING, bool PACKED, bool KEPT>
 __global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
     __shared__ uint32_t ring_raw[RING * (CB / 2) * 64];
     if (CA != CB) {
         // sequence length of this job decides the body (uniform per wave)
-        const uint32_t job = blockIdx.x, slot = job / a.group;
+        if (a.redo_list && blockIdx.x >= *a.redo_n) return;
+        const uint32_t job = a.redo_list ? a.redo_list[blockIdx.x] : blockIdx.x, slot = job / a.group;
         if (slot >= a.nslots) return;
         const uint32_t w = a.w0 + slot, k = a.k0 + job % a.group;
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
         uint32_t cls = CB;
         if (k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + k + 1] - a.b.seq_off[s0 + k]));
-        if (cls == (uint32_t)CA) { vc_fwd_any<CA, RING, PACKED>(a, ring_raw); return; }
+        if (cls == (uint32_t)CA) { vc_fwd_any<CA, RING, PACKED, KEPT>(a, ring_raw); return; }
     }
-    vc_fwd_any<CB, RING, PACKED>(a, ring_raw);
+    vc_fwd_any<CB, RING, PACKED, KEPT>(a, ring_raw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1536,7 +1751,7 @@ __global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_
             int c0m = VC_INT_MIN;
             for (uint32_t p = 0; p < np; ++p) {
                 uint32_t delta;
-                if (isovf) delta = a.dp.ovf[eb + rec.y + p];
+                if (isovf) { delta = a.dp.ovf[eb + rec.y + p]; if (a.kept && (delta & 0x8000u)) delta &= 0x7Fu; }   // kept-row ring: forward form of the entry
                 else { const uint32_t wsel = p < 2 ? rec.y : (p < 4 ? rec.z : rec.w); delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF); }
                 const uint32_t pr = i - delta;
                 int hv[C], hl, c0p;
@@ -1680,6 +1895,10 @@ struct VcTraceArgs {
     unsigned long long* stat;   // [VC_STAT_SLOTS][8], see vc_ctx::d_stat
     const int* wmat; uint64_t wstride; uint32_t wcols; const int* c0w;   // matrices of k_fwd_wide (job types 2, 3)
     int packed;                 // stored row form of this launch's k_fwd (byte-packed rows or raw int16 pairs)
+    uint32_t kept;              // != 0: long predecessor lists (VcDp::ovf) are in the forward form of the kept-row ring (vc_frec_kept)
+    const uint32_t* bmat; const uint32_t* band_par; int band;     // banded matrix store of this launch's k_fwd (see vc_band_start)
+    const uint32_t* redo_list; const uint32_t* redo_n;            // != nullptr: walk the listed jobs (their matrices were stored whole again)
+    uint32_t* redo_out; uint32_t* redo_out_n;                     // band != 0: jobs whose walk needed a cell outside the band
     int only_wide;              // k_trace: take only those jobs (k_tracew walked the rest)
     int shared_table;           // k_tracew: the VC_TG alignments of a wave share a window (group % VC_TG == 0)
     uint32_t tab_rows;          // k_tracew: rows the LDS table is sized for (>= every graph's height in this launch)
@@ -1744,7 +1963,7 @@ __global__ void k_trace(VcTraceArgs a) {
                 const bool isovf = ((rec.x >> 8) & VC_RF_OVF) != 0;
                 const uint32_t np = isovf ? rec.z : ((rec.x >> 16) & 0xFF);
                 auto delta_of = [&](uint32_t p) -> uint32_t {
-                    if (isovf) return a.dp.ovf[eb + rec.y + p];
+                    if (isovf) { const uint32_t e = a.dp.ovf[eb + rec.y + p]; return (a.kept && (e & 0x8000u)) ? (e & 0x7Fu) : e; }
                     const uint32_t wsel = p < 2 ? rec.y : (p < 4 ? rec.z : rec.w);
                     return (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
                 };
@@ -1844,8 +2063,15 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     uint8_t* tab = smem + (shared_tab ? 0u : grp) * vc_tracew_tab_len(a.tab_rows);
 #endif
     const uint32_t njobs = a.nslots * a.group;
-    const uint32_t job = blockIdx.x * VC_TG + grp;
+    const bool redo = a.redo_list != nullptr;
+    uint32_t job = blockIdx.x * VC_TG + grp;
     bool valid = job < njobs;
+    if (redo) {                                               // second pass: the jobs the first one gave up on
+        const uint32_t nr = *a.redo_n;
+        if (blockIdx.x * VC_TG >= nr) return;
+        valid = job < nr;
+        job = valid ? a.redo_list[job] : 0u;
+    }
     const uint32_t slot = valid ? job / a.group : 0, k = valid ? a.k0 + job % a.group : 0;
     const uint32_t w = a.w0 + slot;
     const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
@@ -1865,6 +2091,11 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
     const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
     const bool packed = a.packed != 0;
+    // banded store: global alignments of a banded launch keep VC_BAND_LANES lanes per row around the rank diagonal
+    const bool band = a.band != 0 && !redo && valid && type == 1;
+    const uint32_t* bm32 = a.bmat + (uint64_t)(valid ? job : 0) * (a.hstride / 4);
+    const uint32_t band_rb = band ? a.band_par[2 * job] : 0u, band_ql = band ? a.band_par[2 * job + 1] : 0u;
+    bool oob = false;                                          // this lane asked for a cell outside the band (its value is then meaningless)
     const uint32_t nrows = valid ? min(a.dp.nrows[slot], a.tab_rows) : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
     // horizontal T == T', SW stop T == -col*g.  (The runtime division by cpl stays: a multiply-high in its place made the
@@ -1873,6 +2104,11 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         if (r == 0) return nw ? 0 : -(int)col * g;
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
+        if (band) {
+            const uint32_t bl = lc - vc_band_start(r, band_rb, band_ql);
+            if (bl >= (uint32_t)VC_BAND_LANES) { oob = true; return 0; }
+            return vc_packed_cell(bm32 + ((uint64_t)(r - 1) * VC_BAND_LANES + bl) * nds, cc, cpl);
+        }
         if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl);
         return (int)(short)hm[((uint64_t)(r - 1) * nd * 64 + (cc >> 1) * 64 + lc) * 2 + (cc & 1)];
     };
@@ -1884,6 +2120,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     auto gmask = [&](unsigned long long mm) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(mm >> gbase) & 0xFFFFu; };
 
     bool walking = valid && end != 0;
+    bool gredo = false;                                       // this alignment goes on the redo list
     if (shared_tab) {
         // every lane of the wave has the same slot; the first valid lane's view of it is everybody's
         const unsigned long long vm = __ballot(valid);
@@ -1925,6 +2162,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     if (walking) {
         gT = Tat(gi, gj);
         if (gi) grec = a.dp.rec[nb + gi - 1];
+        if (oob) { gredo = true; walking = false; }           // (cannot happen: the band ends on the end cell)
     }
     for (;;) {
         if (walking && (nw ? (gi == 0 && gj == 0) : (gT == -(int)gj * g))) walking = false;
@@ -1964,6 +2202,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         int tv = 0;
         uint32_t bs = 0;
         uint4 rnext = zero4;
+        oob = false;
         if (lb) {
             bs = a.b.bases[so + jk - 1];
             if (my_in) rnext = a.dp.rec[nb + my_in - 1];
@@ -1972,7 +2211,8 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         }
         const uint32_t codek = (uint32_t)vc_row_shr1((int)rnext.x, (int)grec.x) & 0xFF;       // code of position k's row
         const int tprev = vc_row_shr1(tv, gT);                                               // T at position k
-        bool ok = lb && tprev == tv + (((bs == codek) ? m : n) - g);
+        // a speculated cell outside the band confirms nothing: the walk stops in front of it and the general step decides
+        bool ok = lb && !oob && tprev == tv + (((bs == codek) ? m : n) - g);
         if (!nw && tprev == -(int)jk * g) ok = false;                   // SW: the walk ends at this position
         // ---- C: longest confirmed prefix
         uint32_t f = 0;
@@ -2005,6 +2245,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
             bool found = false, have_v = false;
             uint32_t v_pi = 0; int v_hv = 0; uint4 v_rec = zero4;
             int hz = 0;                                                  // lane 15 of the group: T[gi][gj-1]
+            oob = false;
             if (need && gl == VC_TL - 1 && gj != 0) hz = Tat(gi, gj - 1);
             const bool isovf = ((grec.x >> 8) & VC_RF_OVF) != 0;
             const uint32_t np = (need && gi != 0) ? (isovf ? grec.z : ((grec.x >> 16) & 0xFF)) : 0u;
@@ -2016,7 +2257,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
                 const bool act = !found && (isd || isv) && p < np && (!isd || gj != 0) && (isd || !have_v);
                 uint32_t delta = 0;
                 if (act) {
-                    if (isovf) delta = a.dp.ovf[eb + grec.y + p];
+                    if (isovf) { delta = a.dp.ovf[eb + grec.y + p]; if (a.kept && (delta & 0x8000u)) delta &= 0x7Fu; }
                     else {
                         const uint32_t wsel = p < 2 ? grec.y : (p < 4 ? grec.z : grec.w);
                         delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
@@ -2041,11 +2282,17 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
                 else if (take_v) { v_pi = s_pr; v_hv = s_cv; v_rec = s_rr; have_v = true; }
             }
             if (need && !found && have_v) { pi_ = v_pi; pj_ = gj; hv = v_hv; nrec = v_rec; found = true; }
+            if (a.band) {
+                // a candidate of this step lay outside the band: the decision cannot be taken from what is stored -- give the
+                // alignment up here; k_fwd stores its matrix whole in the redo pass and the walk is done again from there
+                const bool goob = gmask(__ballot(oob && need)) != 0;
+                if (need && goob) { gredo = true; walking = false; }
+            }
             {
                 const int v = __shfl(hz, (int)(gbase + VC_TL - 1), 64);
                 if (need && !found && gj != 0 && gT == v) { pi_ = gi; pj_ = gj - 1; hv = v; nrec = grec; found = true; }
             }
-            if (need) {
+            if (need && !gredo) {
                 if (!found) { gbroken = true; walking = false; }
                 else if (gnout >= a.PC) { govf = true; walking = false; }
                 else {
@@ -2057,8 +2304,9 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         }
     }
     if (valid && gl == 0) {
-        if (gbroken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, gi); gnout = 0; }
-        if (govf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, gnout); gnout = 0; }
+        if (gredo) { gnout = 0; a.redo_out[atomicAdd(a.redo_out_n, 1u)] = job; }
+        else if (gbroken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, gi); gnout = 0; }
+        else if (govf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, gnout); gnout = 0; }
         a.npairs[pj] = gnout;
     }
     {   // statistics: summed over the wave first, then one of VC_STAT_SLOTS counter sets (a single set serialises in the L2)
@@ -2088,6 +2336,7 @@ struct VcAddArgs {
     uint16_t* scratch;            // [CW * (4*PC + NC)]
     uint32_t ring;                // rows k_fwd keeps in LDS (the row records of the NEXT layer are made at the end of this kernel)
     int make_rows;                // 0: leave the row records of THIS layer in place (vc_debug_stop_after looks at them)
+    uint32_t kept;                // != 0: slots of k_fwd's kept-row ring (the dynamic LDS then also covers vc_kept_lds_bytes(NC))
 };
 
 __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
@@ -2335,7 +2584,7 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
     }
     if (lane == 0) { a.g.n_nodes[slot] = N0 + nnew; a.g.n_edges[slot] = E0 + enew; }
     __syncthreads();
-    if (a.make_rows) vc_rows_full(a.b, a.g, a.dp, slot, w, a.NC, a.EC, (int)a.layer + 1, a.ring, N0 + nnew);   // the next layer's rows (full-span layers)
+    if (a.make_rows) vc_rows_full(a.b, a.g, a.dp, slot, w, a.NC, a.EC, (int)a.layer + 1, a.ring, N0 + nnew, a.kept, smem);   // the next layer's rows (full-span layers)
 }
 
 // ------------------------------------------------------------------------------------------------

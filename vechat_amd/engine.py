@@ -96,6 +96,7 @@ class HipContext:
         self._chk(self.lib.vc_get_stats(self.h, C.byref(s)), "vc_get_stats")
         d = dict(cells=int(s.cells), alignments=int(s.alignments), dp_rows=int(s.dp_rows), far_row_reads=int(s.far_row_reads), trace_steps=int(s.trace_steps), trace_spec=int(s.trace_spec), trace_rounds=int(s.trace_rounds),
                  max_nodes=int(s.max_nodes), max_edges=int(s.max_edges), chunk_windows=int(s.chunk_windows), n_streams=int(s.n_streams),
+                 band_redo=int(s.band_redo), device_bytes=int(s.device_bytes),
                  kernels={})
         for i in range(s.n_classes):
             d["kernels"][s.names[i].value.decode()] = dict(ms=float(s.ms[i]), launches=int(s.launches[i]), busy_ms=float(s.busy_ms[i]))
