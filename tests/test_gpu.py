@@ -1,6 +1,9 @@
 """GPU suite (-m gpu): the HIP path, driven through the C ABI, against the oracle and the golden
 fixtures.  Bar: bit-exact consensus bytes and status for every window."""
 import hashlib
+import json
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -11,6 +14,7 @@ from vechat_amd import capi
 from vechat_amd.engine import HipBatchProcessor, HipContext, VcError, create_window
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -449,3 +453,68 @@ def test_stage_digests_on_the_device(built):
                 got, want = got[:4], want[:4]
             assert got == want, (name, "first differing stage", k, e[:2], got, want)
     c.close()
+
+
+def test_backtracks_that_leave_the_stored_band(built):
+    """k_fwd stores 16 lanes per row around the rank diagonal; an alignment whose path leaves them (here: reads with a 140-base
+    insertion or deletion against their window) is put on the redo list, stored whole and walked again.  Same bytes as the
+    oracle, and the redo path did run."""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    wins, fasta = [], []
+    for w in range(6):
+        L = 520
+        bb = rng.choice(alpha, L)
+        seqs, quals, b, e = [bb.tobytes()], [b"5" * L], [0], [0]
+        for k in range(14):
+            r = bb.copy()
+            mut = rng.random(L) < 0.06
+            r[mut] = rng.choice(alpha, int(mut.sum()))
+            r = r.tobytes()
+            if k % 5 == 1:                                   # long insertion in the middle of the read
+                cut = 200 + 10 * k
+                r = r[:cut] + rng.choice(alpha, 110).tobytes() + r[cut:]
+            elif k % 5 == 3:                                 # long deletion
+                cut = 150 + 10 * k
+                r = r[:cut] + r[cut + 140:]
+            seqs.append(r); quals.append(bytes(rng.integers(40, 70, len(r), dtype=np.uint8))); b.append(0); e.append(L - 1)
+        wins.append((seqs, quals, b, e)); fasta.append(0)
+    batch = capi.Batch.from_windows(wins, fasta)
+    c = HipContext(device=0)
+    _check(c, batch, "band redo")
+    st = c.stats()
+    c.close()
+    assert st["band_redo"] > 0, st
+
+
+def test_command_line_refuses_windows_the_device_cannot_hold(built, tmp_path, capfd):
+    """a window whose graph does not fit the device (here: capacity pinned to 704 nodes, no retry -- the same path a
+    graph beyond the 16-bit id space takes after the retries) must not come out as silently different bytes: the command names
+    the windows and exits 3; with --keep-going it says so and emits them unpolished."""
+    from vechat_amd import polish
+    from test_seqio import write_inputs
+    fx, wb = fixtures.load_plumbing()
+    wb.close()
+    rp, op, tp = write_inputs(fx, tmp_path, sam=True)
+    argv = [str(rp), str(op), str(tp), "-p", "-d", "0.2", "-s", "0.2", "--max-nodes", "704", "--no-capacity-retry"]
+    assert polish.main(argv) == 3
+    out, err = capfd.readouterr()
+    assert out == "" and "could not be computed on the device" in err and "window" in err
+    assert polish.main(argv + ["--keep-going", "-u"]) == 0
+    out, err = capfd.readouterr()
+    assert out.count(">") == fx["n_targets"] and "kept as unpolished backbone" in err
+
+
+def test_two_ranks_on_two_devices(built, tmp_path):
+    """bench.py --gpus 2 on a box with at least two devices: two ranks over RCCL, n_gpus == 2, every window gathered."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--windows", "512", "--no-cpu",
+                          "--no-extras"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().split("\n")[-1])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["windows_not_ok"] == 0
+    assert line["config"]["windows_per_step"] == 1024
