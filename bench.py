@@ -15,7 +15,7 @@ The one JSON line also carries
   value_e2e   the same windows from host memory to host memory (vc_submit -> vc_run -> vc_collect, H2D and D2H
               included), two contexts double-buffering batches of 16 384 windows -- SURVEY 8(d)'s definition of the
               metric; `value` is the resident-input rate the driver's contract asks for
-  roofline    k_fwd: 4 B/cell model of SURVEY 8(d), measured HBM traffic (profiles/r2_hbm_traffic.json, refused when it
+  roofline    k_fwd: 4 B/cell model of SURVEY 8(d), measured HBM traffic (profiles/r3_hbm_traffic.json, refused when it
               was taken for other kernels than the ones built here), and the calibrated VALU issue bound
   cpu_baseline  the reference itself (oracle/_ref, built in place from /root/reference) on the host cores, bounded
   configs     windows/s on BASELINE configs B and E, short runs
@@ -307,18 +307,18 @@ def main():
                 # The same bytes over the time during which ANY k_fwd launch was running:
                 "busy_ms_per_step": fwd_busy_ms / a.steps, "frac_over_busy_time": BYTES_PER_CELL * cells / (fwd_busy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fwd_busy_ms > 0 else None,
                 "kernel_hash": khash}
-        # measured HBM bytes of k_fwd (rocprofv3 PMC passes; profiles/r2_hbm_traffic.json says for which kernel sources)
+        # measured HBM bytes of k_fwd (rocprofv3 PMC passes; profiles/r3_hbm_traffic.json says for which kernel sources)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")))
             if tj.get("kernel_hash") != khash:
-                roof["traffic_note"] = f"profiles/r2_hbm_traffic.json was measured for kernels {tj.get('kernel_hash')}, these are {khash}: not used"
+                roof["traffic_note"] = f"profiles/r3_hbm_traffic.json was measured for kernels {tj.get('kernel_hash')}, these are {khash}: not used"
             else:
                 roof["traffic"] = tj["bytes_per_cell"] * cells / max(fwd_launches, 1)
                 roof["hbm_frac_measured"] = tj["bytes_per_cell"] * cells / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 roof["hbm_frac_measured_over_busy_time"] = tj["bytes_per_cell"] * cells / (fwd_busy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 # the kernel moves less than the 4 B/cell model, so the VALU issue bound is stated beside it, against
                 # the issue rate MEASURED on this chip for the instructions k_fwd is made of (tools/valu_peak.hip)
-                vp = json.load(open(os.path.join(ROOT, "profiles", "r2_valu_peak.json")))
+                vp = json.load(open(os.path.join(ROOT, "profiles", "r3_valu_peak.json")))
                 simds = torch.cuda.get_device_properties(local).multi_processor_count * 4
                 ipr = tj["instructions_per_dp_row"]["VALU"]
                 roof["valu_issue"] = {"valu_insts_per_dp_row": ipr, "dp_rows_per_step": rows / a.steps, "simds": simds,

@@ -1109,9 +1109,14 @@ __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp
 // compact band matrix [row][VC_BAND_LANES][NDS].  Rows that a later row reads back from the stored matrix (VC_RF_FULL, set
 // by the row builders) are also written whole, as before.  A backtrack that needs a cell outside the band gives up and
 // puts its alignment on a redo list: k_fwd runs again for those (whole rows), and the backtrack walks them from there.
-// Both kernels take the band of a row from the same two numbers per alignment (VcFwdArgs::band_par): first row and slope.
-__device__ __forceinline__ uint32_t vc_band_start(uint32_t i, uint32_t rb, uint32_t ql) {
-    const uint32_t t = i > rb ? (uint32_t)(((unsigned long long)(i - rb) * ql) >> 16) : 0u;     // lane of the diagonal at row i
+// Both kernels take the band of a row from the same number per alignment (VcFwdArgs::band_par): the slope of the diagonal.
+__device__ __forceinline__ uint32_t vc_band_slope(uint32_t len, uint32_t nrows, uint32_t cpl) {   // lanes per row, 16.16 fixed point
+    return min((uint32_t)((((unsigned long long)len << 16) / nrows) / cpl), 0xFFFFFFu);
+}
+__device__ __forceinline__ uint32_t vc_band_start(uint32_t i, uint32_t ql) {
+    // lane of the diagonal at row i (i <= rows, so i * ql < 2^22 * ... fits 32 bits; the 24-bit multiply is the fast one).  Any
+    // function would do as long as k_fwd and the backtrack use the same: a band that misses the path only costs a redo
+    const uint32_t t = __umul24(i, ql) >> 16;
     return min(max(t, (uint32_t)(VC_BAND_LANES / 2 - 1)) - (VC_BAND_LANES / 2 - 1), 64u - VC_BAND_LANES);
 }
 
@@ -1139,7 +1144,7 @@ struct VcFwdArgs {
     uint32_t wcols;                // != 0: k_fwd_wide follows this launch and takes what the packed-int16 kernel declines
     uint32_t kept;                 // build phase: slots of the kept-row ring the forward records were made for (0: plain ring)
     uint32_t* bmat;                // band matrix of a job: bmat + job * (hstride / 4)
-    uint32_t* band_par;            // [jobs * 2] first row and slope (lanes per row, 16.16) of the job's band
+    uint32_t* band_par;            // [jobs] slope (lanes per row, 16.16) of the job's band
     int band;                      // 1: global alignments store the band (+ whole rows where VC_RF_FULL asks for them)
     const uint32_t* redo_list;     // != nullptr: this launch re-runs the listed jobs with whole rows (the backtrack left the band)
     const uint32_t* redo_n;
@@ -1321,8 +1326,8 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     // banded store: global alignments only (a local alignment may end and start anywhere), byte-packed rows only
     const bool band = NWT && PACKED && a.band && !redo;
     uint32_t* const brow0 = a.bmat + (uint64_t)job * (a.hstride / 4);
-    const uint32_t band_rb = 0, band_ql = (uint32_t)((((unsigned long long)len << 16) / nrows) / CPL);
-    if (band && lane == 0) { a.band_par[2 * job] = band_rb; a.band_par[2 * job + 1] = band_ql; }
+    const uint32_t band_ql = vc_band_slope(len, nrows, CPL);
+    if (band && lane == 0) a.band_par[job] = band_ql;
     int bvec = 0;                             // lane t: first band lane of row (block * 64 + t + 1)
     int16_t* const c0p_out = a.c0 + (uint64_t)job * a.NC;
     const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
@@ -1497,7 +1502,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
           const uint32_t r = i0 - 1 + 64 + lane;
           if (r < nrows) nextrec = a.dp.frec[nb + r];
       }
-      if (band) bvec = (int)vc_band_start(i0 + (uint32_t)lane, band_rb, band_ql);
+      if (band) bvec = (int)vc_band_start(i0 + (uint32_t)lane, band_ql);
       const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, nrows - i0 + 1));
       for (uint32_t ri = 0; ri < cnt; ++ri) {
         const uint32_t i = i0 + ri;
@@ -1669,9 +1674,15 @@ __device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_ra
 
 // CA <= CB: the two adjacent width classes of a batch share one launch (register and LDS budget of the
 // wider one); each alignment takes the narrowest body that holds its sequence.  CA == CB: single class.
+#ifndef VC_FWD_OCC
+#define VC_FWD_OCC            // development: e.g. -DVC_FWD_OCC='__attribute__((amdgpu_waves_per_eu(4,4)))' caps the forward kernel's waves per SIMD
+#endif
 template <int CA, int CB, int RING, bool PACKED, bool KEPT>
-__global__ __launch_bounds__(64) void k_fwd(VcFwdArgs a) {
+__global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
     __shared__ uint32_t ring_raw[RING * (CB / 2) * 64];
+#ifdef VC_FWD_VGPR_PAD
+    asm volatile("; keep the register allocation at 104: four forward waves per SIMD leave LDS and registers to the other kernels" ::: "v103");
+#endif
     if (CA != CB) {
         // sequence length of this job decides the body (uniform per wave)
         if (a.redo_list && blockIdx.x >= *a.redo_n) return;
@@ -2094,7 +2105,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     // banded store: global alignments of a banded launch keep VC_BAND_LANES lanes per row around the rank diagonal
     const bool band = a.band != 0 && !redo && valid && type == 1;
     const uint32_t* bm32 = a.bmat + (uint64_t)(valid ? job : 0) * (a.hstride / 4);
-    const uint32_t band_rb = band ? a.band_par[2 * job] : 0u, band_ql = band ? a.band_par[2 * job + 1] : 0u;
+    const uint32_t band_ql = band ? a.band_par[job] : 0u;
     bool oob = false;                                          // this lane asked for a cell outside the band (its value is then meaningless)
     const uint32_t nrows = valid ? min(a.dp.nrows[slot], a.tab_rows) : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
@@ -2105,7 +2116,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
         if (band) {
-            const uint32_t bl = lc - vc_band_start(r, band_rb, band_ql);
+            const uint32_t bl = lc - vc_band_start(r, band_ql);
             if (bl >= (uint32_t)VC_BAND_LANES) { oob = true; return 0; }
             return vc_packed_cell(bm32 + ((uint64_t)(r - 1) * VC_BAND_LANES + bl) * nds, cc, cpl);
         }
