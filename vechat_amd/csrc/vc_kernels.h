@@ -2102,6 +2102,9 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
     const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
     const bool packed = a.packed != 0;
+#ifdef VC_TRACE_MAGIC
+    const uint32_t cmagic = vc_magic(cpl ? cpl : 4u);
+#endif
     // banded store: global alignments of a banded launch keep VC_BAND_LANES lanes per row around the rank diagonal
     const bool band = a.band != 0 && !redo && valid && type == 1;
     const uint32_t* bm32 = a.bmat + (uint64_t)(valid ? job : 0) * (a.hstride / 4);
@@ -2114,7 +2117,11 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     auto Tat = [&](uint32_t r, uint32_t col) __attribute__((always_inline)) -> int {
         if (r == 0) return nw ? 0 : -(int)col * g;
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
+#ifdef VC_TRACE_MAGIC
+        const uint32_t ci = col - 1, lc = __umulhi(ci, cmagic), cc = ci - lc * cpl;          // cpl <= 32, ci < 65536: exact (vc_magic)
+#else
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
+#endif
         if (band) {
             const uint32_t bl = lc - vc_band_start(r, band_ql);
             if (bl >= (uint32_t)VC_BAND_LANES) { oob = true; return 0; }
@@ -2338,6 +2345,9 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
 // reproduced with prefix sums over the pair list: new ids are handed out in alignment order exactly
 // as nodes_.size()/edges_.size() would grow.
 // ------------------------------------------------------------------------------------------------
+#ifndef VC_ADD_U
+#define VC_ADD_U 3             // blocks of 64 alignment pairs that k_addaln carries through its lookup chains side by side
+#endif
 struct VcAddArgs {
     VcBatchDev b;
     VcGraph g;
@@ -2378,52 +2388,90 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
     const uint32_t N0 = a.g.n_nodes[slot], E0 = a.g.n_edges[slot];
     int err = 0;
 
-    // pass A: choose the node of every aligned base; count new nodes
+    // pass A: choose the node of every aligned base; count new nodes.  The lookups of a pair are a chain (pair -> node -> its
+    // position, code and aligned mates -> their positions and codes); VC_ADD_U blocks of 64 pairs go through it level by level,
+    // so that a lane has the loads of several pairs in flight instead of one chain after the other
     uint32_t nnew = 0, nvalid = 0;
-    for (uint32_t f0 = 0; f0 < P; f0 += 64) {
-        const uint32_t f = f0 + lane;
-        const bool act = f < P;
-        uint32_t pv = act ? pr[P - 1 - f] : 0;
-        const uint32_t row = pv >> 16, col = pv & 0xFFFF;
-        const bool valid = act && col != 0;
-        uint32_t curr = VC_NONE16;
-        bool isnew = false;
-        if (act) {
-            s_row[f] = (uint16_t)row;
-            if (row != 0) {
-                const uint32_t nd = a.dp.rank2node[nb + row - 1];
-                const uint32_t pn = a.g.pos[nb + nd];
-                uint32_t bs = pn, be = pn;
-                const uint32_t cnt = a.g.al_cnt[nb + nd];
-                for (uint32_t t = 0; t < cnt; ++t) {
-                    const uint32_t pa = a.g.pos[nb + a.g.al[(nb + nd) * a.g.ma + t]];
-                    bs = min(bs, pa); be = max(be, pa);
-                }
-                s_pn[f] = (uint16_t)pn; s_bs[f] = (uint16_t)bs; s_be[f] = (uint16_t)be;
+    constexpr int AU = VC_ADD_U, AM = 4;                      // AM: aligned mates fetched with the node (longer lists: the loop below)
+    const uint32_t ma = a.g.ma;
+    for (uint32_t f0 = 0; f0 < P; f0 += 64 * AU) {
+        uint32_t pv[AU], nd[AU], cb[AU], pn[AU], cnt[AU], cd[AU], alv[AU][AM], pa[AU][AM], ca[AU][AM];
+        bool act[AU];
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const uint32_t f = f0 + 64 * u + lane;
+            act[u] = f < P;
+            pv[u] = act[u] ? pr[P - 1 - f] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const uint32_t row = pv[u] >> 16, col = pv[u] & 0xFFFF;
+            nd[u] = (act[u] && row != 0) ? (uint32_t)a.dp.rank2node[nb + row - 1] : 0u;
+            cb[u] = (act[u] && col != 0) ? (uint32_t)a.b.bases[so + col - 1] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            pn[u] = 0; cnt[u] = 0; cd[u] = 0;
+#pragma unroll
+            for (int t = 0; t < AM; ++t) alv[u][t] = 0;
+            if (act[u] && (pv[u] >> 16) != 0) {
+                pn[u] = a.g.pos[nb + nd[u]];
+                cnt[u] = a.g.al_cnt[nb + nd[u]];
+                cd[u] = a.g.code[nb + nd[u]];
+#pragma unroll
+                for (int t = 0; t < AM; ++t) if ((uint32_t)t < ma) alv[u][t] = a.g.al[(nb + nd[u]) * ma + t];
             }
         }
-        if (valid) {
-            const uint8_t c = a.b.bases[so + col - 1];
-            if (row == 0) isnew = true;                                    // graph.cpp:249-251
-            else {
-                const uint32_t nd = a.dp.rank2node[nb + row - 1];
-                if (a.g.code[nb + nd] == c) curr = nd;                     // :254-257
-                else {
-                    const uint32_t cnt = a.g.al_cnt[nb + nd];
-                    for (uint32_t t = 0; t < cnt; ++t) {                   // :258-266
-                        const uint32_t al = a.g.al[(nb + nd) * a.g.ma + t];
-                        if (a.g.code[nb + al] == c) { curr = al; break; }
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+#pragma unroll
+            for (int t = 0; t < AM; ++t) {
+                pa[u][t] = 0; ca[u][t] = 0;
+                if ((uint32_t)t < cnt[u]) { pa[u][t] = a.g.pos[nb + alv[u][t]]; ca[u][t] = a.g.code[nb + alv[u][t]]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const uint32_t f = f0 + 64 * u + lane;
+            const uint32_t row = pv[u] >> 16, col = pv[u] & 0xFFFF;
+            const bool valid = act[u] && col != 0;
+            uint32_t curr = VC_NONE16;
+            bool isnew = false;
+            if (act[u]) {
+                s_row[f] = (uint16_t)row;
+                if (row != 0) {
+                    uint32_t bs = pn[u], be = pn[u];
+#pragma unroll
+                    for (int t = 0; t < AM; ++t) if ((uint32_t)t < cnt[u]) { bs = min(bs, pa[u][t]); be = max(be, pa[u][t]); }
+                    for (uint32_t t = AM; t < cnt[u]; ++t) {              // alphabets beyond five bytes
+                        const uint32_t pa2 = a.g.pos[nb + a.g.al[(nb + nd[u]) * ma + t]];
+                        bs = min(bs, pa2); be = max(be, pa2);
                     }
-                    if (curr == VC_NONE16) isnew = true;                   // :267-277
+                    s_pn[f] = (uint16_t)pn[u]; s_bs[f] = (uint16_t)bs; s_be[f] = (uint16_t)be;
                 }
             }
+            if (valid) {
+                if (row == 0) isnew = true;                                    // graph.cpp:249-251
+                else if (cd[u] == cb[u]) curr = nd[u];                         // :254-257
+                else {
+#pragma unroll
+                    for (int t = AM - 1; t >= 0; --t) if ((uint32_t)t < cnt[u] && ca[u][t] == cb[u]) curr = alv[u][t];   // :258-266, first match wins
+                    if (curr == VC_NONE16) {
+                        for (uint32_t t = AM; t < cnt[u]; ++t) {
+                            const uint32_t al = a.g.al[(nb + nd[u]) * ma + t];
+                            if (a.g.code[nb + al] == cb[u]) { curr = al; break; }
+                        }
+                    }
+                    if (curr == VC_NONE16) isnew = true;                       // :267-277
+                }
+            }
+            uint32_t tot;
+            const uint32_t my = wave_excl_sum(isnew ? 1u : 0u, tot);
+            if (isnew) curr = N0 + nnew + my;
+            if (act[u]) s_curr[f] = valid ? (uint16_t)curr : VC_NONE16;
+            nnew += tot;
+            nvalid += __popcll(__ballot(valid));
         }
-        uint32_t tot;
-        const uint32_t my = wave_excl_sum(isnew ? 1u : 0u, tot);
-        if (isnew) curr = N0 + nnew + my;
-        if (act) s_curr[f] = valid ? (uint16_t)curr : VC_NONE16;
-        nnew += tot;
-        nvalid += __popcll(__ballot(valid));
     }
     // every base must be aligned (NW alignments always are); otherwise the reference would add
     // unaligned prefix/suffix chains (graph.cpp:233-236), which this flow never produces
@@ -2479,75 +2527,122 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
         }
     }
 
-    // pass C: edges between consecutive aligned bases (graph.cpp:282-290 -> AddEdge :94-107)
+    // pass C: edges between consecutive aligned bases (graph.cpp:282-290 -> AddEdge :94-107), VC_ADD_U blocks of pairs level by
+    // level like pass A.  A path meets a node once: it is `prev` of one pair and `curr` of one pair, so the list heads, tails and
+    // node records the pairs of different blocks touch are different words and the blocks can go side by side.
     uint32_t enew = 0;
     uint32_t carry_prev = VC_NONE16;                   // node of the last aligned base of earlier chunks
-    for (uint32_t f0 = 0; f0 < P; f0 += 64) {
-        const uint32_t f = f0 + lane;
-        const bool act = f < P;
-        const uint32_t pv = act ? pr[P - 1 - f] : 0;
-        const uint32_t col = pv & 0xFFFF;
-        const uint32_t curr = act ? s_curr[f] : VC_NONE16;
-        const bool valid = act && col != 0;
-        // previous aligned base: nearest lower lane with valid, else carry
-        const unsigned long long vm = __ballot(valid);
-        const unsigned long long below = vm & ((1ull << lane) - 1ull);
-        const int src = below ? 63 - __clzll((long long)below) : lane;
-        const uint32_t pv_prev = (uint32_t)__shfl((int)curr, src, 64);     // outside divergent code
-        const uint32_t prev = below ? pv_prev : carry_prev;
-        bool make = false;
-        uint32_t wgt = 0;
-        if (valid && prev != VC_NONE16) {
-            const uint32_t q = col - 1;
-            wgt = vc_weight(a.b, so, q - 1, hq) + vc_weight(a.b, so, q, hq);
-            uint32_t found = VC_NONE16;
-            if (prev < N0 && curr < N0) {
-                for (uint32_t e = a.g.out_first[nb + prev]; e != VC_NONE16; ) {
-                    const uint32_t hn = a.g.e_hn[eb + e];
-                    if ((hn & 0xFFFF) == curr) { found = e; break; }
-                    e = hn >> 16;
+    for (uint32_t f0 = 0; f0 < P; f0 += 64 * AU) {
+        uint32_t col[AU], curr[AU], prev[AU], wgt[AU], e0[AU], qa[AU], qb[AU], found[AU];
+        bool valid[AU], link[AU], make[AU];
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const uint32_t f = f0 + 64 * u + lane;
+            const bool act = f < P;
+            col[u] = act ? (pr[P - 1 - f] & 0xFFFF) : 0u;
+            curr[u] = act ? (uint32_t)s_curr[f] : (uint32_t)VC_NONE16;
+            valid[u] = act && col[u] != 0;
+        }
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            // previous aligned base: nearest lower lane with valid, else carry
+            const unsigned long long vm = __ballot(valid[u]);
+            const unsigned long long below = vm & ((1ull << lane) - 1ull);
+            const int src = below ? 63 - __clzll((long long)below) : lane;
+            const uint32_t pv_prev = (uint32_t)__shfl((int)curr[u], src, 64);     // outside divergent code
+            prev[u] = below ? pv_prev : carry_prev;
+            if (vm) {
+                const int last = 63 - __clzll((long long)vm);
+                carry_prev = (uint32_t)__shfl((int)curr[u], last, 64);
+            }
+            link[u] = valid[u] && prev[u] != VC_NONE16;
+        }
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            qa[u] = 0; qb[u] = 0; e0[u] = VC_NONE16;
+            if (link[u]) {
+                if (hq) { qa[u] = a.b.quals[so + col[u] - 2]; qb[u] = a.b.quals[so + col[u] - 1]; }
+                if (prev[u] < N0 && curr[u] < N0) e0[u] = a.g.out_first[nb + prev[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            wgt[u] = 0; found[u] = VC_NONE16;
+            if (link[u]) wgt[u] = hq ? a.b.lut_w[qa[u]] + a.b.lut_w[qb[u]] : 2u;
+        }
+        // the edge prev -> curr, if it exists: walk prev's out-list (all blocks step together)
+        for (;;) {
+            bool more = false;
+            uint32_t hn[AU];
+#pragma unroll
+            for (int u = 0; u < AU; ++u) hn[u] = e0[u] != VC_NONE16 ? a.g.e_hn[eb + e0[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < AU; ++u) {
+                if (e0[u] != VC_NONE16) {
+                    if ((hn[u] & 0xFFFF) == curr[u]) { found[u] = e0[u]; e0[u] = VC_NONE16; }
+                    else e0[u] = hn[u] >> 16;
                 }
+                more |= e0[u] != VC_NONE16;
             }
-            if (found != VC_NONE16) a.g.e_w[eb + found] += wgt;
-            else make = true;
+            if (!__any(more)) break;
         }
-        uint32_t tot;
-        const uint32_t my = wave_excl_sum(make ? 1u : 0u, tot);
-        if (make) {
-            const uint32_t e = E0 + enew + my;
-            if (e >= a.EC || e >= 0xFFFF) err = VC_WIN_OVERFLOW;
-            else {
-                a.g.e_tn[eb + e] = prev | ((uint32_t)VC_NONE16 << 16);
-                a.g.e_hn[eb + e] = curr | ((uint32_t)VC_NONE16 << 16);
-                a.g.e_w[eb + e] = wgt;
-                // append to prev's out-list
-                const uint32_t ol = prev < N0 ? a.g.out_last[nb + prev] : VC_NONE16;
-                if (ol == VC_NONE16) a.g.out_first[nb + prev] = (uint16_t)e;
-                else a.g.e_hn[eb + ol] = (a.g.e_hn[eb + ol] & 0xFFFF) | (e << 16);
-                a.g.out_last[nb + prev] = (uint16_t)e;
-                // append to curr's in-list
-                const uint32_t il = curr < N0 ? a.g.in_last[nb + curr] : VC_NONE16;
-                if (il == VC_NONE16) a.g.in_first[nb + curr] = (uint16_t)e;
-                else a.g.e_tn[eb + il] = (a.g.e_tn[eb + il] & 0xFFFF) | (e << 16);
-                a.g.in_last[nb + curr] = (uint16_t)e;
-                // node record: the tail joins the head's inline predecessor list (a path meets a node once, so a node gains
-                // at most one in-edge per call and no two lanes touch the same record)
-                uint4 nr = a.g.nrec[nb + curr];
-                const uint32_t k = nr.x >> 16;
-                if (k == 0) nr.y = prev;
-                else if (k == 1) nr.y |= prev << 16;
-                else if (k == 2) nr.z = prev;
-                else if (k == 3) nr.z |= prev << 16;
-                else if (k == 4) nr.w = prev;
-                else if (k == 5) nr.w |= prev << 16;
-                nr.x += 1u << 16;
-                a.g.nrec[nb + curr] = nr;
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            make[u] = false;
+            if (link[u]) {
+                if (found[u] != VC_NONE16) a.g.e_w[eb + found[u]] += wgt[u];
+                else make[u] = true;
             }
         }
-        enew += tot;
-        if (vm) {
-            const int last = 63 - __clzll((long long)vm);
-            carry_prev = (uint32_t)__shfl((int)curr, last, 64);
+        // new edges: ids in path order; list tails and node records of all blocks first, then the writes
+        uint32_t eid[AU], ol[AU], il[AU];
+        uint4 nr[AU];
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            uint32_t tot;
+            const uint32_t my = wave_excl_sum(make[u] ? 1u : 0u, tot);
+            eid[u] = E0 + enew + my;
+            enew += tot;
+            if (make[u] && (eid[u] >= a.EC || eid[u] >= 0xFFFF)) { err = VC_WIN_OVERFLOW; make[u] = false; }
+            ol[u] = VC_NONE16; il[u] = VC_NONE16; nr[u] = make_uint4(0, 0, 0, 0);
+            if (make[u]) {
+                if (prev[u] < N0) ol[u] = a.g.out_last[nb + prev[u]];
+                if (curr[u] < N0) il[u] = a.g.in_last[nb + curr[u]];
+                nr[u] = a.g.nrec[nb + curr[u]];
+            }
+        }
+        uint32_t hol[AU], til[AU];
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            hol[u] = (make[u] && ol[u] != VC_NONE16) ? a.g.e_hn[eb + ol[u]] : 0u;
+            til[u] = (make[u] && il[u] != VC_NONE16) ? a.g.e_tn[eb + il[u]] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            if (!make[u]) continue;
+            const uint32_t e = eid[u];
+            a.g.e_tn[eb + e] = prev[u] | ((uint32_t)VC_NONE16 << 16);
+            a.g.e_hn[eb + e] = curr[u] | ((uint32_t)VC_NONE16 << 16);
+            a.g.e_w[eb + e] = wgt[u];
+            // append to prev's out-list
+            if (ol[u] == VC_NONE16) a.g.out_first[nb + prev[u]] = (uint16_t)e;
+            else a.g.e_hn[eb + ol[u]] = (hol[u] & 0xFFFF) | (e << 16);
+            a.g.out_last[nb + prev[u]] = (uint16_t)e;
+            // append to curr's in-list
+            if (il[u] == VC_NONE16) a.g.in_first[nb + curr[u]] = (uint16_t)e;
+            else a.g.e_tn[eb + il[u]] = (til[u] & 0xFFFF) | (e << 16);
+            a.g.in_last[nb + curr[u]] = (uint16_t)e;
+            // node record: the tail joins the head's inline predecessor list (one new in-edge per node per call)
+            uint4 r4 = nr[u];
+            const uint32_t k = r4.x >> 16;
+            if (k == 0) r4.y = prev[u];
+            else if (k == 1) r4.y |= prev[u] << 16;
+            else if (k == 2) r4.z = prev[u];
+            else if (k == 3) r4.z |= prev[u] << 16;
+            else if (k == 4) r4.w = prev[u];
+            else if (k == 5) r4.w |= prev[u] << 16;
+            r4.x += 1u << 16;
+            a.g.nrec[nb + curr[u]] = r4;
         }
     }
     if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 8, E0 + enew); return; }
