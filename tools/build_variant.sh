@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p vechat_amd/lib/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I include "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -structurizecfg-skip-uniform-regions -I include "$@" \
   vechat_amd/csrc/vc_api.hip vechat_amd/csrc/vc_align.hip vechat_amd/csrc/vc_host.cpp vechat_amd/csrc/vc_windows.cpp \
   -o vechat_amd/lib/variants/libvechat_hip_$name.so
 echo built $name

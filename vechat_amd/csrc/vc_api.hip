@@ -66,7 +66,7 @@ struct Work {
     VcDp dp{};
     int* d_wmat = nullptr; int* d_c0w = nullptr;         // k_fwd_wide: [jobs_cap * NC * wcols] tilted int32 scores, [jobs_cap * NC] column 0
     uint32_t* d_hmat = nullptr; int16_t* d_c0 = nullptr; uint8_t* d_resolve_ws = nullptr;
-    uint32_t* d_bmat = nullptr; uint32_t* d_band_par = nullptr;     // banded matrix store: [hmat_dwords / 4] band rows, [jobs_cap * 2] band of a job
+    uint32_t* d_bmat = nullptr; uint32_t* d_band_par = nullptr;     // banded matrix store: tiled band rows (vc_band_job_dwords per job), [jobs_cap * 2] band of a job
     uint32_t* d_redo_list = nullptr; uint32_t* d_redo_n = nullptr;  // jobs whose backtrack left the band (re-run with whole rows)
     uint8_t* d_big_ws = nullptr;        // [CW * big_ws_stride] graph images that do not fit the LDS (k_topo / k_prune_lcc / k_consensus)
     uint32_t* d_job_end = nullptr; uint8_t* d_job_type = nullptr;
@@ -245,7 +245,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, c->hmat_dwords / 4 + 64)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, c->hmat_dwords / 4 + (size_t)c->jobs_cap * VC_BAND_JOB_PAD_DWORDS + 64)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_band_par, (size_t)c->jobs_cap * 2)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_list, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_n, 4)) ||

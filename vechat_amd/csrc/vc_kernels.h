@@ -1105,10 +1105,15 @@ __global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp
 // ------------------------------------------------------------------------------------------------
 // Banded matrix store.  The backtrack of a global alignment stays close to the rank diagonal -- row i meets column
 // i * len / rows -- so k_fwd writes, per row, only the VC_BAND_LANES lanes around it (192 instead of 768 bytes at 10 cells
-// per lane: the stored matrix is 62 % of all the bytes this path moves through HBM, and HBM is what bounds it), into a
-// compact band matrix [row][VC_BAND_LANES][NDS].  Rows that a later row reads back from the stored matrix (VC_RF_FULL, set
-// by the row builders) are also written whole, as before.  A backtrack that needs a cell outside the band gives up and
-// puts its alignment on a redo list: k_fwd runs again for those (whole rows), and the backtrack walks them from there.
+// per lane: the stored matrix is 62 % of all the bytes this path moves through HBM, and HBM is what bounds it).  Rows that a
+// later row reads back from the stored matrix (VC_RF_FULL, set by the row builders) are also written whole, as before.  A
+// backtrack that needs a cell outside the band gives up and puts its alignment on a redo list: k_fwd runs again for those
+// (whole rows), and the backtrack walks them from there.
+// Layout: [row][VC_BAND_LANES][NDS dwords]; the band lanes store under their own exec mask, worked out on the scalar side
+// (no per-row vector arithmetic for the band).  A TILED layout for the reader (-DVC_BAND_TILED=1: one 128-byte line holds the
+// stored form of ONE lane for 32 / NDS consecutive rows, so that a backtrack finds its next moves in the line it already
+// has) was built and measured in round 3: bytes fetched per move fall as intended, the backtrack gains 3 % and k_fwd loses
+// 5 % to the sixteen partial lines a row then writes -- the job is 1.5 % slower, so rows stay row-major.
 // Both kernels take the band of a row from the same number per alignment (VcFwdArgs::band_par): the slope of the diagonal.
 __device__ __forceinline__ uint32_t vc_band_slope(uint32_t len, uint32_t nrows, uint32_t cpl) {   // lanes per row, 16.16 fixed point
     return min((uint32_t)((((unsigned long long)len << 16) / nrows) / cpl), 0xFFFFFFu);
@@ -1119,6 +1124,20 @@ __device__ __forceinline__ uint32_t vc_band_start(uint32_t i, uint32_t ql) {
     const uint32_t t = __umul24(i, ql) >> 16;
     return min(max(t, (uint32_t)(VC_BAND_LANES / 2 - 1)) - (VC_BAND_LANES / 2 - 1), 64u - VC_BAND_LANES);
 }
+#ifndef VC_BAND_TILED
+#define VC_BAND_TILED 0        // development: 0 = row-major band rows [row][VC_BAND_LANES][NDS] (one row per block, a lane's NDS dwords per "tile")
+#endif
+__host__ __device__ constexpr uint32_t vc_band_tile_rows(uint32_t nds) { return VC_BAND_TILED ? 32u / nds : 1u; }      // rows per tile
+__host__ __device__ constexpr uint32_t vc_band_tile_bytes(uint32_t nds) { return VC_BAND_TILED ? 128u : nds * 4u; }   // one lane's tile
+__host__ __device__ constexpr uint32_t vc_band_block_bytes(uint32_t nds) { return VC_BAND_LANES * vc_band_tile_bytes(nds); }   // a row block: a tile per band lane
+#define VC_BAND_JOB_PAD_DWORDS (VC_BAND_LANES * 128u / 4u)
+__host__ __device__ inline uint64_t vc_band_job_dwords(uint64_t hstride) { return hstride / 4 + VC_BAND_JOB_PAD_DWORDS; }   // + the last, partial block
+__device__ __forceinline__ uint32_t vc_band_tile_of_row(uint32_t r1, uint32_t tile_rows, uint32_t tile_magic) {       // r1 = row - 1 < 65536
+    (void)tile_rows;
+    return VC_BAND_TILED ? __umulhi(r1, tile_magic) : r1;
+}
+// first band lane of row block tb (rows tb * TR + 1 ...): the diagonal at the block's middle
+__device__ __forceinline__ uint32_t vc_band_block_start(uint32_t tb, uint32_t tr, uint32_t ql) { return vc_band_start(tb * tr + 1u + tr / 2u, ql); }
 
 struct VcFwdArgs {
     VcBatchDev b;
@@ -1143,7 +1162,7 @@ struct VcFwdArgs {
     unsigned long long* stat;      // [4] cells, rows, -, far-row reads
     uint32_t wcols;                // != 0: k_fwd_wide follows this launch and takes what the packed-int16 kernel declines
     uint32_t kept;                 // build phase: slots of the kept-row ring the forward records were made for (0: plain ring)
-    uint32_t* bmat;                // band matrix of a job: bmat + job * (hstride / 4)
+    uint32_t* bmat;                // band matrix of a job: bmat + job * vc_band_job_dwords(hstride), tiled (see vc_band_start)
     uint32_t* band_par;            // [jobs] slope (lanes per row, 16.16) of the job's band
     int band;                      // 1: global alignments store the band (+ whole rows where VC_RF_FULL asks for them)
     const uint32_t* redo_list;     // != nullptr: this launch re-runs the listed jobs with whole rows (the backtrack left the band)
@@ -1325,10 +1344,14 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     constexpr bool packed = PACKED;           // the stored row form is a property of the launch (host: both score sets fit the byte bound)
     // banded store: global alignments only (a local alignment may end and start anywhere), byte-packed rows only
     const bool band = NWT && PACKED && a.band && !redo;
-    uint32_t* const brow0 = a.bmat + (uint64_t)job * (a.hstride / 4);
+    const char* const brow0 = reinterpret_cast<const char*>(a.bmat + (uint64_t)job * vc_band_job_dwords(a.hstride));
     const uint32_t band_ql = vc_band_slope(len, nrows, CPL);
     if (band && lane == 0) a.band_par[job] = band_ql;
-    int bvec = 0;                             // lane t: first band lane of row (block * 64 + t + 1)
+    constexpr uint32_t TR = vc_band_tile_rows(NDS);
+    constexpr uint32_t TBB = vc_band_block_bytes(NDS), TLB = vc_band_tile_bytes(NDS);
+    uint32_t t_rin = TR, t_off = 0u - TBB;                     // row inside the current block, byte offset of the block (scalars)
+    unsigned long long t_mask = 0;                             // lanes of the block's band
+    uint32_t t_lane = 0;                                       // my byte offset inside a block: (lane - first band lane) * 128
     int16_t* const c0p_out = a.c0 + (uint64_t)job * a.NC;
     const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
 
@@ -1350,7 +1373,6 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
     constexpr uint32_t rowdw = PACKED ? NDS * 64 : ND * 64;     // dwords per stored row
     uint32_t voff = (PACKED ? lane * NDS : lane) * 4u;          // my BYTE offset inside the stored matrix (one 32-bit add per row; < 4 GB per job)
-    uint32_t boff = 0;                                          // byte offset of the current row inside the band matrix
 
     // a row of the LDS ring merged into the running maximum; column 0 of the last 64 rows lives in c0vec
     auto ring_slot_merge = [&](uint32_t slot, uint32_t c0lane, int& c0m) __attribute__((always_inline)) {
@@ -1481,9 +1503,35 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
             // whole row: always without the band; with it only where a later row reads the row back (VC_RF_FULL)
             if (!band || (r0 & (VC_RF_FULL << 8))) put(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + voff));
             if (band) {
-                const uint32_t bl = (uint32_t)lane - (uint32_t)__builtin_amdgcn_readlane(bvec, ri);
-                if (bl < (uint32_t)VC_BAND_LANES) put(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(brow0) + boff + bl * (NDS * 4u)));
-                boff += VC_BAND_LANES * NDS * 4u;
+                if (t_rin == TR) {                        // next row block: its band, once per TR rows, on the scalar side
+                    t_rin = 0; t_off += TBB;
+                    const uint32_t bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_start(i + TR / 2u, band_ql));
+                    t_mask = (unsigned long long)((1u << VC_BAND_LANES) - 1u) << bs;
+                    t_lane = ((uint32_t)lane - bs) * TLB;
+                }
+                // the band lanes store under their own exec mask (all 64 lanes are active here: one wave, uniform control flow);
+                // the store is not visible to the compiler's vmcnt bookkeeping, which only makes its waits longer, never shorter
+                const char* bp = brow0 + t_off + t_rin * (NDS * 4u);
+                if (NDS == 3) {
+                    typedef uint32_t vc_u3 __attribute__((ext_vector_type(3)));
+                    const vc_u3 d = {wv[0], wv[1], wv[2]};
+                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx3 %1, %2, %3\n\ts_mov_b64 exec, -1" :: "s"(t_mask), "v"(t_lane), "v"(d), "s"(bp) : "memory");
+                } else if (NDS == 2) {
+                    typedef uint32_t vc_u2 __attribute__((ext_vector_type(2)));
+                    const vc_u2 d = {wv[0], wv[1]};
+                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %1, %2, %3\n\ts_mov_b64 exec, -1" :: "s"(t_mask), "v"(t_lane), "v"(d), "s"(bp) : "memory");
+                } else if (NDS == 4) {
+                    typedef uint32_t vc_u4 __attribute__((ext_vector_type(4)));
+                    const vc_u4 d = {wv[0], wv[1], wv[2], wv[3]};
+                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_mov_b64 exec, -1" :: "s"(t_mask), "v"(t_lane), "v"(d), "s"(bp) : "memory");
+                } else {
+                    if ((t_mask >> lane) & 1ull) {
+                        uint32_t* hr = reinterpret_cast<uint32_t*>(const_cast<char*>(bp) + t_lane);
+#pragma unroll
+                        for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
+                    }
+                }
+                t_rin++;
             }
         } else {
             // full 256-B rows on purpose: masking the lanes past the sequence end was measured SLOWER
@@ -1502,7 +1550,6 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
           const uint32_t r = i0 - 1 + 64 + lane;
           if (r < nrows) nextrec = a.dp.frec[nb + r];
       }
-      if (band) bvec = (int)vc_band_start(i0 + (uint32_t)lane, band_ql);
       const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, nrows - i0 + 1));
       for (uint32_t ri = 0; ri < cnt; ++ri) {
         const uint32_t i = i0 + ri;
@@ -2026,8 +2073,8 @@ __global__ void k_trace(VcTraceArgs a) {
 // k_tracew: the same backtrack, cooperative: VC_TG alignments per wave, VC_TL = 16 lanes each.  The walk
 // is a chain of dependent HBM round trips, and ~85 % of its moves are "diagonal through the first
 // in-edge".  Each round therefore
-//   A. follows first in-edges for up to VC_SPECW positions using a per-graph table in LDS (no HBM; VC_TAB_LINKS links
-//      of the chain per entry -- see there for why it is 1 although 2 makes this kernel faster on its own),
+//   A. follows first in-edges for up to VC_SPECW positions using a per-graph table in LDS (no HBM; 4-bit entries, see
+//      vc_tracew_tab_len),
 //   B. lets lane k of the group fetch the diagonal cell (and the row record) of speculated position k --
 //      one round trip for all of them,
 //   C. accepts the longest prefix whose cells confirm the move (exactly the reference's first test at
@@ -2045,14 +2092,12 @@ __global__ void k_trace(VcTraceArgs a) {
 #define VC_SPECW 8         // positions speculated per round: 6..10 measured equal and 5 % better than 16 (fewer lines fetched for moves that get rejected)
 #endif
 #define VC_TL 16
-__host__ __device__ inline uint32_t vc_tracew_tab_len(uint32_t max_rows) { return (max_rows + 2 + 3) & ~3u; }     // entries per table
-// links of the first-in-edge chain per table entry.  2 halves the dependent LDS reads of step A (backtrack alone: 390 ->
-// 370 ms per 32 768 windows) but doubles the table, and 8 waves x 18 KB leave no LDS to the other chunk's k_fwd: with two
-// chunk streams 1 link gives 22.3 k windows/s, 2 links 21.2 k
-#ifndef VC_TAB_LINKS
-#define VC_TAB_LINKS 1
-#endif
-__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table) { return (shared_table ? 1u : (uint32_t)VC_TG) * vc_tracew_tab_len(max_rows) * (uint32_t)VC_TAB_LINKS; }
+// first-in-edge table of k_tracew: one 4-bit entry per row (distance to the row of the first in-edge; 0: do not speculate --
+// also for distances beyond 15, which the general step then takes).  Half a byte instead of a byte per row: what the job is
+// short of is LDS x time (k_fwd alone fills the LDS of every CU; a backtrack wave that waits on memory with 9 KB of tables
+// keeps a forward wave out), and distances beyond 15 are rare
+__host__ __device__ inline uint32_t vc_tracew_tab_len(uint32_t max_rows) { return (max_rows + 2 + 7) & ~7u; }     // entries per table
+__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table) { return (shared_table ? 1u : (uint32_t)VC_TG) * vc_tracew_tab_len(max_rows) / 2u; }
 __device__ __forceinline__ int vc_row_shr1(int v, int first) {          // value of the lane to the left inside a 16-lane row
     return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false);
 }
@@ -2065,14 +2110,8 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     // first in-edge distance of row r (0: do not speculate).  In the re-alignment rounds the alignments of a
     // wave belong to one window (group % VC_TG == 0) and share one table: a quarter of the LDS, more waves
     const bool shared_tab = a.shared_table != 0;
-    // entry of row r: distance to the first in-edge's row (0: stop); with VC_TAB_LINKS == 2 the high byte holds that row's
-    // own distance as well, two links of the chain per LDS access
-#if VC_TAB_LINKS == 2
-    uint16_t* tab = reinterpret_cast<uint16_t*>(smem) + (shared_tab ? 0u : grp) * vc_tracew_tab_len(a.tab_rows);
-    uint8_t* tab8 = reinterpret_cast<uint8_t*>(tab);
-#else
-    uint8_t* tab = smem + (shared_tab ? 0u : grp) * vc_tracew_tab_len(a.tab_rows);
-#endif
+    uint8_t* tab = smem + (shared_tab ? 0u : grp) * (vc_tracew_tab_len(a.tab_rows) / 2u);       // two entries per byte
+    auto tab_at = [&](uint32_t r) __attribute__((always_inline)) -> uint32_t { return ((uint32_t)tab[r >> 1] >> ((r & 1u) * 4u)) & 15u; };
     const uint32_t njobs = a.nslots * a.group;
     const bool redo = a.redo_list != nullptr;
     uint32_t job = blockIdx.x * VC_TG + grp;
@@ -2102,30 +2141,27 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
     const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
     const bool packed = a.packed != 0;
-#ifdef VC_TRACE_MAGIC
-    const uint32_t cmagic = vc_magic(cpl ? cpl : 4u);
-#endif
     // banded store: global alignments of a banded launch keep VC_BAND_LANES lanes per row around the rank diagonal
     const bool band = a.band != 0 && !redo && valid && type == 1;
-    const uint32_t* bm32 = a.bmat + (uint64_t)(valid ? job : 0) * (a.hstride / 4);
+    const uint32_t* bm32 = a.bmat + (uint64_t)(valid ? job : 0) * vc_band_job_dwords(a.hstride);
     const uint32_t band_ql = band ? a.band_par[job] : 0u;
+    const uint32_t tile_rows = vc_band_tile_rows(nds ? nds : 3u), tile_magic = tile_rows > 1 ? 0xFFFFFFFFu / tile_rows + 1u : 0u;     // rows < 65536: the multiply-high divides exactly
+    const uint32_t blk_dw = vc_band_block_bytes(nds ? nds : 3u) / 4u, tile_dw = vc_band_tile_bytes(nds ? nds : 3u) / 4u;
     bool oob = false;                                          // this lane asked for a cell outside the band (its value is then meaningless)
     const uint32_t nrows = valid ? min(a.dp.nrows[slot], a.tab_rows) : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
-    // horizontal T == T', SW stop T == -col*g.  (The runtime division by cpl stays: a multiply-high in its place made the
-    // kernel 10 % SLOWER -- 352 -> 390 ms per 32 768 windows -- the compiler then schedules the loads of a round differently.)
+    // horizontal T == T', SW stop T == -col*g.  (The runtime division by cpl stays: a multiply in its place -- a multiply-high in
+    // round 2, a 24-bit multiply and a shift in round 3 -- made the kernel 8-10 % SLOWER both times: 394 -> 427 ms per 32 768
+    // windows; the compiler then orders the loads of a round differently.)
     auto Tat = [&](uint32_t r, uint32_t col) __attribute__((always_inline)) -> int {
         if (r == 0) return nw ? 0 : -(int)col * g;
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
-#ifdef VC_TRACE_MAGIC
-        const uint32_t ci = col - 1, lc = __umulhi(ci, cmagic), cc = ci - lc * cpl;          // cpl <= 32, ci < 65536: exact (vc_magic)
-#else
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
-#endif
         if (band) {
-            const uint32_t bl = lc - vc_band_start(r, band_ql);
+            const uint32_t tb = vc_band_tile_of_row(r - 1, tile_rows, tile_magic), rin = r - 1 - tb * tile_rows;
+            const uint32_t bl = lc - vc_band_block_start(tb, tile_rows, band_ql);
             if (bl >= (uint32_t)VC_BAND_LANES) { oob = true; return 0; }
-            return vc_packed_cell(bm32 + ((uint64_t)(r - 1) * VC_BAND_LANES + bl) * nds, cc, cpl);
+            return vc_packed_cell(bm32 + tb * blk_dw + bl * tile_dw + rin * nds, cc, cpl);
         }
         if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl);
         return (int)(short)hm[((uint64_t)(r - 1) * nd * 64 + (cc >> 1) * 64 + lc) * 2 + (cc & 1)];
@@ -2146,31 +2182,22 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         const uint32_t nr = (uint32_t)__shfl((int)nrows, src, 64);
         const uint32_t nb_lo = (uint32_t)__shfl((int)(uint32_t)nb, src, 64), nb_hi = (uint32_t)__shfl((int)(uint32_t)(nb >> 32), src, 64);
         const uint64_t nbs = ((uint64_t)nb_hi << 32) | nb_lo;
-        for (uint32_t r = lane; r < nr; r += VC_TG * VC_TL) {
-            const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nbs + r]);
+        // lane k packs the entries of rows 2k and 2k + 1 (row numbers; row 0 is the virtual row)
+        auto entry = [&](uint32_t rr) __attribute__((always_inline)) -> uint32_t {
+            if (rr == 0 || rr > nr) return 0u;
+            const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nbs + rr - 1]);
             const uint32_t d0 = q.y & 0xFFFF;
-            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? 0 : d0;
-        }
-        __syncthreads();
-#if VC_TAB_LINKS == 2
-        for (uint32_t r = 1 + lane; r <= nr; r += VC_TG * VC_TL) {                 // second link: byte reads, byte writes, no overlap
-            const uint32_t d1 = tab8[2 * r];
-            tab8[2 * r + 1] = (d1 && r > d1) ? tab8[2 * (r - d1)] : (uint8_t)0;
-        }
-#endif
+            return (((q.x >> 8) & VC_RF_OVF) || d0 > 15) ? 0u : d0;
+        };
+        for (uint32_t k2 = lane; 2 * k2 <= nr; k2 += VC_TG * VC_TL) tab[k2] = (uint8_t)(entry(2 * k2) | (entry(2 * k2 + 1) << 4));
     } else {
-        for (uint32_t r = gl; walking && r < nrows; r += VC_TL) {
-            const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + r]);
+        auto entry = [&](uint32_t rr) __attribute__((always_inline)) -> uint32_t {
+            if (rr == 0 || rr > nrows) return 0u;
+            const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + rr - 1]);
             const uint32_t d0 = q.y & 0xFFFF;
-            tab[r + 1] = (((q.x >> 8) & VC_RF_OVF) || d0 > 255) ? 0 : d0;
-        }
-        __syncthreads();
-#if VC_TAB_LINKS == 2
-        for (uint32_t r = 1 + gl; walking && r <= nrows; r += VC_TL) {
-            const uint32_t d1 = tab8[2 * r];
-            tab8[2 * r + 1] = (d1 && r > d1) ? tab8[2 * (r - d1)] : (uint8_t)0;
-        }
-#endif
+            return (((q.x >> 8) & VC_RF_OVF) || d0 > 15) ? 0u : d0;
+        };
+        for (uint32_t k2 = gl; walking && 2 * k2 <= nrows; k2 += VC_TL) tab[k2] = (uint8_t)(entry(2 * k2) | (entry(2 * k2 + 1) << 4));
     }
     __syncthreads();
     uint32_t gi = end >> 16, gj = end & 0xFFFF, gnout = 0, nspec_ok = 0, nrounds = 0;
@@ -2191,14 +2218,10 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
             uint32_t ci = gi;
             bool can = walking && gi != 0 && gj != 0;
 #pragma unroll
-            for (uint32_t t = 0; t < VC_TL; t += 2) {                    // two links per iteration (one LDS access with VC_TAB_LINKS == 2)
+            for (uint32_t t = 0; t < VC_TL; t += 2) {                    // two links per iteration
                 can = can && ci != 0 && gj > t && t < VC_SPECW;
-                const uint32_t e = (can && ci <= a.tab_rows) ? (uint32_t)tab[ci] : 0u;
-#if VC_TAB_LINKS == 2
-                const uint32_t d1 = e & 0xFFu, d2 = e >> 8;
-#else
-                const uint32_t d1 = e, d2 = (can && d1 != 0 && ci - d1 != 0 && ci - d1 <= a.tab_rows) ? (uint32_t)tab[ci - d1] : 0u;
-#endif
+                const uint32_t d1 = (can && ci <= a.tab_rows) ? tab_at(ci) : 0u;
+                const uint32_t d2 = (can && d1 != 0 && ci - d1 != 0 && ci - d1 <= a.tab_rows) ? tab_at(ci - d1) : 0u;
                 can = can && d1 != 0;
                 const uint32_t c1 = ci - d1;
                 const bool can2 = can && c1 != 0 && gj > t + 1 && d2 != 0;
