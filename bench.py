@@ -102,7 +102,7 @@ def e2e_rate(batch, device, reps=1):
     n = batch.n_windows
     parts = [batch.slice(lo, min(lo + E2E_BATCH, n)) for lo in range(0, n, E2E_BATCH)]
     free_b, _ = torch.cuda.mem_get_info(device)
-    ctxs = [HipContext(device=device, scratch_bytes=int(0.42 * free_b)) for _ in range(2)]
+    ctxs = [HipContext(device=device, scratch_bytes=min(int(0.42 * free_b), 96 << 30)) for _ in range(2)]
     out = [None] * len(parts)
 
     def worker(k):

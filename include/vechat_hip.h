@@ -55,7 +55,7 @@ typedef struct vc_params {
     uint32_t max_nodes;                     /* per-window graph capacity; 0 = derive from batch    */
     uint32_t max_edges;                     /* 0 = derive                                          */
     uint32_t chunk_windows;                 /* windows resident per pass; 0 = derive from memory   */
-    uint64_t scratch_bytes;                 /* device scratch budget; 0 = 1/4 of free memory       */
+    uint64_t scratch_bytes;                 /* device scratch budget; 0 = 60 % of free memory, at most 96 GiB */
     int32_t  profile;                       /* 1 = bracket every kernel launch with HIP events, 2 = only the forward kernel's */
     uint32_t n_streams;                     /* chunks in flight on separate HIP streams; 0 = 4     */
 } vc_params;

@@ -245,7 +245,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, c->hmat_dwords / 4 + (size_t)c->jobs_cap * VC_BAND_JOB_PAD_DWORDS + 64)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, c->hmat_dwords / 4 + (VC_BAND_TILED ? c->hmat_dwords / 16 : 0) + (size_t)c->jobs_cap * VC_BAND_JOB_PAD_DWORDS + 64)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_band_par, (size_t)c->jobs_cap * 2)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_list, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_n, 4)) ||
@@ -887,8 +887,10 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     free_b += c->chunk_bytes;            // our own workspaces are reusable: the plan must not depend on whether they exist yet
     const uint32_t S = c->n_streams;
-    uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : (uint64_t)(free_b * 0.6)) / S;
-    const uint64_t rowd = 64ull * (cpl / 2);
+    // default budget: 60 % of what is free, but no more than 96 GiB -- config C runs at 97 % of its unrestricted rate with 64 GiB
+    // (chunks of 4 096 windows) and at 86 % with 32 GiB (2 048), so holding more than that buys nothing (profiles/r3c_footprint.txt)
+    uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : std::min<uint64_t>((uint64_t)(free_b * 0.6), 96ull << 30)) / S;
+    const uint64_t rowd = 64ull * (c->packed ? (uint64_t)vc_nds((int)cpl) : cpl / 2);      // dwords per stored row: byte-packed (NDS per lane) or raw int16 pairs
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6 + 16) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2) + EC * 2ull + 32) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
     // Can any alignment of this batch leave the packed-int16 kernel's envelope (vc_fwd_body's check: the reference's int16
@@ -905,7 +907,10 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);
     if (CW == 0) CW = 1;
-    while (CW > 1 && (per_slot_fixed + per_job) * CW > budget) CW /= 2;
+    if ((per_slot_fixed + per_job) * CW > budget) {          // as many windows per chunk as the budget holds (whole waves of 64 where it can)
+        CW = (uint32_t)std::max<uint64_t>(budget / (per_slot_fixed + per_job), 1);
+        if (CW > 64) CW &= ~63u;
+    }
     if ((per_slot_fixed + per_job) * CW > budget) return fail(c, VC_ERR_ARG, "scratch budget %llu too small", (unsigned long long)budget);
     // spare matrix space lets re-alignment rounds run several sequences of a window per launch
     uint64_t spare = budget - (per_slot_fixed + per_job) * CW;
@@ -966,7 +971,7 @@ int vc_run(vc_ctx* c) {
     pl.add_lds = std::max(2 * c->PC + 2 * (c->PC - c->NC) + 64, c->kept ? vc_kept_lds_bytes(c->NC) : 0u);
     pl.rows_lds = 0;
     pl.cons_lds = vc_cons_lds_bytes(c->NC, c->EC);
-    pl.rowd = 64ull * (c->ws_cpl / 2);
+    pl.rowd = 64ull * (c->packed ? (uint64_t)vc_nds((int)c->ws_cpl) : c->ws_cpl / 2);
     HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.topo_lds, kLdsCap)));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.prune_lds, kLdsCap)));
     if (pl.add_lds > kLdsCap) return fail(c, VC_ERR_ARG, "a layer of %u bases on graphs of %u nodes needs %u bytes of LDS in k_addaln (limit %u)", c->ws_max_len, c->NC, pl.add_lds, kLdsCap);
@@ -1218,7 +1223,7 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
     pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
     pl.add_lds = std::max(2 * c->PC + 2 * (c->PC - c->NC) + 64, c->kept ? vc_kept_lds_bytes(c->NC) : 0u);
     pl.rows_lds = 0; pl.cons_lds = 0;
-    pl.rowd = 64ull * (c->ws_cpl / 2);
+    pl.rowd = 64ull * (c->packed ? (uint64_t)vc_nds((int)c->ws_cpl) : c->ws_cpl / 2);
     HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
     HIPCHK(c, hipMemsetAsync(c->b.status, 0, c->b.n_windows, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

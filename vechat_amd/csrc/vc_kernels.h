@@ -1131,7 +1131,9 @@ __host__ __device__ constexpr uint32_t vc_band_tile_rows(uint32_t nds) { return 
 __host__ __device__ constexpr uint32_t vc_band_tile_bytes(uint32_t nds) { return VC_BAND_TILED ? 128u : nds * 4u; }   // one lane's tile
 __host__ __device__ constexpr uint32_t vc_band_block_bytes(uint32_t nds) { return VC_BAND_LANES * vc_band_tile_bytes(nds); }   // a row block: a tile per band lane
 #define VC_BAND_JOB_PAD_DWORDS (VC_BAND_LANES * 128u / 4u)
-__host__ __device__ inline uint64_t vc_band_job_dwords(uint64_t hstride) { return hstride / 4 + VC_BAND_JOB_PAD_DWORDS; }   // + the last, partial block
+__host__ __device__ inline uint64_t vc_band_job_dwords(uint64_t hstride) {       // a quarter of the whole rows (16 of 64 lanes), + the last, partial block
+    return hstride / 4 + (VC_BAND_TILED ? hstride / 16 : 0) + VC_BAND_JOB_PAD_DWORDS;                                // (tiles pad their rows to 128-byte lines)
+}
 __device__ __forceinline__ uint32_t vc_band_tile_of_row(uint32_t r1, uint32_t tile_rows, uint32_t tile_magic) {       // r1 = row - 1 < 65536
     (void)tile_rows;
     return VC_BAND_TILED ? __umulhi(r1, tile_magic) : r1;
@@ -1148,7 +1150,7 @@ struct VcFwdArgs {
     int do_init;                   // first width class of a launch group resets the per-job outputs
     int m, n, g;                   // NW scores
     int sm, sn, sg;                // SW scores
-    uint32_t* hmat;                // [jobs * hstride] packed int16 H, row = [CPL/2][64 lanes] dwords
+    uint32_t* hmat;                // [jobs * hstride] stored rows: byte-packed [64 lanes][NDS] or raw int16 pairs [CPL/2][64 lanes] dwords
     uint64_t  hstride;             // dwords per job
     int16_t*  c0;                  // [jobs * NC] H[i][0]
     uint32_t* job_end;             // [jobs] (row << 16) | col ; 0 = empty alignment
@@ -1162,7 +1164,7 @@ struct VcFwdArgs {
     unsigned long long* stat;      // [4] cells, rows, -, far-row reads
     uint32_t wcols;                // != 0: k_fwd_wide follows this launch and takes what the packed-int16 kernel declines
     uint32_t kept;                 // build phase: slots of the kept-row ring the forward records were made for (0: plain ring)
-    uint32_t* bmat;                // band matrix of a job: bmat + job * vc_band_job_dwords(hstride), tiled (see vc_band_start)
+    uint32_t* bmat;                // band matrix of a job: bmat + job * vc_band_job_dwords(hstride) (see vc_band_start)
     uint32_t* band_par;            // [jobs] slope (lanes per row, 16.16) of the job's band
     int band;                      // 1: global alignments store the band (+ whole rows where VC_RF_FULL asks for them)
     const uint32_t* redo_list;     // != nullptr: this launch re-runs the listed jobs with whole rows (the backtrack left the band)
@@ -1372,7 +1374,8 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     uint4 myrec = make_uint4(0, 0, 0, 0), nextrec = make_uint4(0, 0, 0, 0);
     if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
     constexpr uint32_t rowdw = PACKED ? NDS * 64 : ND * 64;     // dwords per stored row
-    uint32_t voff = (PACKED ? lane * NDS : lane) * 4u;          // my BYTE offset inside the stored matrix (one 32-bit add per row; < 4 GB per job)
+    const uint32_t loff = (PACKED ? lane * NDS : lane) * 4u;    // my BYTE offset inside a stored row
+    uint32_t srow = 0;                                          // byte offset of the current row (scalar; < 4 GB per job)
 
     // a row of the LDS ring merged into the running maximum; column 0 of the last 64 rows lives in c0vec
     auto ring_slot_merge = [&](uint32_t slot, uint32_t c0lane, int& c0m) __attribute__((always_inline)) {
@@ -1435,7 +1438,9 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         P[0] = pk_max_hi_with_lo(P[0]);
 #pragma unroll
         for (int q = 1; q < ND; ++q) P[q] = pk_max_bcast_hi(pk_max_hi_with_lo(P[q]), P[q - 1]);
-        int sc = pk_hi(P[ND - 1]);
+        // the scan runs on the raw dword of the lane's last pair: as an int32 it orders by its high half (the lane's running
+        // maximum), the low half only decides between equal high halves -- and only the high half of the result is used
+        int sc = (int)P[ND - 1];
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x111, 0xF));
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x112, 0xF));
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x114, 0xF));
@@ -1443,10 +1448,9 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x142, 0xA));
         sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x143, 0xC));
         int carry = VC_DPP_SHR(sc, VC_INT_MIN, 0x138, 0xF);
-        carry = max(carry, col0);                     // column 0 enters as T[i][0] = H[i][0]
-        const uint32_t cc = pk_dup(carry);
+        carry = max(carry, (int)((uint32_t)col0 << 16));   // column 0 enters as T[i][0] = H[i][0]
 #pragma unroll
-        for (int q = 0; q < ND; ++q) acc[q] = pk_max(P[q], cc);
+        for (int q = 0; q < ND; ++q) acc[q] = pk_max_bcast_hi(P[q], (uint32_t)carry);       // both halves against the carry's high half
 
         // ---- end cell
         if (nw) {
@@ -1501,7 +1505,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
                 }
             };
             // whole row: always without the band; with it only where a later row reads the row back (VC_RF_FULL)
-            if (!band || (r0 & (VC_RF_FULL << 8))) put(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + voff));
+            if (!band || (r0 & (VC_RF_FULL << 8))) put(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + srow + loff));
             if (band) {
                 if (t_rin == TR) {                        // next row block: its band, once per TR rows, on the scalar side
                     t_rin = 0; t_off += TBB;
@@ -1536,11 +1540,11 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         } else {
             // full 256-B rows on purpose: masking the lanes past the sequence end was measured SLOWER
             // (partial cache-line writes), although it would save 20 % of the bytes
-            uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + voff);
+            uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + srow + loff);
 #pragma unroll
             for (int q = 0; q < ND; ++q) hr[q * 64] = acc[q];
         }
-        voff += rowdw * 4u;
+        srow += rowdw * 4u;
         __builtin_amdgcn_wave_barrier();
     };
 

@@ -17,6 +17,8 @@ not in the tree).
 import gzip
 import re
 
+import numpy as np
+
 
 def _open(path):
     return gzip.open(path, "rb") if str(path).endswith(".gz") else open(path, "rb")
@@ -55,7 +57,9 @@ def _records(path):
                 qual = f.readline().strip()
                 if len(qual) != len(data):
                     raise ValueError(f"{path}: quality length differs from sequence length for {name.decode()}")
-                if sum(c - 33 for c in qual) == 0:
+                # an all-'!' quality string counts as none (src/sequence.cpp:19-42 sums c - '!'); the byte-wise sum is only
+                # needed when a byte below '!' could cancel others
+                if qual.count(b"!") == len(qual) or (qual and min(qual) < 33 and sum(c - 33 for c in qual) == 0):
                     qual = None
                 yield name.decode(), data, qual
             else:
@@ -74,6 +78,10 @@ def sequence_index(path):
 
 
 _CIG = re.compile(rb"(\d+)([MIDNSHP=X])")
+_CIG_TO_SPACE = bytes.maketrans(b"MIDNSHP=X", b" " * 9)
+_CIG_OK = np.zeros(256, bool); _CIG_OK[list(b"MIDNSHP=X")] = True
+_CIG_Q, _CIG_T, _CIG_CLIP = np.zeros(256, bool), np.zeros(256, bool), np.zeros(256, bool)
+_CIG_Q[list(b"M=XI")] = True; _CIG_T[list(b"M=XDN")] = True; _CIG_CLIP[list(b"SH")] = True
 
 
 class Overlap:
@@ -89,11 +97,23 @@ def _sam_overlap(q_name, flag, t_name, pos, cigar):
         return None
     if len(cigar) < 2:
         raise ValueError("missing alignment from SAM object")
-    ops = _CIG.findall(cigar)
-    q_begin = int(ops[0][0]) if ops and ops[0][1] in b"SH" else 0
-    q_aln = sum(int(n) for n, o in ops if o in b"M=XI")
-    t_aln = sum(int(n) for n, o in ops if o in b"M=XDN")
-    clip = sum(int(n) for n, o in ops if o in b"SH")
+    # lengths and letters of the CIGAR as two arrays (a 10 kb read has thousands of operations: no Python loop over them)
+    lets = np.frombuffer(cigar.translate(None, b"0123456789"), dtype=np.uint8)
+    n = None
+    if len(lets) and cigar[:1].isdigit() and not cigar[-1:].isdigit() and _CIG_OK[lets].all():
+        n = np.fromstring(cigar.translate(_CIG_TO_SPACE).decode("ascii", "replace"), dtype=np.int64, sep=" ")
+        if len(n) != len(lets):                 # two letters in a row, or the like
+            n = None
+    if n is not None:
+        is_q, is_t, is_clip = _CIG_Q[lets], _CIG_T[lets], _CIG_CLIP[lets]
+        q_begin = int(n[0]) if is_clip[0] else 0
+        q_aln, t_aln, clip = int(n[is_q].sum()), int(n[is_t].sum()), int(n[is_clip].sum())
+    else:                                       # anything unusual: the plain scan over (count, letter) pairs
+        ops = _CIG.findall(cigar)
+        q_begin = int(ops[0][0]) if ops and ops[0][1] in b"SH" else 0
+        q_aln = sum(int(k) for k, o in ops if o in b"M=XI")
+        t_aln = sum(int(k) for k, o in ops if o in b"M=XDN")
+        clip = sum(int(k) for k, o in ops if o in b"SH")
     strand = bool(flag & 0x10)
     q_end = q_begin + q_aln
     q_length = clip + q_aln
