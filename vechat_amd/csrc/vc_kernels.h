@@ -1754,12 +1754,16 @@ __global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
 // than 64 lanes x 32 columns, unusual score signs.  Same recurrence (sisd_alignment_engine.cpp:118-254, 292-360), int32,
 // no assumption beyond what the reference makes: columns are processed in tiles of 512 (64 lanes x 8 cells), one full
 // sweep over the rows per tile, predecessor rows re-read from the stored matrix (raw int32, tilted like k_fwd's:
-// T[i][j] = H[i][j] - j*g), the row directly above kept in registers.  Not tuned: it exists so that no valid window is
-// refused, and it runs only for jobs k_fwd left untouched (job_type still 255).
+// T[i][j] = H[i][j] - j*g), the row directly above kept in registers, row records fetched a block of 64 ahead, the lane scan
+// on DPP.  It runs only for jobs k_fwd left untouched (job_type still 255).
 // ------------------------------------------------------------------------------------------------
 #define VC_WIDE_CPL 8
+#define VC_WIDE_RING 8          // rows of the current tile kept in LDS (16 KB per wave; this kernel never fills a CU)
 #define VC_WIDE_NEG (-(1 << 29))
 __global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_t wstride, uint32_t wcols, int* c0w) {
+    // the last VC_WIDE_RING rows of the tile in LDS (slot = row % VC_WIDE_RING): the predecessors that are not the row directly
+    // above are nearly always among them, and a read back from the stored matrix costs a fence and a memory round trip
+    __shared__ int wring[VC_WIDE_RING][VC_WIDE_CPL][64];
     const int lane = vc_lane();
     const uint32_t job = blockIdx.x;
     const uint32_t slot = job / a.group;
@@ -1802,8 +1806,23 @@ __global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_
 #pragma unroll
         for (int q = 0; q < C; ++q) prevT[q] = 0;
         int c0prev = 0, c0vec = 0;
+        // row records a block of 64 ahead, lane t holding the record of row (block * 64 + t + 1), as in k_fwd: a load per row
+        // would put a memory round trip on every row's critical path
+        uint4 blkrec = make_uint4(0, 0, 0, 0), nextrec = make_uint4(0, 0, 0, 0);
+        int blkedge = 0, prvedge = 0;                          // left edge of the tile for the rows of this block / of the block before
+        if ((uint32_t)lane < nrows) nextrec = a.dp.rec[nb + lane];
         for (uint32_t i = 1; i <= nrows; ++i) {
-            const uint4 rec = a.dp.rec[nb + i - 1];
+            const uint32_t ri = (i - 1) & 63u;
+            if (ri == 0) {
+                blkrec = nextrec;
+                const uint32_t r = i - 1 + 64 + (uint32_t)lane;
+                if (r < nrows) nextrec = a.dp.rec[nb + r];
+                // what enters this tile from the left, for the 64 rows of the block at once (the previous sweep wrote it)
+                prvedge = blkedge;
+                if (tile && i - 1 + (uint32_t)lane < nrows) blkedge = T[(uint64_t)(i - 1 + (uint32_t)lane) * wcols + tile * 64 * C - 1];
+            }
+            const uint4 rec = make_uint4((uint32_t)__builtin_amdgcn_readlane((int)blkrec.x, ri), (uint32_t)__builtin_amdgcn_readlane((int)blkrec.y, ri),
+                                         (uint32_t)__builtin_amdgcn_readlane((int)blkrec.z, ri), (uint32_t)__builtin_amdgcn_readlane((int)blkrec.w, ri));
             const uint32_t x = rec.x & 0xFF, fl = (rec.x >> 8) & 0xFF;
             const bool isovf = (fl & VC_RF_OVF) != 0;
             const uint32_t np = isovf ? rec.z : ((rec.x >> 16) & 0xFF);
@@ -1826,16 +1845,24 @@ __global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_
 #pragma unroll
                     for (int q = 0; q < C; ++q) hv[q] = prevT[q];
                     hl = prevLeft; c0p = c0prev;
+                } else if (delta <= (uint32_t)VC_WIDE_RING) {
+                    const int (*wr)[64] = wring[pr & (VC_WIDE_RING - 1)];
+#pragma unroll
+                    for (int q = 0; q < C; ++q) hv[q] = wr[q][lane];
+                    c0p = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
+                    int edge = nw ? c0p : 0;                   // column 0 of that row
+                    if (tile) edge = (pr - 1 >= ((i - 1) & ~63u)) ? __builtin_amdgcn_readlane(blkedge, (pr - 1) & 63) : __builtin_amdgcn_readlane(prvedge, (pr - 1) & 63);
+                    hl = VC_DPP_SHR(hv[C - 1], edge, 0x138, 0xF);
                 } else {
+                    __threadfence_block();                     // a row read back: my own earlier stores must have landed (only here, not per row)
                     const int* hr = T + (uint64_t)(pr - 1) * wcols + cb;
 #pragma unroll
                     for (int q = 0; q < C; ++q) hv[q] = hr[q];
                     if (delta <= 64) c0p = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
                     else c0p = (int)__builtin_amdgcn_readfirstlane(c0out[pr - 1]);
-                    const int up = __shfl_up(hv[C - 1], 1, 64);
                     int edge = nw ? c0p : 0;                   // column 0 of that row
                     if (tile) edge = (int)__builtin_amdgcn_readfirstlane(T[(uint64_t)(pr - 1) * wcols + tile * 64 * C - 1]);
-                    hl = lane ? up : edge;
+                    hl = VC_DPP_SHR(hv[C - 1], edge, 0x138, 0xF);          // the left lane's last cell; lane 0 takes the edge
                 }
 #pragma unroll
                 for (int q = 0; q < C; ++q) { accv[q] = max(accv[q], hv[q]); accd[q] = max(accd[q], q ? hv[q - 1] : hl); }
@@ -1851,14 +1878,17 @@ __global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_
                 P[q] = cb + q < len ? v : VC_WIDE_NEG;
             }
             // horizontal pass: prefix maximum with the value entering from the left of the tile
-            const int carry_in = tile ? (int)__builtin_amdgcn_readfirstlane(T[(uint64_t)(i - 1) * wcols + tile * 64 * C - 1]) : col0;
+            const int carry_in = tile ? __builtin_amdgcn_readlane(blkedge, ri) : col0;
 #pragma unroll
             for (int q = 1; q < C; ++q) P[q] = max(P[q], P[q - 1]);
             int sc = P[C - 1];
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int t2 = __shfl_up(sc, d, 64); if (lane >= d) sc = max(sc, t2); }
-            int carry = __shfl_up(sc, 1, 64);
-            carry = lane ? max(carry, carry_in) : carry_in;
+            sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x111, 0xF));
+            sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x112, 0xF));
+            sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x114, 0xF));
+            sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x118, 0xF));
+            sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x142, 0xA));
+            sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x143, 0xC));
+            const int carry = max(VC_DPP_SHR(sc, VC_INT_MIN, 0x138, 0xF), carry_in);     // lane 0: what enters from the left of the tile
             int cur[C];
 #pragma unroll
             for (int q = 0; q < C; ++q) cur[q] = max(P[q], carry);
@@ -1866,6 +1896,12 @@ __global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_
                 int* hr = T + (uint64_t)(i - 1) * wcols + cb;
 #pragma unroll
                 for (int q = 0; q < C; ++q) hr[q] = cur[q];
+                // one wave per workgroup: its LDS operations retire in order, no barrier -- only keep the compiler from reordering
+                __builtin_amdgcn_wave_barrier();
+                int (*ww)[64] = wring[i & (VC_WIDE_RING - 1)];
+#pragma unroll
+                for (int q = 0; q < C; ++q) ww[q][lane] = cur[q];
+                __builtin_amdgcn_wave_barrier();
             }
             // end cell
             if (nw) {
@@ -1898,17 +1934,16 @@ __global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_
             }
 #pragma unroll
             for (int q = 0; q < C; ++q) prevT[q] = cur[q];
-            { const int up = __shfl_up(cur[C - 1], 1, 64); prevLeft = lane ? up : carry_in; }
+            prevLeft = VC_DPP_SHR(cur[C - 1], carry_in, 0x138, 0xF);
             // bookkeeping of column 0 like k_fwd: the last 64 rows in a register, the rest in memory
             c0prev = col0;
             c0vec = ((uint32_t)lane == ((i - 1) & 63)) ? col0 : c0vec;
             if ((i & 63) == 0 || i == nrows) {
                 const uint32_t first = (i - 1) & ~63u;
                 if (first + lane < i) c0out[first + lane] = c0vec;
-                __threadfence_block();
             }
-            __threadfence_block();                             // rows just written are read back by their successors
         }
+        __threadfence_block();                                 // the next tile reads this tile's last column of every row
     }
     uint32_t end = 0;
     if (nw) {
