@@ -1076,7 +1076,12 @@ __device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const
 
 // a few resident workgroups walk the list of windows whose alignment ended in a tie (appended by k_fwd),
 // so the thousands of untied windows cost nothing and nobody parks 60 KB of LDS per window
-__global__ __launch_bounds__(64) void k_resolve(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+// (at most 72 VGPRs, the rest in scratch: nearly every launch finds an empty list, and a 127-register wave could not even be
+// placed beside k_fwd's waves to find that out -- 77 -> 37 ms per 32 768 windows spent in these launches)
+#ifndef VC_RESOLVE_OCC
+#define VC_RESOLVE_OCC __attribute__((amdgpu_waves_per_eu(7, 8)))
+#endif
+__global__ __launch_bounds__(64) VC_RESOLVE_OCC void k_resolve(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                                 uint32_t NC, uint32_t EC, uint32_t STK,
                                                 const uint16_t* tie_rows, const uint32_t* tie_cnt, const uint32_t* tie_over, uint32_t tie_over_stride, uint32_t* job_end,
                                                 const uint32_t* tie_list, const uint32_t* tie_n,
