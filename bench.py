@@ -314,6 +314,8 @@ def main():
                 roof["traffic_note"] = f"profiles/r3_hbm_traffic.json was measured for kernels {tj.get('kernel_hash')}, these are {khash}: not used"
             else:
                 roof["traffic"] = tj["bytes_per_cell"] * cells / max(fwd_launches, 1)
+                roof["traffic_source"] = ("bytes per cell from a separate rocprofv3 PMC pass over the same kernel sources (profiles/r3_hbm_traffic.json, "
+                                          "FETCH_SIZE / WRITE_SIZE, one counter per pass) x this run's cells per launch -- not counters of this run")
                 roof["hbm_frac_measured"] = tj["bytes_per_cell"] * cells / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 roof["hbm_frac_measured_over_busy_time"] = tj["bytes_per_cell"] * cells / (fwd_busy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 # the kernel moves less than the 4 B/cell model, so the VALU issue bound is stated beside it, against

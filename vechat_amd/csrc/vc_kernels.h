@@ -1439,6 +1439,14 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
 #pragma unroll
             for (int q = 0; q < ND; ++q) P[q] = pk_max(P[q], njg[q]);
         }
+#ifdef VC_PAD_VALU
+        {   // development: VC_PAD_VALU independent vector instructions per row (is the job bound by VALU issue?)
+            uint32_t pad = (uint32_t)lane;
+#pragma unroll
+            for (int t = 0; t < VC_PAD_VALU; ++t) asm volatile("v_add_u32 %0, %0, %1" : "+v"(pad) : "v"(pfA[t % ND]));
+            asm volatile("" :: "v"(pad));
+        }
+#endif
         // ---- horizontal pass (sisd :347-349): prefix maximum, in-lane then across lanes
         P[0] = pk_max_hi_with_lo(P[0]);
 #pragma unroll
