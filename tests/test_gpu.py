@@ -216,6 +216,21 @@ def test_result_is_independent_of_chunking(built):
     a.close(); b.close()
 
 
+def test_a_small_scratch_budget_only_changes_the_chunking(built):
+    """Chunks take as many windows as the scratch budget holds (whole waves of 64, no halving): the result does not change,
+    the context holds about what it was given, and several chunks per stream run."""
+    batch = capi.synth_batch(capi.synth_cfg(62, 300, 24, frac_partial=0.1), 0, 700)
+    ref = HipContext(device=0)
+    cr, sr = ref.consensus(batch)
+    small = HipContext(device=0, scratch_bytes=1 << 30, n_streams=2)
+    cs, ss = small.consensus(batch)
+    st = small.stats()
+    assert cs == cr and (ss == sr).all()
+    assert st["chunk_windows"] < 700 and st["chunk_windows"] % 64 == 0, st["chunk_windows"]
+    assert st["device_bytes"] < 2 * (1 << 30), st["device_bytes"]
+    ref.close(); small.close()
+
+
 def test_graph_images_beyond_the_lds_use_the_hbm_workspace(built):
     """Capacities whose topo / prune / consensus images exceed 160 KB are not refused: those kernels then work
     from an HBM workspace.  Same bytes as the oracle."""

@@ -129,3 +129,33 @@ def test_sequence_ingest_matches_the_reference_parser(tmp_path, seed):
             assert (rn, rd, rq) == (n, d, q)
             assert rrc == windows_ref.revcomp(d)
             assert rrq == (q[::-1] if q is not None else None)
+
+
+def test_cigar_scan_fast_and_plain_paths_agree():
+    """The vectorised CIGAR scan of the SAM constructor (lengths and letters as two arrays) against the plain scan over
+    (count, letter) pairs it replaced (src/overlap.cpp:44-110), on random and on odd strings."""
+    import random
+    from vechat_amd import seqio
+    rnd = random.Random(5)
+
+    def plain(cigar, flag, pos):
+        ops = seqio._CIG.findall(cigar)
+        q_begin = int(ops[0][0]) if ops and ops[0][1] in b"SH" else 0
+        q_aln = sum(int(k) for k, o in ops if o in b"M=XI")
+        t_aln = sum(int(k) for k, o in ops if o in b"M=XDN")
+        clip = sum(int(k) for k, o in ops if o in b"SH")
+        strand = bool(flag & 0x10)
+        q_end, q_length = q_begin + q_aln, clip + q_aln
+        if strand:
+            q_begin, q_end = q_length - q_end, q_length - q_begin
+        return q_begin, q_end, q_length, pos - 1, pos - 1 + t_aln, max(q_aln, t_aln)
+
+    cases = [b"10M", b"5S10M2I3D4H", b"3H7M", b"12=3X1I", b"10", b"M10", b"3MM", b"12Q", b"1M2", b"7N3M", b"2P5M"]
+    for _ in range(300):
+        n = rnd.randint(1, 400)
+        body = b"".join(b"%d%s" % (rnd.randint(1, 5000), rnd.choice([b"M", b"I", b"D", b"=", b"X", b"N"])) for _ in range(n))
+        cases.append(rnd.choice([b"", b"12S", b"3H"]) + body + rnd.choice([b"", b"9S", b"40H"]))
+    for cg in cases:
+        for flag in (0, 16):
+            o = seqio._sam_overlap("q", flag, "t", 101, cg)
+            assert (o.q_begin, o.q_end, o.q_length, o.t_begin, o.t_end, o.length) == plain(cg, flag, 101), cg

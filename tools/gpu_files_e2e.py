@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vechat_amd import capi                                                     # noqa: E402
 from vechat_amd.engine import HipContext                                        # noqa: E402
-from vechat_amd.seqio import load_polisher_input, read_overlaps, read_sequences, sequence_index  # noqa: E402
+from vechat_amd.seqio import load_polisher_input, read_overlaps, read_sequences  # noqa: E402
 from vechat_amd.windows import WindowBuilder                                    # noqa: E402
 
 NT = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -69,8 +69,8 @@ def main():
     print(f"generated {nt} targets x {tl} bp x {depth} reads: {mb:.0f} MB of files in {time.time() - t0:.1f} s", flush=True)
 
     T = {}
-    t0 = time.time(); overlaps = read_overlaps(sam); r_index = sequence_index(fq); T["parse overlaps + index"] = time.time() - t0
-    t0 = time.time(); targets, reads = read_sequences(tg), read_sequences(fq); T["parse sequences"] = time.time() - t0
+    t0 = time.time(); overlaps = read_overlaps(sam); T["parse overlaps (SAM)"] = time.time() - t0
+    t0 = time.time(); targets, reads = read_sequences(tg), read_sequences(fq); T["parse sequences (FASTQ)"] = time.time() - t0
     t0 = time.time()
     wb = WindowBuilder(500, 10.0)
     kept, _ = load_polisher_input(wb, targets, reads, overlaps, 0.3)

@@ -74,7 +74,14 @@ def main(argv=None):
     distributed = world > 1 or os.environ.get("VC_FORCE_DIST") == "1"
     device = int(os.environ.get("LOCAL_RANK", a.device)) if distributed else a.device
     overlaps = read_overlaps(a.overlaps)
-    r_index = sequence_index(a.sequences)                         # window type comes from the mean length of ALL reads (polisher.cpp:300-306)
+    # window type comes from the mean length of ALL reads (polisher.cpp:300-306).  One process reads the file once and keeps
+    # the records; a rank of a multi-GPU run only needs names and lengths here and loads its own share of the reads below
+    all_reads = None
+    if distributed:
+        r_index = sequence_index(a.sequences)
+    else:
+        all_reads = read_sequences(a.sequences)
+        r_index = [(n, len(d)) for n, d, _ in all_reads]
     if not r_index:
         raise ValueError("empty sequences set")
     window_type = 0 if sum(l for _, l in r_index) / float(len(r_index)) <= 1000 else 1
@@ -100,7 +107,8 @@ def main(argv=None):
     n_targets = n_windows = n_polished = kept = n_aligned = 0
     failure = None                                                # (exit code, message): reported by every rank through the collective below
     try:
-        targets, reads = read_sequences(a.targets, keep_t), read_sequences(a.sequences, keep_r)
+        targets = read_sequences(a.targets, keep_t)
+        reads = all_reads if all_reads is not None else read_sequences(a.sequences, keep_r)
         n_targets = len(targets)
         if not distributed and not (targets and reads and overlaps):
             raise ValueError("empty overlap set")
