@@ -222,12 +222,13 @@ def test_a_small_scratch_budget_only_changes_the_chunking(built):
     batch = capi.synth_batch(capi.synth_cfg(62, 300, 24, frac_partial=0.1), 0, 700)
     ref = HipContext(device=0)
     cr, sr = ref.consensus(batch)
-    small = HipContext(device=0, scratch_bytes=1 << 30, n_streams=2)
+    small = HipContext(device=0, scratch_bytes=192 << 20, n_streams=2)
     cs, ss = small.consensus(batch)
     st = small.stats()
     assert cs == cr and (ss == sr).all()
-    assert st["chunk_windows"] < 700 and st["chunk_windows"] % 64 == 0, st["chunk_windows"]
-    assert st["device_bytes"] < 2 * (1 << 30), st["device_bytes"]
+    assert st["chunk_windows"] < 350, st["chunk_windows"]                     # without the budget: 700 windows / 2 streams
+    assert st["chunk_windows"] % 64 == 0 or st["chunk_windows"] < 64, st["chunk_windows"]
+    assert st["device_bytes"] < (1 << 30), st["device_bytes"]
     ref.close(); small.close()
 
 
