@@ -124,6 +124,8 @@ struct vc_ctx {
     uint32_t max_backbone = 0;           // longest backbone of the batch
     std::vector<uint8_t> h_pre_status;   // per-window status decided at submit (outside the envelope), empty = none
     bool trace_wave = true;
+    int prune_hbm = 1;              // 1: the first prune of a chunk works from the HBM workspace instead of LDS; 2: every prune; 0: LDS
+    bool topo_hbm = false;          // k_topo of the pruned graphs from the HBM workspace
     uint32_t dbg_stop_kind = 0, dbg_stop_index = 0;   // vc_debug_stop_after: leave the chunk's graphs as they are after that stage
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
     uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
@@ -539,7 +541,14 @@ struct Plan {
         VcPruneArgs pa{};
         pa.b = c->b; pa.src = wk.gr[wk.cur]; pa.dst = wk.gr[wk.cur ^ 1]; pa.w0 = wk.w0; pa.nslots = ns; pa.NC = NC; pa.EC = EC;
         pa.NCl = NCl; pa.ECl = ECl;
-        const bool pws = vc_prune_lds_bytes(NCl, ECl) > kLdsCap, tws = topo_lds_bytes(NCl, ECl, c->STK, c->MA) > kLdsCap;
+        // the first prune works on the whole graph (60 KB image at 2 240 nodes): in LDS only two windows fit a CU, and beside a
+        // full house of k_fwd waves not even one until eight of them retire; from the HBM workspace every window of the chunk
+        // is resident at once: 76 -> 34 ms per 32 768 windows alone, 250 -> 53 ms beside k_fwd, the job + 4 % (VC_PRUNE_HBM=0 / 2:
+        // development switch; the later prunes work on graphs a quarter of the size and are faster from LDS).  The same for
+        // k_topo (VC_TOPO_HBM=1) and for k_addaln's per-pair notes was measured and does not pay: k_addaln with 1.4 instead of
+        // 7 KB of LDS is placed sooner, waits on HBM instead, and its 8 192 waves then sit on the slots k_tracew needs.
+        const bool first_hbm = c->prune_hbm && (!wk.pruned_known || c->prune_hbm >= 2) && c->big_ws_stride >= vc_prune_lds_bytes(NCl, ECl);
+        const bool pws = first_hbm || vc_prune_lds_bytes(NCl, ECl) > kLdsCap, tws = topo_lds_bytes(NCl, ECl, c->STK, c->MA) > kLdsCap;
         pa.ws = pws ? wk.d_big_ws : nullptr; pa.ws_stride = c->big_ws_stride;
         pa.min_conf = c->prm.min_confidence; pa.min_supp = c->prm.min_support;
         for (uint32_t rep = 0; rep < ((c->dup & 4u) ? 2u : 1u); ++rep) { Timer t(c, KC_PRUNE, wk.stream); hipLaunchKernelGGL(k_prune_lcc, dim3(ns), dim3(64), pws ? 0 : vc_prune_lds_bytes(NCl, ECl), wk.stream, pa); }
@@ -553,7 +562,8 @@ struct Plan {
                 NCt = std::min(NC, (uint32_t)((c->max_backbone * 5 / 4 + 127) & ~63u));
                 ECt = std::min(EC, (uint32_t)((c->max_backbone * 2 + 127) & ~63u));
             }
-            const bool tw = topo_lds_bytes(NCt, ECt, c->STK, c->MA) > kLdsCap;
+            bool tw = topo_lds_bytes(NCt, ECt, c->STK, c->MA) > kLdsCap;
+            if (c->topo_hbm && c->big_ws_stride >= topo_lds_bytes(NCl, ECl, c->STK, c->MA)) { tw = true; NCt = NCl; ECt = ECl; }
             for (uint32_t rep = 0; rep < ((c->dup & 8u) ? 2u : 1u); ++rep) { Timer t(c, KC_TOPO, wk.stream);
               hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tw ? 0 : topo_lds_bytes(NCt, ECt, c->STK, c->MA), wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRingPruned, NCt, ECt,
                                  (tw || c->big_ws_topo) ? wk.d_big_ws : nullptr, c->big_ws_stride, tw ? 1 : 0); }
@@ -694,6 +704,8 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
+    if (const char* d = getenv("VC_PRUNE_HBM")) c->prune_hbm = std::atoi(d);
+    if (const char* d = getenv("VC_TOPO_HBM")) c->topo_hbm = std::atoi(d) != 0;
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }
     // The chunk streams must run CONCURRENTLY.  HIP multiplexes streams of one priority onto a small pool of
     // hardware queues (GPU_MAX_HW_QUEUES, default 4) round-robin, so two of ours can land on the same queue
@@ -877,7 +889,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     if (vc_prune_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_prune_lds_bytes(NC, EC));
     if (c->prm.mode == 1 && vc_cons_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_cons_lds_bytes(NC, EC));
     c->big_ws_topo = c->prm.mode == 0;                    // k_topo's LDS image of the first pruned graphs is sized optimistically: its fallback lives here
-    if (c->big_ws_topo) big = std::max(big, topo_lds_bytes(NC, EC, c->STK, MA));
+    if (c->big_ws_topo) big = std::max(big, std::max(topo_lds_bytes(NC, EC, c->STK, MA), vc_prune_lds_bytes(NC, EC)));   // (and the first prune's image, see Plan::prune)
     c->max_backbone = max_backbone;
     big = (big + 255u) & ~255u;
     const uint32_t PC = NC + ws_max_len + 8;
