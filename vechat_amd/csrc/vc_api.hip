@@ -485,6 +485,10 @@ struct Plan {
             if (n >= 3) wk.layers = std::max(wk.layers, n - 1);
         }
         (void)hipMemsetAsync(wk.dp.nrows, 0, (size_t)ns * 4, wk.stream);      // skipped windows must not carry a stale height
+        for (int gi = 0; gi < 2; ++gi) {                                       // ... nor stale graph sizes: prune() sizes the next round's LDS
+            (void)hipMemsetAsync(wk.gr[gi].n_nodes, 0, (size_t)ns * 4, wk.stream);   // images from the maximum over the chunk, skipped windows
+            (void)hipMemsetAsync(wk.gr[gi].n_edges, 0, (size_t)ns * 4, wk.stream);   // (fewer than three sequences) included
+        }
         { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3(ns), dim3(64), 0, wk.stream, c->b, w0, ns); }
         { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), c->kept ? vc_kept_lds_bytes(NC) : 0, wk.stream, c->b, wk.gr[0], wk.dp, w0, ns, NC, EC, (uint32_t)kRing, c->kept); }
     }
