@@ -343,24 +343,27 @@ void flush_events(vc_ctx* c) {
     c->ev_next = 0;
 }
 
+// nwonly: every alignment of the launch is global (mode 0 always; a re-alignment launch whose layers are all full-span)
 template <int CA, int CB>
-void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs, bool packed) {
+void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs, bool packed, bool nwonly) {
     if (a.mode == 0 && a.kept) {
-        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, (kKept ? kKept : 1), true, true>), dim3(jobs), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_fwd<CA, CB, (kKept ? kKept : 1), false, true>), dim3(jobs), dim3(64), 0, st, a);
+        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, (kKept ? kKept : 1), true, true, true>), dim3(jobs), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_fwd<CA, CB, (kKept ? kKept : 1), false, true, true>), dim3(jobs), dim3(64), 0, st, a);
     } else if (a.mode == 0) {
-        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, kRing, true, false>), dim3(jobs), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_fwd<CA, CB, kRing, false, false>), dim3(jobs), dim3(64), 0, st, a);
+        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, kRing, true, false, true>), dim3(jobs), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_fwd<CA, CB, kRing, false, false, true>), dim3(jobs), dim3(64), 0, st, a);
+    } else if (nwonly && packed) {
+        hipLaunchKernelGGL((k_fwd<CA, CB, kRingPruned, true, false, true>), dim3(jobs), dim3(64), 0, st, a);
     } else {
-        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, kRingPruned, true, false>), dim3(jobs), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_fwd<CA, CB, kRingPruned, false, false>), dim3(jobs), dim3(64), 0, st, a);
+        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, kRingPruned, true, false, false>), dim3(jobs), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_fwd<CA, CB, kRingPruned, false, false, false>), dim3(jobs), dim3(64), 0, st, a);
     }
 }
 
 // One launch when the batch's sequences fall into one width class or two adjacent ones (the usual case:
 // read pieces of a window differ by a few percent in length); otherwise one launch per class.
-int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, const Work* wk = nullptr) {
-    if (c->dup & 16u) { const uint32_t d = c->dup; c->dup = 0; (void)launch_fwd(c, st, a0, jobs, wk); c->dup = d; (void)hipMemsetAsync(a0.tie_n, 0, 4, st); }
+int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, const Work* wk = nullptr, bool nwonly = false) {
+    if (c->dup & 16u) { const uint32_t d = c->dup; c->dup = 0; (void)launch_fwd(c, st, a0, jobs, wk, nwonly); c->dup = d; (void)hipMemsetAsync(a0.tie_n, 0, 4, st); }
     const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
     VcFwdArgs a = a0;
     a.do_init = 1;
@@ -374,16 +377,16 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
         { Timer t(c, KC_FWD, st);
         switch (hi) {
 #ifndef VC_FAST_BUILD          // development builds (-DVC_FAST_BUILD) carry only the width classes of the benchmark
-            case 1: launch_fwd_t<4, 6>(st, a, jobs, c->packed); break;
-            case 2: launch_fwd_t<6, 8>(st, a, jobs, c->packed); break;
+            case 1: launch_fwd_t<4, 6>(st, a, jobs, c->packed, nwonly); break;
+            case 2: launch_fwd_t<6, 8>(st, a, jobs, c->packed, nwonly); break;
 #endif
-            case 3: launch_fwd_t<8, 10>(st, a, jobs, c->packed); break;
+            case 3: launch_fwd_t<8, 10>(st, a, jobs, c->packed, nwonly); break;
 #ifndef VC_FAST_BUILD
-            case 4: launch_fwd_t<10, 12>(st, a, jobs, c->packed); break;
-            case 5: launch_fwd_t<12, 16>(st, a, jobs, c->packed); break;
-            case 6: launch_fwd_t<16, 20>(st, a, jobs, c->packed); break;
-            case 7: launch_fwd_t<20, 24>(st, a, jobs, c->packed); break;
-            case 8: launch_fwd_t<24, 32>(st, a, jobs, c->packed); break;
+            case 4: launch_fwd_t<10, 12>(st, a, jobs, c->packed, nwonly); break;
+            case 5: launch_fwd_t<12, 16>(st, a, jobs, c->packed, nwonly); break;
+            case 6: launch_fwd_t<16, 20>(st, a, jobs, c->packed, nwonly); break;
+            case 7: launch_fwd_t<20, 24>(st, a, jobs, c->packed, nwonly); break;
+            case 8: launch_fwd_t<24, 32>(st, a, jobs, c->packed, nwonly); break;
 #else
             default: return fail(c, VC_ERR_ARG, "development build: width classes 8 / 10 only");
 #endif
@@ -396,17 +399,17 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
         Timer t(c, KC_FWD, st);
         switch (opts[i]) {
 #ifndef VC_FAST_BUILD
-            case 4:  launch_fwd_t<4, 4>(st, a, jobs, c->packed); break;
-            case 6:  launch_fwd_t<6, 6>(st, a, jobs, c->packed); break;
+            case 4:  launch_fwd_t<4, 4>(st, a, jobs, c->packed, nwonly); break;
+            case 6:  launch_fwd_t<6, 6>(st, a, jobs, c->packed, nwonly); break;
 #endif
-            case 8:  launch_fwd_t<8, 8>(st, a, jobs, c->packed); break;
-            case 10: launch_fwd_t<10, 10>(st, a, jobs, c->packed); break;
+            case 8:  launch_fwd_t<8, 8>(st, a, jobs, c->packed, nwonly); break;
+            case 10: launch_fwd_t<10, 10>(st, a, jobs, c->packed, nwonly); break;
 #ifndef VC_FAST_BUILD
-            case 12: launch_fwd_t<12, 12>(st, a, jobs, c->packed); break;
-            case 16: launch_fwd_t<16, 16>(st, a, jobs, c->packed); break;
-            case 20: launch_fwd_t<20, 20>(st, a, jobs, c->packed); break;
-            case 24: launch_fwd_t<24, 24>(st, a, jobs, c->packed); break;
-            case 32: launch_fwd_t<32, 32>(st, a, jobs, c->packed); break;
+            case 12: launch_fwd_t<12, 12>(st, a, jobs, c->packed, nwonly); break;
+            case 16: launch_fwd_t<16, 16>(st, a, jobs, c->packed, nwonly); break;
+            case 20: launch_fwd_t<20, 20>(st, a, jobs, c->packed, nwonly); break;
+            case 24: launch_fwd_t<24, 24>(st, a, jobs, c->packed, nwonly); break;
+            case 32: launch_fwd_t<32, 32>(st, a, jobs, c->packed, nwonly); break;
 #else
             default: return fail(c, VC_ERR_ARG, "development build: width classes 8 / 10 only");
 #endif
@@ -467,10 +470,10 @@ struct Plan {
 
     // banded store: the alignments whose backtrack needed a cell outside the band (a few per thousand) run once more with
     // whole rows, and are walked from there; both launches find their jobs on the list the first backtrack left
-    int redo(Work& wk, VcFwdArgs fa, VcTraceArgs ta, uint32_t njobs, uint32_t max_rows) {
+    int redo(Work& wk, VcFwdArgs fa, VcTraceArgs ta, uint32_t njobs, uint32_t max_rows, bool nwonly = false) {
         if (!c->band || fa.mode == 2) return VC_OK;
         fa.redo_list = wk.d_redo_list; fa.redo_n = wk.d_redo_n; fa.band = 0;
-        int rc = launch_fwd(c, wk.stream, fa, njobs, nullptr);
+        int rc = launch_fwd(c, wk.stream, fa, njobs, nullptr, nwonly);
         if (rc) return rc;
         ta.redo_list = wk.d_redo_list; ta.redo_n = wk.d_redo_n; ta.band = 0;
         launch_trace(wk, ta, njobs, 1, max_rows);         // listed jobs are of any window: no shared first-in-edge table
@@ -600,12 +603,14 @@ struct Plan {
             const uint32_t gsz = std::min(group, wk.nseq_max - k0);
             fa.group = gsz; fa.k0 = k0; fa.mode = 1; fa.hstride = stride;
             if (c->band) HIPCHK(c, hipMemsetAsync(wk.d_redo_n, 0, 4, wk.stream));
-            int rc = launch_fwd(c, wk.stream, fa, ns * gsz, &wk);
+            bool nwonly = true;                                // no partial-span layer among these sequences in any window of the batch?
+            for (uint32_t k = std::max(k0, 1u); k < k0 + gsz; ++k) nwonly = nwonly && !(k < c->h_layer_partial.size() && c->h_layer_partial[k]);
+            int rc = launch_fwd(c, wk.stream, fa, ns * gsz, &wk, nwonly);
             if (rc) return rc;
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
             launch_trace(wk, ta, ns * gsz, gsz, maxn);
-            if ((rc = redo(wk, fa, ta, ns * gsz, maxn))) return rc;
+            if ((rc = redo(wk, fa, ta, ns * gsz, maxn, nwonly))) return rc;
         }
         VcAddwArgs wa{};
         wa.b = c->b; wa.g = wk.gr[wk.cur]; wa.dp = wk.dp; wa.w0 = wk.w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
@@ -919,6 +924,9 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         if (wc < -31744 || (mm - gg) * (64ll * cpl + 1) >= 32767 || (sw && nn >= 0)) maybe_wide = true;
     }
     const uint32_t wcols = maybe_wide ? ((ws_max_len + 64 * VC_WIDE_CPL - 1) / (64 * VC_WIDE_CPL)) * (64 * VC_WIDE_CPL) : 0;
+    // (the int32 matrices of k_fwd_wide are 86 MB per alignment at 7 040 rows x 3 072 columns: there the chunk size IS the budget,
+    // and the 96-GiB cap above would halve it)
+    if (maybe_wide && !c->prm.scratch_bytes) budget = (uint64_t)(free_b * 0.6) / S;
     const uint64_t per_job = NC * rowd * 5 + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);

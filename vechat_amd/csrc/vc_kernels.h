@@ -1717,23 +1717,29 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     if (lane == 0) a.job_end[job] = end;
 }
 
-template <int CPL, int RING, bool PACKED, bool KEPT>
+// NWONLY: the launch holds global alignments only (every build-phase launch; re-alignment launches whose layers are all
+// full-span -- the host knows).  The kernel then carries no local-alignment body: 66 instead of 83 VGPRs at 10 cells per lane,
+// which is what lets a backtrack wave (96) sit beside five forward waves on a SIMD.
+template <int CPL, int RING, bool PACKED, bool KEPT, bool NWONLY>
 __device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_raw) {
     // alignment type of this job (uniform per wave)
     bool nw = a.mode == 0;
+    uint32_t w_of_job = 0;
     if (a.mode == 1) {
         if (a.redo_list && blockIdx.x >= *a.redo_n) return;
         const uint32_t job = a.redo_list ? a.redo_list[blockIdx.x] : blockIdx.x, slot = job / a.group;
         if (slot >= a.nslots) return;
         const uint32_t w = a.w0 + slot, k = a.k0 + job % a.group;
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
+        w_of_job = w;
         if (k < ns) {
             const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
             nw = (k == 0) || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L);
-        }
+        } else if (NWONLY) nw = true;                         // no such sequence in this window: the body resets the job's outputs and leaves
     }
     if (nw) vc_fwd_body<CPL, RING, true, PACKED, KEPT>(a, ring_raw);
-    else vc_fwd_body<CPL, RING, false, PACKED, KEPT>(a, ring_raw);
+    else if (!NWONLY) vc_fwd_body<CPL, RING, false, PACKED, KEPT>(a, ring_raw);
+    else if (vc_lane() == 0) vc_fail(a.b, w_of_job, VC_WIN_INVALID, 28, a.k0);     // the host promised global alignments only: say so, do not skip
 }
 
 // CA <= CB: the two adjacent width classes of a batch share one launch (register and LDS budget of the
@@ -1741,7 +1747,7 @@ __device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_ra
 #ifndef VC_FWD_OCC
 #define VC_FWD_OCC            // development: e.g. -DVC_FWD_OCC='__attribute__((amdgpu_waves_per_eu(4,4)))' caps the forward kernel's waves per SIMD
 #endif
-template <int CA, int CB, int RING, bool PACKED, bool KEPT>
+template <int CA, int CB, int RING, bool PACKED, bool KEPT, bool NWONLY>
 __global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
     __shared__ uint32_t ring_raw[RING * (CB / 2) * 64];
 #ifdef VC_FWD_VGPR_PAD
@@ -1756,9 +1762,9 @@ __global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
         uint32_t cls = CB;
         if (k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + k + 1] - a.b.seq_off[s0 + k]));
-        if (cls == (uint32_t)CA) { vc_fwd_any<CA, RING, PACKED, KEPT>(a, ring_raw); return; }
+        if (cls == (uint32_t)CA) { vc_fwd_any<CA, RING, PACKED, KEPT, NWONLY>(a, ring_raw); return; }
     }
-    vc_fwd_any<CB, RING, PACKED, KEPT>(a, ring_raw);
+    vc_fwd_any<CB, RING, PACKED, KEPT, NWONLY>(a, ring_raw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2421,7 +2427,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
 // as nodes_.size()/edges_.size() would grow.
 // ------------------------------------------------------------------------------------------------
 #ifndef VC_ADD_U
-#define VC_ADD_U 3             // blocks of 64 alignment pairs that k_addaln carries through its lookup chains side by side
+#define VC_ADD_U 2             // blocks of 64 alignment pairs that k_addaln carries through its lookup chains side by side (3: 90 VGPRs, a wave of it does not fit beside five k_fwd waves; 2: + 1.7 % on the job, k_addaln 650 -> 435 ms beside k_fwd; 1: + 0.6 %)
 #endif
 struct VcAddArgs {
     VcBatchDev b;
