@@ -509,8 +509,10 @@ struct Plan {
         VcFwdArgs fa = fwd_args(wk);
         fa.group = 1; fa.k0 = j; fa.mode = 0; fa.hstride = (uint64_t)NC * rowd;
         fa.tie_over = wk.d_pairs; fa.tie_over_stride = PC;      // the pair list of the job is written only after k_resolve
-        HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
-        if (c->band) HIPCHK(c, hipMemsetAsync(wk.d_redo_n, 0, 4, wk.stream));
+        if (j == 1 || c->dbg_stop_kind) {                      // later layers: k_addaln of the layer before cleared the counters
+            HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
+            HIPCHK(c, hipMemsetAsync(wk.d_redo_n, 0, 4, wk.stream));
+        }
         int rc = launch_fwd(c, wk.stream, fa, ns, &wk);
         if (rc) return rc;
         { Timer t(c, KC_RESOLVE, wk.stream);
@@ -528,6 +530,7 @@ struct Plan {
         aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
         aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16; aa.ring = (uint32_t)kRing;
         aa.make_rows = !(c->dbg_stop_kind == 1 && c->dbg_stop_index == j); aa.kept = c->kept;
+        aa.tie_n = wk.d_tie_n; aa.redo_n = wk.d_redo_n;
         { Timer t(c, KC_ADDALN, wk.stream); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, wk.stream, aa); }
         return VC_OK;
     }

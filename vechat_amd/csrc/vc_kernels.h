@@ -2439,10 +2439,14 @@ struct VcAddArgs {
     uint32_t ring;                // rows k_fwd keeps in LDS (the row records of the NEXT layer are made at the end of this kernel)
     int make_rows;                // 0: leave the row records of THIS layer in place (vc_debug_stop_after looks at them)
     uint32_t kept;                // != 0: slots of k_fwd's kept-row ring (the dynamic LDS then also covers vc_kept_lds_bytes(NC))
+    uint32_t* tie_n; uint32_t* redo_n;   // the layer's tie-list and redo-list counters: this is the layer's last kernel, it clears them for the next layer
 };
 
 __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
     VC_LATENCY_KERNEL_PRIO();
+    // every reader of the layer's counters (k_resolve, the redo pass) is an earlier kernel of this stream; a memset per counter
+    // per layer was 2 000 tiny launches per step, each waiting ~100 us for a slot beside k_fwd
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *a.tie_n = 0; *a.redo_n = 0; }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* s_curr = (uint16_t*)smem;                 // [PC] node chosen for each pair (forward order)
     uint16_t* s_anchor = s_curr + a.PC;                 // [max_len] new node t goes in front of old position anchor[t]
