@@ -45,16 +45,7 @@ BYTES_PER_CELL = 4.0           # one int16 score store + one load b
 E2E_BATCH = 16384
 
 
-def usable_cores():
-    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return n
+usable_cores = capi.usable_cores      # affinity mask, cgroup quota, shared out over the ranks of this node
 
 
 def kernel_hash():
@@ -129,20 +120,41 @@ def e2e_rate(batch, device, reps=1):
     return n / dt, cons
 
 
-def short_config(device, seed, L, D, n, profile):
-    cfg = capi.synth_cfg(seed, L, D, profile=profile)
-    b = capi.synth_batch(cfg, 0, n)
+def short_config(device, seed, L, D, n, profile, frac_partial=0.0, n_haplotypes=1, snp_rate=0.01, first=0, check=0):
+    """One short resident-input run of another workload shape; `check` > 0: that many of its windows are also run through the
+    reference itself (oracle/_ref) on the host cores and compared byte for byte (CHECKER leg, after the timed region)."""
+    cfg = capi.synth_cfg(seed, L, D, profile=profile, frac_partial=frac_partial, n_haplotypes=n_haplotypes, snp_rate=snp_rate)
+    b = capi.synth_batch(cfg, first, n, n_threads=usable_cores())
     c = HipContext(device=device)
     c.submit(b)
     c.run(); c.sync()
     t0 = time.perf_counter()
     c.run(); c.sync()
     dt = time.perf_counter() - t0
-    _, status = c.collect()
+    cons, status = c.collect()
     st = c.stats()
+    params = c.params
     c.close()
-    return {"windows_per_s": n / dt, "windows": n, "backbone_len": L, "reads_per_window": D, "gcups": st["cells"] / dt / 1e9,
-            "windows_not_ok": int((status > 1).sum())}
+    out = {"windows_per_s": n / dt, "windows": n, "backbone_len": L, "reads_per_window": D, "gcups": st["cells"] / dt / 1e9,
+           "windows_not_ok": int((status > 1).sum()), "band_redo": st.get("band_redo", 0)}
+    if frac_partial:
+        out["frac_partial_layers"] = frac_partial
+    if n_haplotypes > 1:
+        out["n_haplotypes"] = n_haplotypes; out["snp_rate"] = snp_rate
+    if check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api as oa
+        if oa.have_ref("sse41"):
+            oa.load_ref("sse41")
+            ws = list(range(0, n, max(1, n // check)))[:check]
+            with ThreadPoolExecutor(usable_cores()) as ex:
+                ref = list(ex.map(lambda w: oa.ref_window(b, w, params)[0], ws))
+            out["parity_windows_checked"] = len(ws)
+            out["parity_mismatches"] = sum(1 for w, r in zip(ws, ref) if cons[w] != r)
+            out["parity_against"] = "oracle/_ref (the reference built in place), byte comparison of the consensus"
+        else:
+            out["parity_windows_checked"] = 0
+    return out
 
 
 def stub_main(a, world):
@@ -370,9 +382,15 @@ def main():
         line["e2e"] = {"definition": "host arrays -> vc_submit -> vc_run -> vc_collect -> host bytes, H2D and D2H included, "
                                      f"two contexts / two host threads alternating over batches of {E2E_BATCH} windows",
                        "identical_to_resident_run": all(cons_np[off[w]:off[w + 1]].tobytes() == cons_e2e[w] for w in range(0, n, 97))}
-        line["configs"] = {"B": short_config(local, 1001, 500, 32, 10000, capi.PACBIO),
+        line["configs"] = {"B": short_config(local, 1001, 500, 32, 10000, capi.PACBIO, check=256),
                            "E": short_config(local, 1005, 1000, 128, 4096, capi.ONT),
-                           "W": short_config(local, 1007, 3000, 12, 1024, capi.PACBIO)}      # every alignment on k_fwd_wide (int32, column tiles)
+                           "W": short_config(local, 1007, 3000, 12, 1024, capi.PACBIO),      # every alignment on k_fwd_wide (int32, column tiles)
+                           # the hard cases of SURVEY 8(d): partial-span layers (Subgraph + local re-alignment), two haplotypes
+                           # (graphs that stay branched after pruning), and the per-rank shards of configs D and E on this one GPU
+                           "C_mixed": short_config(local, 1011, 500, 64, 16384, capi.PACBIO, frac_partial=0.2, check=256),
+                           "C_hap2": short_config(local, 1012, 500, 64, 16384, capi.PACBIO, n_haplotypes=2, snp_rate=0.01, check=256),
+                           "D_shard": short_config(local, 1002, 500, 64, 125000, capi.PACBIO, first=3 * 125000, check=256),
+                           "E_shard": short_config(local, 1005, 1000, 128, 6250, capi.ONT, first=5 * 6250, check=256)}
     if rank == 0 and world == 1 and not a.no_cpu:
         cb, ref_out = cpu_baseline(batch, ctx_params, a.cpu_seconds)
         cons_np = cons_all.cpu().numpy()

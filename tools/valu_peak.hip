@@ -14,10 +14,17 @@
 // MODE 2: dependent chain of DPP row_shr max (the cross-lane scan step)
 // MODE 3: 8 independent v_perm_b32
 // MODE 4: 8 independent v_max_i32 (32-bit reference)
+// MODE 5: 8 independent chains of v_pk_max_f16 / v_pk_add_f16   (round 4: does a packed-f16 max-plus issue faster than packed i16?)
+// MODE 6: 8 independent chains of v_max_f32 / v_add_f32
+// MODE 7: 4 independent chains of v_pk_add_f32 (64-bit register pairs)
+// MODE 8: 8 independent v_fma_f32
+// MODE 9: 8 independent v_pk_fma_f16
 template <int MODE>
 __global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, unsigned long long* cyc) {
     uint32_t r0 = threadIdx.x, r1 = r0 * 3 + 1, r2 = r0 * 5 + 2, r3 = r0 * 7 + 3, r4 = r0 ^ 0x55, r5 = r0 + 77, r6 = r0 * 11, r7 = r0 + 9;
     const uint32_t c = 0x00010001u * (blockIdx.x & 3) + 0x00020001u;
+    unsigned long long q0 = r0 | ((unsigned long long)r1 << 32), q1 = r2 | ((unsigned long long)r3 << 32), q2 = r4 | ((unsigned long long)r5 << 32), q3 = r6 | ((unsigned long long)r7 << 32);
+    const unsigned long long qc = c | ((unsigned long long)c << 32);
     const unsigned long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) {
@@ -49,6 +56,41 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, unsigned
                 "v_perm_b32 %0, %0, %8, %9\n v_perm_b32 %1, %1, %8, %9\n v_perm_b32 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n"
                 "v_perm_b32 %4, %4, %8, %9\n v_perm_b32 %5, %5, %8, %9\n v_perm_b32 %6, %6, %8, %9\n v_perm_b32 %7, %7, %8, %9\n"
                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c), "v"(0x06040200u));
+        } else if (MODE == 5) {
+            asm volatile(
+                "v_pk_max_f16 %0, %0, %8\n v_pk_add_f16 %1, %1, %8\n v_pk_max_f16 %2, %2, %8\n v_pk_add_f16 %3, %3, %8\n"
+                "v_pk_max_f16 %4, %4, %8\n v_pk_add_f16 %5, %5, %8\n v_pk_max_f16 %6, %6, %8\n v_pk_add_f16 %7, %7, %8\n"
+                "v_pk_max_f16 %0, %0, %8\n v_pk_add_f16 %1, %1, %8\n v_pk_max_f16 %2, %2, %8\n v_pk_add_f16 %3, %3, %8\n"
+                "v_pk_max_f16 %4, %4, %8\n v_pk_add_f16 %5, %5, %8\n v_pk_max_f16 %6, %6, %8\n v_pk_add_f16 %7, %7, %8\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c));
+        } else if (MODE == 6) {
+            asm volatile(
+                "v_max_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                "v_max_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                "v_max_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                "v_max_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c));
+        } else if (MODE == 7) {
+            asm volatile(
+                "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qc));
+        } else if (MODE == 8) {
+            asm volatile(
+                "v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                "v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c));
+        } else if (MODE == 9) {
+            asm volatile(
+                "v_pk_fma_f16 %0, %0, %8, %8\n v_pk_fma_f16 %1, %1, %8, %8\n v_pk_fma_f16 %2, %2, %8, %8\n v_pk_fma_f16 %3, %3, %8, %8\n"
+                "v_pk_fma_f16 %4, %4, %8, %8\n v_pk_fma_f16 %5, %5, %8, %8\n v_pk_fma_f16 %6, %6, %8, %8\n v_pk_fma_f16 %7, %7, %8, %8\n"
+                "v_pk_fma_f16 %0, %0, %8, %8\n v_pk_fma_f16 %1, %1, %8, %8\n v_pk_fma_f16 %2, %2, %8, %8\n v_pk_fma_f16 %3, %3, %8, %8\n"
+                "v_pk_fma_f16 %4, %4, %8, %8\n v_pk_fma_f16 %5, %5, %8, %8\n v_pk_fma_f16 %6, %6, %8, %8\n v_pk_fma_f16 %7, %7, %8, %8\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c));
         } else {
             asm volatile(
                 "v_max_i32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_max_i32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
@@ -59,7 +101,7 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, unsigned
         }
     }
     const unsigned long long t1 = clock64();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + (uint32_t)(q0 + q1 + q2 + q3) + (uint32_t)((q0 + q1 + q2 + q3) >> 32);
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
 }
 
@@ -98,6 +140,11 @@ int main() {
     for (int w : {1, 2, 4, 8}) if (run<0>("pk_i16_independent", w, n_cu, 16)) return 1;
     for (int w : {1, 4}) if (run<4>("i32_independent", w, n_cu, 16)) return 1;
     for (int w : {1, 4}) if (run<3>("v_perm_independent", w, n_cu, 16)) return 1;
+    for (int w : {1, 2, 4, 8}) if (run<5>("pk_f16_independent", w, n_cu, 16)) return 1;
+    for (int w : {1, 2, 4, 8}) if (run<6>("f32_max_add_independent", w, n_cu, 16)) return 1;
+    for (int w : {1, 2, 4, 8}) if (run<7>("pk_add_f32_independent", w, n_cu, 16)) return 1;
+    for (int w : {1, 4, 8}) if (run<8>("fma_f32_independent", w, n_cu, 16)) return 1;
+    for (int w : {1, 4, 8}) if (run<9>("pk_fma_f16_independent", w, n_cu, 16)) return 1;
     for (int w : {1, 2, 4}) if (run<1>("pk_i16_dependent", w, n_cu, 16)) return 1;
     for (int w : {1, 4}) if (run<2>("dpp_max_dependent", w, n_cu, 8)) return 1;
     return 0;

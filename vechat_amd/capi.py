@@ -288,10 +288,27 @@ def synth_cfg(seed, backbone_len, n_layers, profile=PACBIO, frac_partial=0.0, fa
                       n_haplotypes=n_haplotypes, snp_rate=snp_rate)
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota, shared out over the ranks
+    of a one-process-per-GPU launch on this node (LOCAL_WORLD_SIZE): eight ranks must not start eight full-size pools."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        local_world = 1
+    return max(1, n // max(1, local_world))
+
+
 def synth_batch(cfg, first, n, n_threads=0, lib=None):
     """Generate windows [first, first+n) of the synthetic stream as a Batch (rank-ordered layers)."""
     lib = lib or load_host()
-    n_threads = n_threads or min(os.cpu_count() or 1, 32)
+    n_threads = n_threads or min(usable_cores(), 32)
     h = lib.vc_synth_generate(C.byref(cfg), first, n, n_threads)
     if not h:
         raise RuntimeError("vc_synth_generate failed")

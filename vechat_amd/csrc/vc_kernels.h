@@ -1262,8 +1262,21 @@ __device__ __forceinline__ int vc_packed_cell(const uint32_t* w, uint32_t cc, ui
 //     max_p (H[p][j-1] + P[j]) = (max_p H[p][j-1]) + P[j],   max_p (H[p][j] + g) = (max_p H[p][j]) + g,
 // so each additional in-edge costs one packed max per register instead of a full relaxation, and the
 // order of the in-edges is irrelevant here (it matters only to the backtrack, which follows it).
-template <int CPL, int RING, bool NWT, bool PACKED, bool KEPT>
-__device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_raw) {
+// The alignment a forward wave works on.  Lock-step launches derive it from the workgroup index (vc_fwd_pick); the waves of the
+// persistent build pipeline (vc_pipe.h) take it from their work queue.
+struct VcJob {
+    uint32_t job;       // index of the per-alignment buffers (stored matrix, column 0, end cell, ties)
+    uint32_t slot;      // window of the chunk
+    uint32_t k;         // sequence of the window
+    bool redo;          // second pass with whole rows (the backtrack left the band)
+};
+// what vc_fwd_body did with its job
+#define VC_FWD_NONE 0u      // nothing to do here (another width class, no such sequence, window not OK, outside the envelope)
+#define VC_FWD_DONE 1u
+#define VC_FWD_TIE  2u      // done, and the end cell is tied between sinks on a non-reference order: the resolver decides
+
+template <int CPL, int RING, bool NWT, bool PACKED, bool KEPT, bool PIPE = false>
+__device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_raw, const VcJob& jb) {
     // KEPT: the LDS ring holds RING SLOTS for the rows a later row reads back (vc_frec_kept gave every such row its slot);
     // otherwise the last RING rows, slot = row % RING
     static_assert(KEPT || (RING & (RING - 1)) == 0, "ring slots are taken with a mask");
@@ -1271,20 +1284,16 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     constexpr int NDS = vc_nds(CPL);         // dwords per lane per row in the packed stored form
     uint32_t (*ring)[ND][64] = reinterpret_cast<uint32_t (*)[ND][64]>(ring_raw);
     const int lane = vc_lane();
-    const bool redo = a.redo_list != nullptr;                 // second pass over the alignments whose backtrack left the band
-    if (redo && blockIdx.x >= *a.redo_n) return;
-    const uint32_t job = redo ? a.redo_list[blockIdx.x] : blockIdx.x;
-    const uint32_t slot = job / a.group;
-    if (slot >= a.nslots) return;
-    const uint32_t k = a.k0 + job % a.group;
+    const bool redo = jb.redo;                                // second pass over the alignments whose backtrack left the band
+    const uint32_t job = jb.job, slot = jb.slot, k = jb.k;
     const uint32_t w = a.w0 + slot;
     if (a.do_init && lane == 0 && !redo) { a.job_type[job] = 255; a.job_end[job] = 0; a.tie_cnt[job] = 0; }
-    if (a.b.status[w] != VC_WIN_OK) return;
+    if (a.b.status[w] != VC_WIN_OK) return VC_FWD_NONE;
     const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
-    if (k >= ns) return;
+    if (k >= ns) return VC_FWD_NONE;
     const uint64_t so = a.b.seq_off[s0 + k];
     const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k + 1] - so);
-    if (vc_cpl_for(len) != (uint32_t)CPL) return;             // another width class handles this sequence
+    if (vc_cpl_for(len) != (uint32_t)CPL) return VC_FWD_NONE;             // another width class handles this sequence
     const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
     // NW or SW is fixed per instantiation (the caller looked at the layer, window.cpp:336-349): the row loop
     // then carries no alignment-type branches
@@ -1293,7 +1302,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         bool want = true;
         if (a.mode == 2) want = false;
         else if (a.mode == 1) want = (k == 0) || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L);
-        if (want != nw) return;
+        if (want != nw) return VC_FWD_NONE;
     }
     const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
     const uint32_t nrows = a.dp.nrows[slot];
@@ -1315,7 +1324,7 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
             // length, like the reference's fallback to 32-bit lanes, simd impl:699-706) takes it
             if (len == 0 || nrows == 0 || (a.dp.flags[slot] & 1u)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 3, (a.dp.flags[slot] & 1u) ? 1 : 2); }
             else if (a.wcols == 0) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 27, nrows); }    // the host planned no k_fwd_wide: say so, do not skip silently
-            return;
+            return VC_FWD_NONE;
         }
     }
     if (lane == 0 && !redo) {
@@ -1675,13 +1684,15 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
     }
     if (lane == 0 && far_reads && !redo) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
 
-    if (redo) return;                                       // the end cell, ties and counters stand from the first pass
+    if (redo) return VC_FWD_DONE;                           // the end cell, ties and counters stand from the first pass
     // publish the end cell
     uint32_t end = 0;
+    uint32_t outcome = VC_FWD_DONE;
     if (nw) {
         end = (best_row << 16) | len;
         if (ntie > 1 && (a.dp.flags[slot] & 2u)) {          // tie on a non-reference order: k_resolve decides
-            if (lane == 0) { a.tie_cnt[job] = ntie; a.tie_list[atomicAdd(a.tie_n, 1u)] = slot; }
+            if (lane == 0) { a.tie_cnt[job] = ntie; if (!PIPE) a.tie_list[atomicAdd(a.tie_n, 1u)] = slot; }
+            outcome = VC_FWD_TIE;                           // (the persistent pipeline hands the window to its resolver wave instead of the list)
         }
     } else {
         const int gmax = wave_max_i32(best);
@@ -1715,31 +1726,38 @@ __device__ __forceinline__ void vc_fwd_body(const VcFwdArgs& a, uint32_t* ring_r
         }
     }
     if (lane == 0) a.job_end[job] = end;
+    return outcome;
+}
+
+// the job of this workgroup in a lock-step launch: workgroup index, or the entry of the redo list
+__device__ __forceinline__ bool vc_fwd_pick(const VcFwdArgs& a, VcJob& jb) {
+    jb.redo = a.redo_list != nullptr;
+    if (jb.redo && blockIdx.x >= *a.redo_n) return false;
+    jb.job = jb.redo ? a.redo_list[blockIdx.x] : blockIdx.x;
+    jb.slot = jb.job / a.group;
+    if (jb.slot >= a.nslots) return false;
+    jb.k = a.k0 + jb.job % a.group;
+    return true;
 }
 
 // NWONLY: the launch holds global alignments only (every build-phase launch; re-alignment launches whose layers are all
 // full-span -- the host knows).  The kernel then carries no local-alignment body: 66 instead of 83 VGPRs at 10 cells per lane,
 // which is what lets a backtrack wave (96) sit beside five forward waves on a SIMD.
 template <int CPL, int RING, bool PACKED, bool KEPT, bool NWONLY>
-__device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_raw) {
+__device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_raw, const VcJob& jb) {
     // alignment type of this job (uniform per wave)
     bool nw = a.mode == 0;
-    uint32_t w_of_job = 0;
+    const uint32_t w = a.w0 + jb.slot;
     if (a.mode == 1) {
-        if (a.redo_list && blockIdx.x >= *a.redo_n) return;
-        const uint32_t job = a.redo_list ? a.redo_list[blockIdx.x] : blockIdx.x, slot = job / a.group;
-        if (slot >= a.nslots) return;
-        const uint32_t w = a.w0 + slot, k = a.k0 + job % a.group;
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
-        w_of_job = w;
-        if (k < ns) {
+        if (jb.k < ns) {
             const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
-            nw = (k == 0) || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L);
+            nw = (jb.k == 0) || vc_full_span(a.b.seq_begin[s0 + jb.k], a.b.seq_end[s0 + jb.k], L);
         } else if (NWONLY) nw = true;                         // no such sequence in this window: the body resets the job's outputs and leaves
     }
-    if (nw) vc_fwd_body<CPL, RING, true, PACKED, KEPT>(a, ring_raw);
-    else if (!NWONLY) vc_fwd_body<CPL, RING, false, PACKED, KEPT>(a, ring_raw);
-    else if (vc_lane() == 0) vc_fail(a.b, w_of_job, VC_WIN_INVALID, 28, a.k0);     // the host promised global alignments only: say so, do not skip
+    if (nw) (void)vc_fwd_body<CPL, RING, true, PACKED, KEPT>(a, ring_raw, jb);
+    else if (!NWONLY) (void)vc_fwd_body<CPL, RING, false, PACKED, KEPT>(a, ring_raw, jb);
+    else if (vc_lane() == 0) vc_fail(a.b, w, VC_WIN_INVALID, 28, a.k0);     // the host promised global alignments only: say so, do not skip
 }
 
 // CA <= CB: the two adjacent width classes of a batch share one launch (register and LDS budget of the
@@ -1753,18 +1771,17 @@ __global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
 #ifdef VC_FWD_VGPR_PAD
     asm volatile("; keep the register allocation at 104: four forward waves per SIMD leave LDS and registers to the other kernels" ::: "v103");
 #endif
+    VcJob jb;
+    if (!vc_fwd_pick(a, jb)) return;
     if (CA != CB) {
         // sequence length of this job decides the body (uniform per wave)
-        if (a.redo_list && blockIdx.x >= *a.redo_n) return;
-        const uint32_t job = a.redo_list ? a.redo_list[blockIdx.x] : blockIdx.x, slot = job / a.group;
-        if (slot >= a.nslots) return;
-        const uint32_t w = a.w0 + slot, k = a.k0 + job % a.group;
+        const uint32_t w = a.w0 + jb.slot;
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
         uint32_t cls = CB;
-        if (k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + k + 1] - a.b.seq_off[s0 + k]));
-        if (cls == (uint32_t)CA) { vc_fwd_any<CA, RING, PACKED, KEPT, NWONLY>(a, ring_raw); return; }
+        if (jb.k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + jb.k + 1] - a.b.seq_off[s0 + jb.k]));
+        if (cls == (uint32_t)CA) { vc_fwd_any<CA, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb); return; }
     }
-    vc_fwd_any<CB, RING, PACKED, KEPT, NWONLY>(a, ring_raw);
+    vc_fwd_any<CB, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2160,9 +2177,14 @@ __device__ __forceinline__ int vc_row_shr1(int v, int first) {          // value
     return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false);
 }
 
-__global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
-    VC_LATENCY_KERNEL_PRIO();
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// The walk of the VC_TG alignments of one wave.  Group g (lanes 16 g .. 16 g + 15) walks alignment `job` of window `slot`,
+// sequence k, pair list pj; `redo`: its matrix was stored whole (no band).  Lock-step launches take these from the workgroup
+// index (k_tracew), the persistent build pipeline (vc_pipe.h) from its work queue -- there the groups of a wave hold alignments
+// of different windows AND different layers.  Returns (per lane of the group) whether the alignment left the band; PIPE: the
+// caller puts it on its own redo queue instead of the launch's redo list.
+template <bool PIPE>
+__device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* smem, uint32_t job, const uint32_t slot, const uint32_t k,
+                                               const uint64_t pj, bool valid, const bool redo) {
     const int lane = vc_lane();
     const uint32_t grp = (uint32_t)lane / VC_TL, gl = (uint32_t)lane % VC_TL, gbase = grp * VC_TL;
     // first in-edge distance of row r (0: do not speculate).  In the re-alignment rounds the alignments of a
@@ -2170,23 +2192,11 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     const bool shared_tab = a.shared_table != 0;
     uint8_t* tab = smem + (shared_tab ? 0u : grp) * (vc_tracew_tab_len(a.tab_rows) / 2u);       // two entries per byte
     auto tab_at = [&](uint32_t r) __attribute__((always_inline)) -> uint32_t { return ((uint32_t)tab[r >> 1] >> ((r & 1u) * 4u)) & 15u; };
-    const uint32_t njobs = a.nslots * a.group;
-    const bool redo = a.redo_list != nullptr;
-    uint32_t job = blockIdx.x * VC_TG + grp;
-    bool valid = job < njobs;
-    if (redo) {                                               // second pass: the jobs the first one gave up on
-        const uint32_t nr = *a.redo_n;
-        if (blockIdx.x * VC_TG >= nr) return;
-        valid = job < nr;
-        job = valid ? a.redo_list[job] : 0u;
-    }
-    const uint32_t slot = valid ? job / a.group : 0, k = valid ? a.k0 + job % a.group : 0;
     const uint32_t w = a.w0 + slot;
-    const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
     const uint8_t type = valid ? a.job_type[job] : (uint8_t)255;
     valid = valid && type < 2;                                // 255: nothing to walk; 2, 3: k_fwd_wide's, walked by k_trace
     if (valid && a.b.status[w] != VC_WIN_OK) valid = false;
-    if (!__any(valid)) return;
+    if (!__any(valid)) return false;
     uint32_t* out = a.pairs + pj * a.PC;
     const uint32_t end = valid ? a.job_end[job] : 0u;
     const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
@@ -2403,7 +2413,7 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         }
     }
     if (valid && gl == 0) {
-        if (gredo) { gnout = 0; a.redo_out[atomicAdd(a.redo_out_n, 1u)] = job; }
+        if (gredo) { gnout = 0; if (!PIPE) a.redo_out[atomicAdd(a.redo_out_n, 1u)] = job; }
         else if (gbroken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, gi); gnout = 0; }
         else if (govf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, gnout); gnout = 0; }
         a.npairs[pj] = gnout;
@@ -2417,6 +2427,26 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
             atomicAdd(st + 4, (unsigned long long)s0); atomicAdd(st + 5, (unsigned long long)s1); atomicAdd(st + 6, (unsigned long long)s2);
         }
     }
+    return valid && gredo;
+}
+
+__global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
+    VC_LATENCY_KERNEL_PRIO();
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t grp = (uint32_t)vc_lane() / VC_TL;
+    const uint32_t njobs = a.nslots * a.group;
+    const bool redo = a.redo_list != nullptr;
+    uint32_t job = blockIdx.x * VC_TG + grp;
+    bool valid = job < njobs;
+    if (redo) {                                               // second pass: the jobs the first one gave up on
+        const uint32_t nr = *a.redo_n;
+        if (blockIdx.x * VC_TG >= nr) return;
+        valid = job < nr;
+        job = valid ? a.redo_list[job] : 0u;
+    }
+    const uint32_t slot = valid ? job / a.group : 0, k = valid ? a.k0 + job % a.group : 0;
+    const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
+    (void)vc_tracew_body<false>(a, smem, job, slot, k, pj, valid, redo);
 }
 
 // ------------------------------------------------------------------------------------------------
