@@ -120,12 +120,12 @@ def e2e_rate(batch, device, reps=1):
     return n / dt, cons
 
 
-def short_config(device, seed, L, D, n, profile, frac_partial=0.0, n_haplotypes=1, snp_rate=0.01, first=0, check=0):
+def short_config(device, seed, L, D, n, profile, frac_partial=0.0, n_haplotypes=1, snp_rate=0.01, first=0, check=0, pipeline=None, chunk=0, streams=0):
     """One short resident-input run of another workload shape; `check` > 0: that many of its windows are also run through the
     reference itself (oracle/_ref) on the host cores and compared byte for byte (CHECKER leg, after the timed region)."""
     cfg = capi.synth_cfg(seed, L, D, profile=profile, frac_partial=frac_partial, n_haplotypes=n_haplotypes, snp_rate=snp_rate)
     b = capi.synth_batch(cfg, first, n, n_threads=usable_cores())
-    c = HipContext(device=device)
+    c = HipContext(device=device, pipeline=pipeline, chunk_windows=chunk, n_streams=streams)
     c.submit(b)
     c.run(); c.sync()
     t0 = time.perf_counter()
@@ -137,6 +137,11 @@ def short_config(device, seed, L, D, n, profile, frac_partial=0.0, n_haplotypes=
     c.close()
     out = {"windows_per_s": n / dt, "windows": n, "backbone_len": L, "reads_per_window": D, "gcups": st["cells"] / dt / 1e9,
            "windows_not_ok": int((status > 1).sum()), "band_redo": st.get("band_redo", 0)}
+    if pipeline:
+        out["plan"] = ("persistent build pipeline (vc_set_pipeline 1): the build loop of a chunk as two resident kernels and device-side queues, "
+                       "the re-alignment rounds lock-step on the same stream; the headline `value` is the lock-step plan")
+        out["launches"] = int(sum(k["launches"] for k in st["kernels"].values()))
+        out["chunk_windows"] = st["chunk_windows"]; out["streams"] = st["n_streams"]
     if frac_partial:
         out["frac_partial_layers"] = frac_partial
     if n_haplotypes > 1:
@@ -387,6 +392,8 @@ def main():
                            "W": short_config(local, 1007, 3000, 12, 1024, capi.PACBIO),      # every alignment on k_fwd_wide (int32, column tiles)
                            # the hard cases of SURVEY 8(d): partial-span layers (Subgraph + local re-alignment), two haplotypes
                            # (graphs that stay branched after pruning), and the per-rank shards of configs D and E on this one GPU
+                           # the other execution plan of the build loop, on the same workload (32 768 windows of config C)
+                           "C_pipeline": short_config(local, 1002, 500, 64, 32768, capi.PACBIO, check=256, pipeline=True, chunk=16384, streams=1),
                            "C_mixed": short_config(local, 1011, 500, 64, 16384, capi.PACBIO, frac_partial=0.2, check=256),
                            "C_hap2": short_config(local, 1012, 500, 64, 16384, capi.PACBIO, n_haplotypes=2, snp_rate=0.01, check=256),
                            "D_shard": short_config(local, 1002, 500, 64, 125000, capi.PACBIO, first=3 * 125000, check=256),

@@ -130,6 +130,12 @@ int vc_debug_stop_after(vc_ctx* ctx, uint32_t kind, uint32_t index);
 int vc_debug_stage_digest(vc_ctx* ctx, uint32_t window, int with_pairs, uint64_t* out /*[8], [0..1] untouched*/);
 void* vc_stream(vc_ctx* ctx);                         /* the hipStream_t the context launches on               */
 int   vc_set_profile(vc_ctx* ctx, int profile);       /* change vc_params.profile of a live context (0, 1, 2)  */
+/* Execution plan of the build loop (src/window.cpp:239-298).  0 (default): lock-step -- one launch per kernel per layer for a
+ * whole chunk.  1: persistent pipeline -- two resident kernels per chunk (forward + AddAlignment waves, backtrack waves) that
+ * hand windows to each other through device-side queues, no launch and no lock-step per layer (vechat_amd/csrc/vc_pipe.h).
+ * Results are identical either way; the environment variable VC_PIPE=0/1 sets the default of a new context.
+ * forward_waves / backtrack_waves: resident workgroups of the two kernels (0: 15 and 5 per CU). */
+int   vc_set_pipeline(vc_ctx* ctx, int on, uint32_t forward_waves, uint32_t backtrack_waves);
 
 /* -- host helpers that keep reference semantics on the host side of the boundary ---------------- */
 /* rank[] as produced by window.cpp:203-210: rank[0]=0, rank[1..] = std::sort of 1..n-1 by begin

@@ -25,6 +25,23 @@ for rep in range(2):
         acc[k] += s[k]
     km = {k: round(v['ms'], 1) for k, v in s['kernels'].items()}
     print(f"rep {rep}: {n/(t1-t0):.1f} win/s ({t1-t0:.3f}s) cells={s['cells']:.3e} GCUPS={s['cells']/(t1-t0)/1e9:.1f} rows={s['dp_rows']:.3e} far={s['far_row_reads']} redo={s['band_redo']} trace steps/spec/rounds={s['trace_steps']}/{s['trace_spec']}/{s['trace_rounds']} NC={s['max_nodes']} EC={s['max_edges']} CW={s['chunk_windows']}x{s['n_streams']} dev={s.get('device_bytes', 0)/2**30:.1f}GiB ms={km}", flush=True)
+if os.environ.get("VC_PIPE") == "1":
+    import ctypes as C
+    pp = (C.c_uint64 * 144)()
+    ctx.lib.vc_debug_pipe_prof.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    ctx.lib.vc_debug_pipe_prof(ctx.h, pp)
+    v = list(pp)
+    ms = lambda x: x / 1e5          # ticks of 100 MHz -> ms
+    if v[5] and v[11] and v[4] and v[10]:
+        print(f"pipe F waves={v[5]} items={v[4]}: per wave wait {ms(v[0])/v[5]:.1f} add {ms(v[1])/v[5]:.1f} fwd {ms(v[2])/v[5]:.1f} hand {ms(v[3])/v[5]:.1f} ms; per item add {ms(v[1])/v[4]*1e3:.0f} fwd {ms(v[2])/v[4]*1e3:.0f} hand {ms(v[3])/v[4]*1e3:.0f} us", flush=True)
+        print(f"pipe T waves={v[11]} rounds={v[9]} items={v[10]} ties={v[12]}: per wave wait {ms(v[6])/v[11]:.1f} walk {ms(v[7])/v[11]:.1f} hand {ms(v[8])/v[11]:.1f} ms; per round walk {ms(v[7])/v[9]*1e3:.0f} hand {ms(v[8])/v[9]*1e3:.0f} us; items per round {v[10]/v[9]:.2f}", flush=True)
+    if os.environ.get("VC_PIPE") == "1":
+        tl = lambda k: [round(x / 1e5) for x in v[16 + 32 * k: 16 + 32 * k + 32]]
+        print(f"tie resolution: {ms(v[15])/max(v[12],1)*1e3:.0f} us per tie, {ms(v[15])/max(v[11],1):.1f} ms per T wave")
+        print(f"pickup latency (publish -> consumer has it): F {ms(v[13])/max(v[4],1)*1e3:.0f} us per item, T {ms(v[14])/max(v[10],1)*1e3:.0f} us per item")
+        print("timeline (20 ms buckets since wave start, summed over waves and chunks)")
+        print("  F wait ms ", tl(0)); print("  F busy ms ", tl(1))
+        print("  T rounds  ", v[16 + 64: 16 + 96]); print("  T items   ", v[16 + 96: 16 + 128])
 cons, status = ctx.collect()
 import collections
 print("status histogram", collections.Counter(int(x) for x in status), "errinfo sample", [e for e in ctx.errinfo() if e != (0, 0)][:5])

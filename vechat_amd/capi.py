@@ -269,6 +269,8 @@ def load_hip():
         lib.vc_debug_stage_digest.restype = C.c_int
         lib.vc_set_profile.argtypes = [vp, C.c_int]
         lib.vc_set_profile.restype = C.c_int
+        lib.vc_set_pipeline.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
+        lib.vc_set_pipeline.restype = C.c_int
         lib.vc_stream.argtypes = [vp]
         lib.vc_stream.restype = vp
         _hip = lib

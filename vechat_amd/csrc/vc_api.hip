@@ -27,14 +27,15 @@
 #include <vector>
 
 #include "vc_kernels.h"
+#include "vc_pipe.h"
 
 namespace {
 
 thread_local std::string g_create_error;
 
-enum KClass { KC_AVG = 0, KC_INIT, KC_TOPO, KC_FWD, KC_TRACE, KC_ADDALN, KC_PRUNE, KC_ADDW, KC_FINISH, KC_ROWS, KC_RESOLVE, KC_CONS, KC_N };
+enum KClass { KC_AVG = 0, KC_INIT, KC_TOPO, KC_FWD, KC_TRACE, KC_ADDALN, KC_PRUNE, KC_ADDW, KC_FINISH, KC_ROWS, KC_RESOLVE, KC_CONS, KC_PIPE, KC_N };
 const char* kClassNames[KC_N] = {"k_avg", "k_init", "k_topo", "k_fwd", "k_trace", "k_addaln", "k_prune_lcc",
-                                 "k_addw", "k_finish", "k_rows", "k_resolve", "k_consensus"};
+                                 "k_addw", "k_finish", "k_rows", "k_resolve", "k_consensus", "k_pipe"};
 
 #ifndef VC_RING
 #define VC_RING 8
@@ -77,6 +78,13 @@ struct Work {
     uint16_t* d_scratch16 = nullptr;                                 // k_addaln per-pair notes
     uint32_t* d_submask = nullptr;                                   // [CW*(NC/32+1)] Subgraph membership by node id
     uint32_t* h_maxn = nullptr;                                      // pinned: [0] max rows, [1] max edges after a prune round
+    // persistent build pipeline (vc_pipe.h): counters, three queues, the layer every window is at; the backtrack and resolver
+    // kernels run beside the forward kernel on streams of their own
+    uint32_t* d_pipe_ctl = nullptr; unsigned long long* d_pipe_slots = nullptr; uint32_t* d_cur_layer = nullptr;
+    uint32_t pipe_cap = 0;
+    uint8_t* d_pipe_ws = nullptr; size_t pipe_ws_bytes = 0;
+    hipStream_t st_t = nullptr;
+    hipEvent_t ev_seed = nullptr, ev_t = nullptr;
     bool pruned_known = false;                                       // h_maxn describes the current graphs
     // state of the chunk currently in flight
     uint32_t w0 = 0, ns = 0, layers = 0, nseq_max = 0;
@@ -135,6 +143,14 @@ struct vc_ctx {
     // host wait of the path -- the pruned graphs' height before a re-alignment round -- then stalls that stream only, and a
     // stream takes its next chunk as soon as it is done (no lockstep between streams, no barrier between groups of chunks).
     bool host_threads = true;
+    // persistent build pipeline: the build loop of a chunk as three resident kernels and device-side queues instead of six launches
+    // per layer (vc_pipe.h); pipe_f / pipe_t / pipe_r: resident workgroups of the forward / backtrack / resolver kernels (0: default)
+    bool pipe = false;
+    uint32_t pipe_f = 0, pipe_t = 0;
+    uint32_t pipe_patience_s = 20;       // seconds a wave of the pipeline waits for an item before it declares the run failed (VC_PIPE_PATIENCE)
+    unsigned long long* d_pipe_prof = nullptr;   // [VC_PP_N] phase clocks of the pipeline's waves, summed over a run (vc_debug_pipe_prof)
+    uint32_t* d_pipe_abort = nullptr;    // != 0: a wave of the pipeline ran out of patience (site code): the run failed
+    uint32_t n_cu = 256;
     std::thread workers[kMaxStreams];
     bool workers_running = false;
     std::atomic<uint32_t> next_chunk{0};
@@ -189,7 +205,10 @@ void join_workers(vc_ctx* c) {
 void sync_ctx(vc_ctx* c) {
     join_workers(c);
     (void)hipStreamSynchronize(c->stream);
-    for (uint32_t k = 0; k < c->n_streams; ++k) if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
+    for (uint32_t k = 0; k < c->n_streams; ++k) {
+        if (c->works[k].st_t) (void)hipStreamSynchronize(c->works[k].st_t);
+        if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
+    }
 }
 
 template <typename T>
@@ -270,6 +289,18 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->d_submask, CW * (NC / 32 + 1))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_maxn, 2)))
         return rc;
+    {
+        uint32_t cap = 64;
+        while (cap < CW) cap <<= 1;
+        wk->pipe_cap = cap;
+        // (the exact-DFS fallback of the end-cell resolver works from an HBM image of the graph: one per backtrack workgroup)
+        wk->pipe_ws_bytes = (size_t)std::min<uint64_t>((CW + VC_TG - 1) / VC_TG, 256u * 8u) * ((topo_lds_bytes(NC, c->EC, c->STK, c->MA) + 15u) & ~15u);
+        if ((rc = dalloc(c, c->chunk_allocs, &wk->d_pipe_ctl, (size_t)VC_PC_N * VC_PIPE_CTL_STRIDE)) ||
+            (rc = dalloc(c, c->chunk_allocs, &wk->d_pipe_slots, (size_t)2 * cap)) ||
+            (rc = dalloc(c, c->chunk_allocs, &wk->d_cur_layer, CW)) ||
+            (rc = dalloc(c, c->chunk_allocs, &wk->d_pipe_ws, wk->pipe_ws_bytes)))
+            return rc;
+    }
     return VC_OK;
 }
 
@@ -420,6 +451,41 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
     return VC_OK;
 }
 
+// the forward kernel of the persistent build pipeline for this batch's width classes (one class, or two adjacent ones)
+template <int CA, int CB>
+int launch_pipe_fwd_t(vc_ctx* c, hipStream_t st, const VcPipeFwdArgs& a, uint32_t grid, uint32_t lds) {
+    auto k = k_pipe_fwd<CA, CB, (kKept ? kKept : 1), true>;
+    HIPCHK(c, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, a);
+    return VC_OK;
+}
+// The pipeline's forward kernel is built for the widest class of the batch and the one below it (everything narrower runs
+// in that lower class: partial-span layers are short).  -> (CA, CB), CA == CB when the batch has one class.
+bool pipe_classes(const vc_ctx* c, uint32_t* ca, uint32_t* cb) {
+    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
+    int lo = -1, hi = -1;
+    for (int i = 0; i < 9; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
+    if (lo < 0 || hi < 0) return false;
+    *cb = opts[hi]; *ca = lo < hi ? opts[hi - 1] : opts[hi];
+#ifdef VC_FAST_BUILD
+    return *cb == 10 || *cb == 8;
+#else
+    return true;
+#endif
+}
+int launch_pipe_fwd(vc_ctx* c, hipStream_t st, const VcPipeFwdArgs& a, uint32_t grid, uint32_t lds) {
+    uint32_t lo = 0, hi = 0;
+    if (!pipe_classes(c, &lo, &hi)) return fail(c, VC_ERR_ARG, "persistent pipeline: unsupported cells-per-lane %u..%u", c->cpl_min, c->cpl);
+#define VC_PF(A, B) if (lo == A && hi == B) return launch_pipe_fwd_t<A, B>(c, st, a, grid, lds);
+    VC_PF(8, 10) VC_PF(8, 8) VC_PF(10, 10) VC_PF(6, 8)
+#ifndef VC_FAST_BUILD
+    VC_PF(4, 4) VC_PF(4, 6) VC_PF(6, 6) VC_PF(10, 12) VC_PF(12, 12) VC_PF(12, 16) VC_PF(16, 16) VC_PF(16, 20) VC_PF(20, 20)
+    VC_PF(20, 24) VC_PF(24, 24) VC_PF(24, 32) VC_PF(32, 32)
+#endif
+#undef VC_PF
+    return fail(c, VC_ERR_ARG, "persistent pipeline: width classes %u..%u not built", lo, hi);
+}
+
 uint32_t pick_cpl(uint32_t max_len) {
     const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
     for (uint32_t o : opts) if (64 * o >= max_len) return o;
@@ -532,6 +598,73 @@ struct Plan {
         aa.make_rows = !(c->dbg_stop_kind == 1 && c->dbg_stop_index == j); aa.kept = c->kept;
         aa.tie_n = wk.d_tie_n; aa.redo_n = wk.d_redo_n;
         { Timer t(c, KC_ADDALN, wk.stream); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, wk.stream, aa); }
+        return VC_OK;
+    }
+
+    // The whole build loop of the chunk (window.cpp:239-298, every layer of every window) as ONE set of resident kernels working
+    // off device-side queues (vc_pipe.h) instead of build_layer() once per layer.
+    bool pipe_ok() const {
+        uint32_t ca_ = 0, cb_ = 0;
+        return c->pipe && c->kept && c->packed && c->band && c->wcols == 0 && c->dbg_stop_kind == 0 && c->trace_wave && pipe_classes(c, &ca_, &cb_);
+    }
+    int build_pipe(Work& wk) {
+        const uint32_t ns = wk.ns, cap = wk.pipe_cap;
+        uint32_t shift = 0;
+        while ((1u << shift) < cap) ++shift;
+        HIPCHK(c, hipMemsetAsync(wk.d_pipe_ctl, 0, (size_t)VC_PC_N * VC_PIPE_CTL_STRIDE * 4, wk.stream));
+        HIPCHK(c, hipMemsetAsync(wk.d_pipe_slots, 0, (size_t)2 * cap * 8, wk.stream));
+        VcPipe p{};
+        auto ctl = [&](int i) { return wk.d_pipe_ctl + (size_t)i * VC_PIPE_CTL_STRIDE; };
+        p.fq = VcQueue{wk.d_pipe_slots, ctl(VC_PC_FQ_RES), ctl(VC_PC_FQ_HEAD), cap - 1, shift};
+        p.tq = VcQueue{wk.d_pipe_slots + cap, ctl(VC_PC_TQ_RES), ctl(VC_PC_TQ_HEAD), cap - 1, shift};
+        p.n_active = ctl(VC_PC_ACTIVE); p.done = ctl(VC_PC_DONE); p.finished = ctl(VC_PC_FINISHED); p.abort_code = c->d_pipe_abort;
+        p.cur_layer = wk.d_cur_layer;
+        p.prof = c->d_pipe_prof;
+        p.pub_time = getenv("VC_PIPE_PUBTIME") ? reinterpret_cast<unsigned long long*>(wk.d_scratch16 + (size_t)c->CW * (4 * PC + NC)) - c->CW : nullptr;   // development: tail of the note blocks
+        p.spin_limit = c->pipe_patience_s * 100000000u;       // ticks of the 100 MHz clock: this long without an item is a protocol error
+        hipLaunchKernelGGL(k_pipe_seed, dim3((ns + 255) / 256), dim3(256), 0, wk.stream, c->b, p, wk.w0, ns);
+        HIPCHK(c, hipEventRecord(wk.ev_seed, wk.stream));
+        HIPCHK(c, hipStreamWaitEvent(wk.st_t, wk.ev_seed, 0));
+
+        // Resident workgroups.  Both kernels take 96 registers -- five waves per SIMD in all -- so the forward kernel must leave
+        // the backtrack waves their share: a forward grid that fills the device alone would wait for backtracks that can never start.
+        const uint32_t GF = std::max(1u, std::min(ns, c->pipe_f ? c->pipe_f : c->n_cu * 15u));
+        const uint32_t GT = std::max(1u, std::min((ns + VC_TG - 1) / VC_TG, c->pipe_t ? c->pipe_t : c->n_cu * 5u));
+
+        VcPipeTraceArgs pt{};
+        pt.ta = trace_args(wk);
+        pt.ta.group = 1; pt.ta.k0 = 0; pt.ta.hstride = (uint64_t)NC * rowd;
+        pt.ta.pairs = wk.d_pairs; pt.ta.npairs = wk.d_npairs; pt.ta.pair_group = 1; pt.ta.pair_k0 = 0; pt.ta.kept = c->kept;
+        pt.ta.shared_table = 0; pt.ta.tab_rows = std::min(NC, kTraceTabRows);
+        { uint32_t cb_ = 0; (void)pipe_classes(c, &pt.ta.cpl_lo, &cb_); }
+        pt.p = p;
+        pt.g = wk.gr[wk.cur]; pt.STK = c->STK;
+        pt.tie_rows = wk.d_tie_rows; pt.tie_cnt = wk.d_tie_cnt; pt.tie_over = wk.d_pairs; pt.tie_over_stride = PC; pt.job_end = wk.d_job_end;
+        pt.submask = wk.d_submask; pt.workspace = wk.d_pipe_ws; pt.ws_bytes = (topo_lds + 15u) & ~15u; pt.force_dfs = c->force_dfs ? 1 : 0;
+        if ((size_t)GT * pt.ws_bytes > wk.pipe_ws_bytes) return fail(c, VC_ERR_ARG, "persistent pipeline: resolver workspace too small");
+        { Timer t(c, KC_TRACE, wk.st_t);
+          const uint32_t t_lds = std::max(vc_tracew_lds_bytes(pt.ta.tab_rows, false), 4 * ((NC + 31) / 32 + 1) + 2 * 256 + 16);
+          hipLaunchKernelGGL(k_pipe_trace, dim3(GT), dim3(VC_TG * VC_TL), t_lds, wk.st_t, pt); }
+        HIPCHK(c, hipEventRecord(wk.ev_t, wk.st_t));
+
+        VcPipeFwdArgs pf{};
+        pf.fa = fwd_args(wk);
+        pf.fa.group = 1; pf.fa.k0 = 0; pf.fa.mode = 0; pf.fa.hstride = (uint64_t)NC * rowd; pf.fa.do_init = 1;
+        pf.fa.tie_over = wk.d_pairs; pf.fa.tie_over_stride = PC;
+        pf.aa.b = c->b; pf.aa.g = wk.gr[wk.cur]; pf.aa.dp = wk.dp; pf.aa.w0 = wk.w0; pf.aa.nslots = ns; pf.aa.NC = NC; pf.aa.EC = EC; pf.aa.layer = 0;
+        pf.aa.pairs = wk.d_pairs; pf.aa.npairs = wk.d_npairs; pf.aa.PC = PC; pf.aa.scratch = wk.d_scratch16; pf.aa.ring = (uint32_t)kRing;
+        pf.aa.make_rows = 1; pf.aa.kept = c->kept; pf.aa.tie_n = wk.d_tie_n; pf.aa.redo_n = wk.d_redo_n;
+        pf.p = p; pf.submask = wk.d_submask; pf.force_fail_site = 0;
+        bool any_partial = false;
+        for (uint8_t x : c->h_layer_partial) any_partial = any_partial || x;
+        uint32_t lds = std::max((uint32_t)(kKept ? kKept : 1) * (c->cpl / 2) * 64u * 4u, add_lds);
+        if (any_partial) lds = std::max(lds, vc_rows_sub_lds_bytes(NC, c->kept));
+        lds = (lds + 255u) & ~255u;
+        if (lds > kLdsCap) return fail(c, VC_ERR_ARG, "persistent pipeline: %u bytes of LDS per forward wave", lds);
+        int rc;
+        { Timer t(c, KC_PIPE, wk.stream);
+          if ((rc = launch_pipe_fwd(c, wk.stream, pf, std::min(GF, c->CW), lds))) return rc; }
+        HIPCHK(c, hipStreamWaitEvent(wk.stream, wk.ev_t, 0));
         return VC_OK;
     }
 
@@ -660,7 +793,8 @@ struct Plan {
     int run_chunk(Work& wk, uint32_t w0, uint32_t ns) {
         int rc;
         begin(wk, w0, ns);
-        for (uint32_t j = 1; j <= wk.layers; ++j) if ((rc = build_layer(wk, j))) return rc;
+        if (wk.layers && pipe_ok()) { if ((rc = build_pipe(wk))) return rc; }
+        else for (uint32_t j = 1; j <= wk.layers; ++j) if ((rc = build_layer(wk, j))) return rc;
         if (!wk.layers) { wk.active = false; return VC_OK; }
         if (c->prm.mode == 1) return linear_tail(wk);
         for (uint32_t r = 0; r < c->prm.num_prune; ++r) {
@@ -716,6 +850,11 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
+    if (const char* d = getenv("VC_PIPE")) c->pipe = std::atoi(d) != 0;
+    if (const char* d = getenv("VC_PIPE_F")) c->pipe_f = (uint32_t)std::atoi(d);
+    if (const char* d = getenv("VC_PIPE_T")) c->pipe_t = (uint32_t)std::atoi(d);
+    if (const char* d = getenv("VC_PIPE_PATIENCE")) c->pipe_patience_s = std::min(40u, std::max(1u, (uint32_t)std::atoi(d)));
+    c->n_cu = (uint32_t)prop.multiProcessorCount;
     if (const char* d = getenv("VC_PRUNE_HBM")) c->prune_hbm = std::atoi(d);
     if (const char* d = getenv("VC_TOPO_HBM")) c->topo_hbm = std::atoi(d) != 0;
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipSetDevice failed"); }
@@ -735,13 +874,22 @@ int vc_create(vc_ctx** out, const vc_params* p) {
         }
         c->works[s].stream = c->streams[s];
         if (hipHostMalloc((void**)&c->works[s].h_maxn, 64) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipHostMalloc failed"); }
+        // the backtrack and resolver kernels of the persistent pipeline must run BESIDE the forward kernel of their chunk: streams of
+        // their own, at other priorities than the chunk stream (never the same hardware queue, see above)
+        Work& wk = c->works[s];
+        const int pt = n_prio > 1 ? prio_least - (int)((s + 1) % (uint32_t)n_prio) : 0;
+        if (hipStreamCreateWithPriority(&wk.st_t, hipStreamNonBlocking, pt) != hipSuccess ||
+            hipEventCreateWithFlags(&wk.ev_seed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&wk.ev_t, hipEventDisableTiming) != hipSuccess) {
+            delete c; return fail(nullptr, VC_ERR_HIP, "stream / event creation failed");
+        }
     }
     c->stream = c->streams[0];
     // lookup tables from this host's libm, like the reference computes them (graph.cpp:169, window.cpp:235)
     uint32_t lw[256]; double ld[256];
     vc_weight_lut(lw);
     for (int ch = 0; ch < 256; ++ch) ld[ch] = 1 - pow(10, (33 - (int)(signed char)ch) / 10.0);
-    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, 8 * VC_STAT_SLOTS)) {
+    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, 8 * VC_STAT_SLOTS) ||
+        dalloc(c, c->allocs, &c->d_pipe_abort, 64) || dalloc(c, c->allocs, &c->d_pipe_prof, VC_PP_TOTAL)) {
         g_create_error = c->err; vc_destroy(c); return VC_ERR_HIP;
     }
     (void)hipMemcpy(c->d_lut_w, lw, sizeof(lw), hipMemcpyHostToDevice);
@@ -764,6 +912,8 @@ void vc_destroy(vc_ctx* c) {
     for (int i = 0; i < 2; ++i) { if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); }
     for (uint32_t s = 0; s < kMaxStreams; ++s) {
         if (c->works[s].h_maxn) (void)hipHostFree(c->works[s].h_maxn);
+        if (c->works[s].st_t) (void)hipStreamDestroy(c->works[s].st_t);
+        for (hipEvent_t e : {c->works[s].ev_seed, c->works[s].ev_t}) if (e) (void)hipEventDestroy(e);
         if (c->streams[s]) (void)hipStreamDestroy(c->streams[s]);
     }
     delete c;
@@ -774,6 +924,13 @@ void* vc_stream(vc_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int vc_set_profile(vc_ctx* c, int profile) {
     if (!c || profile < 0 || profile > 2) return VC_ERR_ARG;
     c->prm.profile = profile;
+    return VC_OK;
+}
+
+int vc_set_pipeline(vc_ctx* c, int on, uint32_t forward_waves, uint32_t backtrack_waves) {
+    if (!c) return VC_ERR_ARG;
+    join_workers(c);
+    c->pipe = on != 0; c->pipe_f = forward_waves; c->pipe_t = backtrack_waves;
     return VC_OK;
 }
 
@@ -1011,6 +1168,8 @@ int vc_run(vc_ctx* c) {
     if (c->prm.mode == 1)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.cons_lds, kLdsCap)));
     HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64 * VC_STAT_SLOTS, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_pipe_abort, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_pipe_prof, 0, VC_PP_TOTAL * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
     if (!c->h_pre_status.empty()) HIPCHK(c, hipMemcpyAsync(b.status, c->h_pre_status.data(), b.n_windows, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
@@ -1078,9 +1237,15 @@ int vc_sync(vc_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     join_workers(c);
     for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s]));
+    for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->works[s].st_t));
     if (c->prm.profile) flush_events(c);
     if (c->run_rc.load() != VC_OK) { c->ran = false; return c->run_rc.load(); }
     HIPCHK(c, hipGetLastError());
+    if (c->pipe && c->d_pipe_abort) {
+        uint32_t ab = 0;
+        HIPCHK(c, hipMemcpy(&ab, c->d_pipe_abort, 4, hipMemcpyDeviceToHost));
+        if (ab) { c->ran = false; c->run_rc = VC_ERR_HIP; return fail(c, VC_ERR_HIP, "persistent build pipeline gave up waiting (site %u): the run has no result", ab); }
+    }
     return VC_OK;
 }
 
@@ -1288,6 +1453,45 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
     return VC_OK;
 }
 #endif
+
+// development: the persistent pipeline's counters and the per-window words its waves hand to each other, for the first `n` windows
+// of chunk stream 0: out[0..VC_PC_N) counters, then per window {layer, job_end, job_type, npairs}
+int vc_debug_pipe_state(vc_ctx* c, uint32_t* out, uint32_t n) {
+    if (!c || !out || !c->have_batch) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    sync_ctx(c);
+    const Work& wk = c->works[0];
+    std::vector<uint32_t> ctl((size_t)VC_PC_N * VC_PIPE_CTL_STRIDE);
+    HIPCHK(c, hipMemcpy(ctl.data(), wk.d_pipe_ctl, ctl.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 10; ++i) out[i] = i < VC_PC_N ? ctl[(size_t)i * VC_PIPE_CTL_STRIDE] : 0u;
+    HIPCHK(c, hipMemcpy(&out[9], c->d_pipe_abort, 4, hipMemcpyDeviceToHost));
+    n = std::min(n, c->cw_run);
+    std::vector<uint32_t> a(n), b(n), d(n); std::vector<uint8_t> t(n);
+    HIPCHK(c, hipMemcpy(a.data(), wk.d_cur_layer, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(b.data(), wk.d_job_end, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(t.data(), wk.d_job_type, n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(d.data(), wk.d_npairs, n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) {
+        out[10 + 4 * i] = a[i]; out[10 + 4 * i + 1] = b[i]; out[10 + 4 * i + 2] = t[i]; out[10 + 4 * i + 3] = d[i];
+        if (d[i] && d[i] <= c->PC) {                       // pairs with a sequence position, in place of job_type
+            std::vector<uint32_t> pr(d[i]);
+            HIPCHK(c, hipMemcpy(pr.data(), wk.d_pairs + (size_t)i * c->PC, (size_t)d[i] * 4, hipMemcpyDeviceToHost));
+            uint32_t nv = 0;
+            for (uint32_t x : pr) nv += (x & 0xFFFF) != 0;
+            out[10 + 4 * i + 2] = nv;
+        }
+    }
+    return VC_OK;
+}
+
+// development: phase clocks of the persistent pipeline's waves over the last run (VC_PP_* order, ticks of 100 MHz / counts)
+int vc_debug_pipe_prof(vc_ctx* c, unsigned long long* out) {
+    if (!c || !out) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    sync_ctx(c);
+    HIPCHK(c, hipMemcpy(out, c->d_pipe_prof, VC_PP_TOTAL * 8, hipMemcpyDeviceToHost));
+    return VC_OK;
+}
 
 int vc_get_stats(vc_ctx* c, vc_stats* s) {
     if (!c || !s) return VC_ERR_ARG;

@@ -756,11 +756,13 @@ __device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph&
 // with ballots; repeated until nothing changes (groups straddling a block boundary).
 // LDS carve: member bits 8*nW | rowidx 2*NC | node-id bitmap 4*(NC/32+1)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                                 uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask, uint32_t kept) {
-    VC_LATENCY_KERNEL_PRIO();
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t slot = blockIdx.x;
+__host__ __device__ inline uint32_t vc_rows_sub_lds_bytes(uint32_t NC, uint32_t kept) {
+    const uint32_t a = 8 * ((NC + 63) / 64) + 2 * NC + ((NC + 15) & ~15u) + 4 * (NC / 32 + 1) + 64, b = kept ? vc_kept_lds_bytes(NC) : 0u;
+    return a > b ? a : b;
+}
+__device__ __forceinline__ void vc_rows_sub_body(const VcBatchDev& b, const VcGraph& g, const VcDp& dp, uint32_t w0, uint32_t nslots,
+                                                 uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask, uint32_t kept,
+                                                 uint8_t* smem, const uint32_t slot) {
     if (slot >= nslots) return;
     const uint32_t w = w0 + slot;
     if (b.status[w] != VC_WIN_OK) return;
@@ -918,6 +920,13 @@ __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp d
         dp.flags[slot] = (bad ? 1u : 0u) | 2u | 4u;            // incremental order, masked
         if (bad) b.errinfo[w] = (23u << 16);
     }
+}
+
+__global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+                                                 uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask, uint32_t kept) {
+    VC_LATENCY_KERNEL_PRIO();
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    vc_rows_sub_body(b, g, dp, w0, nslots, NC, EC, next_layer, ring, submask, kept, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1293,7 +1302,10 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     if (k >= ns) return VC_FWD_NONE;
     const uint64_t so = a.b.seq_off[s0 + k];
     const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k + 1] - so);
-    if (vc_cpl_for(len) != (uint32_t)CPL) return VC_FWD_NONE;             // another width class handles this sequence
+    // another width class handles this sequence.  (The persistent pipeline is built for the two widest classes of a batch and
+    // takes everything narrower in the lower of them: a lane simply owns more columns than the sequence needs, the matrix is
+    // the same -- its backtrack reads the rows in the same class, VcTraceArgs::cpl_lo.)
+    if (PIPE ? len > 64u * CPL : vc_cpl_for(len) != (uint32_t)CPL) return VC_FWD_NONE;
     const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
     // NW or SW is fixed per instantiation (the caller looked at the layer, window.cpp:336-349): the row loop
     // then carries no alignment-type branches
@@ -2035,6 +2047,7 @@ struct VcTraceArgs {
     int only_wide;              // k_trace: take only those jobs (k_tracew walked the rest)
     int shared_table;           // k_tracew: the VC_TG alignments of a wave share a window (group % VC_TG == 0)
     uint32_t tab_rows;          // k_tracew: rows the LDS table is sized for (>= every graph's height in this launch)
+    uint32_t cpl_lo;            // narrowest width class the forward pass of this launch used (0: every sequence in its own class)
 };
 
 // One alignment per THREAD: the walk is a chain of dependent lookups, so the instruction cost is shared
@@ -2207,7 +2220,7 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     const uint32_t* hm32 = a.hmat + (uint64_t)(valid ? job : 0) * a.hstride;
     const uint16_t* hm = (const uint16_t*)hm32;
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
-    const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
+    const uint32_t cpl = max(vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), a.cpl_lo), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
     const bool packed = a.packed != 0;
     // banded store: global alignments of a banded launch keep VC_BAND_LANES lanes per row around the rank diagonal
     const bool band = a.band != 0 && !redo && valid && type == 1;
@@ -2257,7 +2270,13 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
             const uint32_t d0 = q.y & 0xFFFF;
             return (((q.x >> 8) & VC_RF_OVF) || d0 > 15) ? 0u : d0;
         };
-        for (uint32_t k2 = lane; 2 * k2 <= nr; k2 += VC_TG * VC_TL) tab[k2] = (uint8_t)(entry(2 * k2) | (entry(2 * k2 + 1) << 4));
+        // (two blocks of entries per pass: four record loads in flight per lane instead of two on a chain)
+        for (uint32_t k0 = lane; 2 * k0 <= nr; k0 += 2 * VC_TG * VC_TL) {
+            const uint32_t k1 = k0 + VC_TG * VC_TL;
+            const uint32_t e0 = entry(2 * k0), e1 = entry(2 * k0 + 1), e2 = entry(2 * k1), e3 = entry(2 * k1 + 1);
+            tab[k0] = (uint8_t)(e0 | (e1 << 4));
+            if (2 * k1 <= nr) tab[k1] = (uint8_t)(e2 | (e3 << 4));
+        }
     } else {
         auto entry = [&](uint32_t rr) __attribute__((always_inline)) -> uint32_t {
             if (rr == 0 || rr > nrows) return 0u;
@@ -2265,7 +2284,15 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
             const uint32_t d0 = q.y & 0xFFFF;
             return (((q.x >> 8) & VC_RF_OVF) || d0 > 15) ? 0u : d0;
         };
-        for (uint32_t k2 = gl; walking && 2 * k2 <= nrows; k2 += VC_TL) tab[k2] = (uint8_t)(entry(2 * k2) | (entry(2 * k2 + 1) << 4));
+        // (four blocks of entries per pass: eight record loads in flight per lane -- the table of a 2 200-row graph was 70 dependent
+        // round trips per alignment, a sixth of a backtrack round)
+        for (uint32_t k0 = gl; walking && 2 * k0 <= nrows; k0 += 4 * VC_TL) {
+            uint32_t e[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) { const uint32_t k2 = k0 + u * VC_TL; e[2 * u] = entry(2 * k2); e[2 * u + 1] = entry(2 * k2 + 1); }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) { const uint32_t k2 = k0 + u * VC_TL; if (2 * k2 <= nrows) tab[k2] = (uint8_t)(e[2 * u] | (e[2 * u + 1] << 4)); }
+        }
     }
     __syncthreads();
     uint32_t gi = end >> 16, gj = end & 0xFFFF, gnout = 0, nspec_ok = 0, nrounds = 0;
@@ -2472,31 +2499,28 @@ struct VcAddArgs {
     uint32_t* tie_n; uint32_t* redo_n;   // the layer's tie-list and redo-list counters: this is the layer's last kernel, it clears them for the next layer
 };
 
-__global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
-    VC_LATENCY_KERNEL_PRIO();
-    // every reader of the layer's counters (k_resolve, the redo pass) is an earlier kernel of this stream; a memset per counter
-    // per layer was 2 000 tiny launches per step, each waiting ~100 us for a slot beside k_fwd
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *a.tie_n = 0; *a.redo_n = 0; }
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// AddAlignment of sequence `layer` of window `slot` (+ the row records of the next layer when it is full-span).  `scr`: which of the
+// per-wave note blocks in VcAddArgs::scratch this wave uses (lock-step launches: the workgroup index; persistent pipeline: the
+// index of the resident wave).  smem: 2 * (PC + longest sequence) bytes, and vc_kept_lds_bytes(NC) for the row records.
+__device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem, const uint32_t slot, const uint32_t layer, const uint32_t scr) {
     uint16_t* s_curr = (uint16_t*)smem;                 // [PC] node chosen for each pair (forward order)
     uint16_t* s_anchor = s_curr + a.PC;                 // [max_len] new node t goes in front of old position anchor[t]
     // bulky per-pair notes live in HBM scratch, not LDS: this kernel shares CUs with k_fwd of the other
     // stream and must leave it the LDS (each note is written once and read a few times in pass D)
-    uint16_t* s_row = a.scratch + (uint64_t)blockIdx.x * (4 * a.PC + a.NC);   // [PC] DP row of the pair (0 = none)
+    uint16_t* s_row = a.scratch + (uint64_t)scr * (4 * a.PC + a.NC);   // [PC] DP row of the pair (0 = none)
     uint16_t* s_bs = s_row + a.PC;                      // [PC] first / last position in VcGraph::ord of the
     uint16_t* s_be = s_bs + a.PC;                       //      aligned group of the pair's node
     uint16_t* s_pn = s_be + a.PC;                       // [PC] position of the pair's node itself
     uint16_t* s_ord = s_pn + a.PC;                      // [NC] old order
-    const uint32_t slot = blockIdx.x;
     if (slot >= a.nslots) return;
     const uint32_t w = a.w0 + slot;
     if (a.b.status[w] != VC_WIN_OK) return;
     const int lane = vc_lane();
     const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
-    if (a.layer >= ns) return;
-    const uint64_t so = a.b.seq_off[s0 + a.layer];
-    const uint32_t len = (uint32_t)(a.b.seq_off[s0 + a.layer + 1] - so);
-    const bool hq = a.b.seq_has_qual[s0 + a.layer] != 0;
+    if (layer >= ns) return;
+    const uint64_t so = a.b.seq_off[s0 + layer];
+    const uint32_t len = (uint32_t)(a.b.seq_off[s0 + layer + 1] - so);
+    const bool hq = a.b.seq_has_qual[s0 + layer] != 0;
     const uint32_t P = a.npairs[slot];
     const uint32_t* pr = a.pairs + (uint64_t)slot * a.PC;
     const uint64_t nb = (uint64_t)slot * a.NC, eb = (uint64_t)slot * a.EC;
@@ -2592,6 +2616,9 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
     // unaligned prefix/suffix chains (graph.cpp:233-236), which this flow never produces
     if (nvalid != len || P == 0) err = VC_WIN_INVALID;
     if (N0 + nnew > a.NC || N0 + nnew >= 0xFFFF) err = VC_WIN_OVERFLOW;
+#ifdef VC_DBG_ADD
+    if (err) { if (lane == 0) vc_fail(a.b, w, err, 6, (nvalid & 0x3FF) | ((P & 0x3F) << 10)); return; }
+#endif
     if (err) { if (lane == 0) vc_fail(a.b, w, err, 6, nvalid != len || P == 0 ? 1 : 2); return; }
     __syncthreads();
 
@@ -2805,7 +2832,16 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
     }
     if (lane == 0) { a.g.n_nodes[slot] = N0 + nnew; a.g.n_edges[slot] = E0 + enew; }
     __syncthreads();
-    if (a.make_rows) vc_rows_full(a.b, a.g, a.dp, slot, w, a.NC, a.EC, (int)a.layer + 1, a.ring, N0 + nnew, a.kept, smem);   // the next layer's rows (full-span layers)
+    if (a.make_rows) vc_rows_full(a.b, a.g, a.dp, slot, w, a.NC, a.EC, (int)layer + 1, a.ring, N0 + nnew, a.kept, smem);   // the next layer's rows (full-span layers)
+}
+
+__global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
+    VC_LATENCY_KERNEL_PRIO();
+    // every reader of the layer's counters (k_resolve, the redo pass) is an earlier kernel of this stream; a memset per counter
+    // per layer was 2 000 tiny launches per step, each waiting ~100 us for a slot beside k_fwd
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *a.tie_n = 0; *a.redo_n = 0; }
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    vc_addaln_body(a, smem, blockIdx.x, a.layer, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

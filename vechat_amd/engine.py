@@ -23,7 +23,9 @@ MAX_EDGES = 32000
 class HipContext:
     """Owns a vc_ctx (one device, one stream)."""
 
-    def __init__(self, params=None, **kw):
+    def __init__(self, params=None, pipeline=None, **kw):
+        """pipeline: None = the library's default (lock-step, or what VC_PIPE says); True / False = the persistent build
+        pipeline on / off (vc_set_pipeline); a (forward_waves, backtrack_waves) pair also sizes its two kernels."""
         self.lib = capi.load_hip()
         self.params = params or capi.default_params(**kw)
         h = C.c_void_p()
@@ -32,6 +34,9 @@ class HipContext:
             raise VcError(f"vc_create failed ({rc}): {self.lib.vc_last_error(None).decode()}")
         self.h = h
         self._batch = None
+        if pipeline is not None:
+            fw, bw = pipeline if isinstance(pipeline, tuple) else (0, 0)
+            self._chk(self.lib.vc_set_pipeline(self.h, 1 if pipeline else 0, fw, bw), "vc_set_pipeline")
 
     def close(self):
         if getattr(self, "h", None):
