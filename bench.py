@@ -15,8 +15,10 @@ The one JSON line also carries
   value_e2e   the same windows from host memory to host memory (vc_submit -> vc_run -> vc_collect, H2D and D2H
               included), two contexts double-buffering batches of 16 384 windows -- SURVEY 8(d)'s definition of the
               metric; `value` is the resident-input rate the driver's contract asks for
-  roofline    k_fwd: 4 B/cell model of SURVEY 8(d), measured HBM traffic (profiles/r3_hbm_traffic.json, refused when it
-              was taken for other kernels than the ones built here), and the calibrated VALU issue bound
+  roofline    the bound that holds: VALU issue.  VALU wave-instructions of a step (rocprofv3 PMC counts per window, profiles/
+              r4_hbm_traffic.json, refused when taken for other kernel sources than the ones built here) / step wall time / SIMDs,
+              against the issue rate of packed-int16 max / add measured on this device in this run (lib/valu_peak.bin);
+              roofline.k_fwd: the forward DP alone; roofline.hbm: SURVEY 8(d)'s 4 B/cell model and the measured HBM bytes
   cpu_baseline  the reference itself (oracle/_ref, built in place from /root/reference) on the host cores, bounded
   configs     windows/s on BASELINE configs B and E, short runs
 """
@@ -53,12 +55,31 @@ def kernel_hash():
     Comments and whitespace do not count (a reworded comment does not invalidate a measurement)."""
     import re
     h = hashlib.sha256()
-    for f in ("vc_kernels.h", "vc_api.hip", "vc_device.h"):
+    for f in ("vc_kernels.h", "vc_api.hip", "vc_device.h", "vc_pipe.h"):
         src = open(os.path.join(ROOT, "vechat_amd", "csrc", f), "r").read()
         src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
         src = re.sub(r"//[^\n]*", " ", src)
         h.update(" ".join(src.split()).encode())
     return h.hexdigest()[:16]
+
+
+def valu_peak_now(device):
+    """The VALU issue rate the roofline is priced against, measured on this device in this run: vechat_amd/lib/valu_peak.bin
+    (built by __graft_entry__.build() from tools/valu_peak.hip) in its quick mode -- independent v_pk_max_i16 / v_pk_add_i16
+    chains at 4 and 8 waves per SIMD, ~0.2 s.  -> (wave instructions per microsecond per SIMD or None, provenance)."""
+    import subprocess
+    exe = os.path.join(ROOT, "vechat_amd", "lib", "valu_peak.bin")
+    try:
+        env = dict(os.environ)
+        vis = [x for x in env.get("HIP_VISIBLE_DEVICES", "").split(",") if x]
+        env["HIP_VISIBLE_DEVICES"] = vis[device] if device < len(vis) else str(device)      # the calibration binary uses device 0 of what it sees
+        out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=120, env=env).stdout
+        rates = [json.loads(l)["inst_per_us_per_simd"] for l in out.splitlines() if l.startswith('{"test"')]
+        if rates:
+            return max(rates), "this run (vechat_amd/lib/valu_peak.bin quick, after the timed region on the same device: best of independent v_pk_max_i16 / v_pk_add_i16 chains at 4 and 8 waves per SIMD)"
+    except Exception as e:
+        return None, f"calibration failed: {e!r}"
+    return None, "calibration printed nothing"
 
 
 def cpu_baseline(batch, params, budget_s):
@@ -311,41 +332,53 @@ def main():
         bases = int(lens_all.sum().item()) * a.steps
         s = ctx.stats()
         status = d_status.cpu().numpy()
-        achieved = BYTES_PER_CELL * cells / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
         khash = kernel_hash()
-        roof = {"bound": "hbm", "kernel": "k_fwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells / max(fwd_launches, 1),
-                "algorithmic_bytes_per_cell": BYTES_PER_CELL, "cells_per_step": cells / a.steps,
-                "avg_launch_ms": fwd_ms / max(fwd_launches, 1), "launches_per_step": fwd_launches / a.steps,
-                "timing": "HIP events around every k_fwd launch on its own stream, inside the timed region (vc_params.profile = 2)",
-                # the chunk streams overlap, so k_fwd launches run beside each other and each takes longer than it would alone:
-                # `frac` (bytes per launch / average launch duration, the contract's definition) then understates the kernel.
-                # The same bytes over the time during which ANY k_fwd launch was running:
-                "busy_ms_per_step": fwd_busy_ms / a.steps, "frac_over_busy_time": BYTES_PER_CELL * cells / (fwd_busy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fwd_busy_ms > 0 else None,
+        simds = torch.cuda.get_device_properties(local).multi_processor_count * 4
+        wall_s = dt / a.steps
+        peak_now, peak_src = valu_peak_now(local)
+        # The forward DP keeps its predecessor rows in registers / LDS and stores a byte-packed band: it moves ~0.5 B per cell, an
+        # eighth of SURVEY 8(d)'s 4 B/cell model, so the bound that holds is the instruction stream ("then the VALU
+        # issue bound is the honest limiter and must be stated").  achieved = VALU wave-instructions of ALL kernels of a step
+        # (rocprofv3 PMC SQ_INSTS_VALU per window of this workload, measured on these kernel sources) / step wall time / SIMDs;
+        # peak = issue rate of independent v_pk_max_i16 / v_pk_add_i16 chains measured on THIS device in THIS run.
+        roof = {"bound": "valu_issue", "kernel": "all kernels of a step (k_fwd alone: roofline.k_fwd)", "achieved": None, "peak": peak_now,
+                "unit": "VALU wave-instructions / us / SIMD", "frac": None, "traffic": None, "peak_source": peak_src, "simds": simds,
                 "kernel_hash": khash}
-        # measured HBM bytes of k_fwd (rocprofv3 PMC passes; profiles/r3_hbm_traffic.json says for which kernel sources)
+        hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_cell": BYTES_PER_CELL, "cells_per_step": cells / a.steps,
+               "algorithmic_gbs_over_wall": BYTES_PER_CELL * cells / a.steps / wall_s / 1e9}
+        hbm["algorithmic_model_exceeds_peak"] = hbm["algorithmic_gbs_over_wall"] > HBM_PEAK_GBS
+        hbm["algorithmic_frac"] = None if hbm["algorithmic_model_exceeds_peak"] else hbm["algorithmic_gbs_over_wall"] / HBM_PEAK_GBS
+        kf = {"avg_launch_ms": fwd_ms / max(fwd_launches, 1), "launches_per_step": fwd_launches / a.steps, "busy_ms_per_step": fwd_busy_ms / a.steps,
+              "dp_rows_per_step": rows / a.steps,
+              "timing": "HIP events around every k_fwd launch on its own stream, inside the timed region (vc_params.profile = 2); the chunk streams "
+                        "overlap, so launches run beside each other: busy_ms = time during which at least one k_fwd launch was running"}
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r4_hbm_traffic.json")))
             if tj.get("kernel_hash") != khash:
-                roof["traffic_note"] = f"profiles/r3_hbm_traffic.json was measured for kernels {tj.get('kernel_hash')}, these are {khash}: not used"
+                roof["counts_note"] = f"profiles/r4_hbm_traffic.json was measured for kernels {tj.get('kernel_hash')}, these are {khash}: not used"
             else:
-                roof["traffic"] = tj["bytes_per_cell"] * cells / max(fwd_launches, 1)
-                roof["traffic_source"] = ("bytes per cell from a separate rocprofv3 PMC pass over the same kernel sources (profiles/r3_hbm_traffic.json, "
-                                          "FETCH_SIZE / WRITE_SIZE, one counter per pass) x this run's cells per launch -- not counters of this run")
-                roof["hbm_frac_measured"] = tj["bytes_per_cell"] * cells / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                roof["hbm_frac_measured_over_busy_time"] = tj["bytes_per_cell"] * cells / (fwd_busy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                # the kernel moves less than the 4 B/cell model, so the VALU issue bound is stated beside it, against
-                # the issue rate MEASURED on this chip for the instructions k_fwd is made of (tools/valu_peak.hip)
-                vp = json.load(open(os.path.join(ROOT, "profiles", "r3_valu_peak.json")))
-                simds = torch.cuda.get_device_properties(local).multi_processor_count * 4
+                roof["counts_source"] = ("rocprofv3 --pmc passes over the same kernel sources (profiles/r4_hbm_traffic.json from profiles/r4*_pmc_counters.txt: "
+                                         "SQ_INSTS_VALU, FETCH_SIZE, WRITE_SIZE, one counter group per pass) scaled by this run's windows / DP rows / cells")
+                wps = a.windows * world                                             # windows per step
+                job_valu = tj["valu_insts_per_window_all_kernels"] * wps
+                roof["valu_wave_insts_per_step"] = job_valu
+                if peak_now:
+                    roof["achieved"] = job_valu / (wall_s * 1e6 * simds)
+                    roof["frac"] = roof["achieved"] / peak_now
                 ipr = tj["instructions_per_dp_row"]["VALU"]
-                roof["valu_issue"] = {"valu_insts_per_dp_row": ipr, "dp_rows_per_step": rows / a.steps, "simds": simds,
-                                      "peak_wave_insts_per_us_per_simd": vp["peak_wave_insts_per_us_per_simd"],
-                                      "frac_of_valu_issue_peak": rows * ipr / (fwd_ms * 1e3 * simds * vp["peak_wave_insts_per_us_per_simd"]),
-                                      "frac_of_valu_issue_peak_over_busy_time": rows * ipr / (fwd_busy_ms * 1e3 * simds * vp["peak_wave_insts_per_us_per_simd"])}
+                kf.update({"valu_insts_per_dp_row": ipr, "valu_wave_insts_per_step": ipr * rows / a.steps})
+                if peak_now:
+                    kf["frac_of_valu_issue_peak_over_wall"] = ipr * rows / a.steps / (wall_s * 1e6 * simds * peak_now)
+                    if fwd_busy_ms > 0:
+                        kf["frac_of_valu_issue_peak_over_busy_time"] = ipr * rows / (fwd_busy_ms * 1e3 * simds * peak_now)
+                roof["traffic"] = tj["bytes_per_cell"] * cells / max(fwd_launches, 1)       # measured HBM bytes per k_fwd launch
+                hbm.update({"measured_bytes_per_cell": tj["bytes_per_cell"], "measured_gbs_over_wall": tj["bytes_per_cell"] * cells / a.steps / wall_s / 1e9,
+                            "measured_frac": tj["bytes_per_cell"] * cells / a.steps / wall_s / 1e9 / HBM_PEAK_GBS,
+                            "k_tracew_bytes_fetched_per_move": tj.get("k_tracew_bytes_fetched_per_move")})
         except Exception as e:
-            roof["traffic_note"] = repr(e)
+            roof["counts_note"] = repr(e)
+        roof["k_fwd"] = kf
+        roof["hbm"] = hbm
         line = {
             "metric": "POA windows/sec (500 bp x 64-read)", "value": total_windows / dt, "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

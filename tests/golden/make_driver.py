@@ -20,7 +20,7 @@ JSON travels; the reference's source text never leaves /root/reference.
 import json
 import os
 import re
-import runpy
+import runpy        # NOTE: this executes the (untrusted) reference script; run it only in the sandboxed build container, never on a box with data
 import shutil
 import subprocess
 import sys

@@ -167,6 +167,30 @@ def test_split_reads_gzip_input(tmp_path, monkeypatch, tool_stand_ins):
     assert open(tmp_path / "reads.corrected.fa").read() == sc["output"]
 
 
+def test_pass_through_values_must_be_numbers_and_keep_going_reaches_the_polisher(tmp_path, monkeypatch, tool_stand_ins):
+    """the pass-through options are formatted into `bash -c` command lines, so only plain numbers get that far; and a
+    single uncomputable window must not have to end a two-round run: --keep-going (or VC_KEEP_GOING=1) is handed to our polisher."""
+    reads = tmp_path / "reads.fastq"
+    simulate(str(reads), n_reads=4)
+    for bad in (["-t", "1; touch pwned"], ["-d", "0.2$(id)"], ["--min-ovlplen-cns", "1e3 x"], ["--platform", "pb; id"]):
+        with pytest.raises(SystemExit):
+            driver.main([str(reads), "--workdir", str(tmp_path / "w")] + bad)
+    assert not (tmp_path / "pwned").exists()
+    # our own polisher command (stubbed by a recorder in front of it): the flag is appended in both rounds
+    seen = []
+    monkeypatch.setattr(driver, "_sh", lambda cmd, cwd=None: (seen.append(cmd), (_ for _ in ()).throw(RuntimeError("stop")))[0]
+                        if "vechat_amd.polish" in cmd else None)
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(RuntimeError, match="stop"):
+        driver.main([str(reads), "--workdir", str(tmp_path / "w2"), "--keep-going", "-d", "0.25"])
+    assert seen and seen[0].split(" -m vechat_amd.polish ")[1].startswith("-f -p -d 0.25 -s 0.2 -t 1 --keep-going ")
+    monkeypatch.setenv("VC_KEEP_GOING", "1")
+    seen.clear()
+    with pytest.raises(RuntimeError, match="stop"):
+        driver.main([str(reads), "--workdir", str(tmp_path / "w3"), "--linear"])
+    assert "--keep-going" in seen[0]
+
+
 def test_helpers(tmp_path):
     p = tmp_path / "x.fa"
     p.write_text(">a\nAC\n>b\nGT\n>c\nAA\n")

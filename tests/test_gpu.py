@@ -214,6 +214,23 @@ def test_persistent_build_pipeline_agrees_with_the_lock_step_plan(built):
             assert out[1][0] == ref
 
 
+def test_threaded_and_single_thread_host_schedulers_agree(built, monkeypatch):
+    """the stage-digest tests run the single-thread lock-step host scheduler (vc_debug_stop_after), production runs one
+    host thread per chunk stream and relies on k_addaln clearing the layer's tie / redo counters; same batch through both."""
+    batch = capi.synth_batch(capi.synth_cfg(29, 400, 24, frac_partial=0.2, n_haplotypes=2, snp_rate=0.02), 0, 96)
+    out = []
+    for threads in ("1", "0"):
+        monkeypatch.setenv("VC_HOST_THREADS", threads)
+        c = HipContext(device=0, chunk_windows=16, n_streams=3)
+        c.submit(batch); c.run(); c.sync()
+        cons, status = c.collect()
+        st = c.stats()
+        out.append((cons, [int(x) for x in status], st["cells"], st["band_redo"], st["trace_steps"]))
+        c.close()
+    assert out[0] == out[1]
+    assert st["band_redo"] > 0          # the redo list (and its counter reset) really was in use
+
+
 def test_prune_parameters_and_rounds(built):
     batch = capi.synth_batch(capi.synth_cfg(41, 180, 14, n_haplotypes=2, snp_rate=0.03), 0, 6)
     for kw in (dict(num_prune=1), dict(num_prune=2), dict(num_prune=4, min_confidence=0.22, min_support=0.19),

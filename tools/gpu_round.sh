@@ -19,5 +19,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_
   fc=$(find /tmp/pmc/p$i -name "*counter_collection.csv" | head -1)
   echo "== pass $i: $grp" >> $O/pmc_counters.txt; python $R/tools/pmc_summary.py $fc | cut -c1-700 >> $O/pmc_counters.txt
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/valu_peak.hip -o /tmp/valu_peak.bin && /tmp/valu_peak.bin > $O/valu_peak.txt
+$R/vechat_amd/lib/valu_peak.bin > $O/valu_peak.txt
 python $R/tools/make_traffic_json.py /tmp/pmc $O/pmc_stats.json $O/valu_peak.txt $O

@@ -17,12 +17,13 @@ ctx = HipContext(device=0, profile=1, chunk_windows=chunk, n_streams=streams, nu
                  scratch_bytes=int(float(os.environ.get('VC_SCRATCH_GB', '0')) * (1 << 30)))
 t0 = time.time(); ctx.submit(b); ts = time.time() - t0
 print(f"vc_submit (validation + H2D of {2*b.bases.size/1e6:.0f} MB): {ts:.3f}s = {n/ts:.0f} win/s", flush=True)
-acc = {"cells": 0, "dp_rows": 0, "trace_steps": 0, "command": "python tools/gpu_scale.py " + " ".join(sys.argv[1:])}
+acc = {"cells": 0, "dp_rows": 0, "trace_steps": 0, "windows": 0, "command": "python tools/gpu_scale.py " + " ".join(sys.argv[1:])}
 for rep in range(2):
     t0 = time.time(); ctx.run(); ctx.sync(); t1 = time.time()
     s = ctx.stats()
     for k in ("cells", "dp_rows", "trace_steps"):
         acc[k] += s[k]
+    acc["windows"] += n
     km = {k: round(v['ms'], 1) for k, v in s['kernels'].items()}
     print(f"rep {rep}: {n/(t1-t0):.1f} win/s ({t1-t0:.3f}s) cells={s['cells']:.3e} GCUPS={s['cells']/(t1-t0)/1e9:.1f} rows={s['dp_rows']:.3e} far={s['far_row_reads']} redo={s['band_redo']} trace steps/spec/rounds={s['trace_steps']}/{s['trace_spec']}/{s['trace_rounds']} NC={s['max_nodes']} EC={s['max_edges']} CW={s['chunk_windows']}x{s['n_streams']} dev={s.get('device_bytes', 0)/2**30:.1f}GiB ms={km}", flush=True)
 if os.environ.get("VC_PIPE") == "1":

@@ -1,4 +1,4 @@
-"""Build profiles/r3_hbm_traffic.json and profiles/r3_valu_peak.json from the PMC passes of tools/pmc_run.sh and tools/valu_peak.bin.
+"""Build profiles/r4_hbm_traffic.json and profiles/r4_valu_peak_final.json from the PMC passes of tools/pmc_run.sh and tools/valu_peak.bin.
 
   python tools/make_traffic_json.py <dir with pmc1..4 counter csv> <gpu_scale stats json> <valu_peak output> <out dir>
 
@@ -35,6 +35,12 @@ for k, d in sorted(agg.items()):
     if "WRITE_SIZE" in d:
         e["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024
     out["kernels"][k] = e
+# whole job: VALU wave-instructions of every kernel of the command, per window (bench.py prices a step against the issue peak)
+tot_valu = sum(d.get("SQ_INSTS_VALU", 0.0) for d in agg.values())
+if st.get("windows") and tot_valu:
+    out["windows"] = st["windows"]
+    out["valu_insts_per_window_all_kernels"] = tot_valu / st["windows"]
+    out["valu_insts_per_window_by_kernel"] = {k: d.get("SQ_INSTS_VALU", 0.0) / st["windows"] for k, d in sorted(agg.items()) if d.get("SQ_INSTS_VALU")}
 f = out["kernels"].get("k_fwd", {})
 if f:
     out["bytes_per_cell_written"] = f.get("hbm_write_bytes", 0) / cells
@@ -47,7 +53,7 @@ t = out["kernels"].get("k_tracew", {})
 if t and moves:
     out["k_tracew_bytes_fetched_per_move"] = t.get("hbm_read_bytes", 0) / moves
 os.makedirs(out_dir, exist_ok=True)
-json.dump(out, open(os.path.join(out_dir, "r3_hbm_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(out_dir, "r4_hbm_traffic.json"), "w"), indent=1)
 print("bytes/cell", out.get("bytes_per_cell"), "insts/row", out.get("instructions_per_dp_row"), "tracew B/move", out.get("k_tracew_bytes_fetched_per_move"))
 
 tests = [json.loads(l) for l in open(valu_out) if l.startswith("{")]
@@ -57,5 +63,5 @@ best = max(ind, key=lambda x: x["inst_per_us_per_simd"])
 json.dump({"source": "tools/valu_peak.bin on the bench box", "device": dev, "tests": tests[1:],
            "peak_wave_insts_per_us_per_simd": best["inst_per_us_per_simd"],
            "note": f"best issue rate of independent v_pk_max_i16 / v_pk_add_i16 chains ({best['waves_per_simd']} waves per SIMD)"},
-          open(os.path.join(out_dir, "r3_valu_peak.json"), "w"), indent=1)
+          open(os.path.join(out_dir, "r4_valu_peak_final.json"), "w"), indent=1)
 print("valu peak", best["inst_per_us_per_simd"], "wave insts / us / SIMD")

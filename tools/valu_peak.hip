@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/valu_peak.hip -o tools/valu_peak.bin && tools/valu_peak.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <string>
 #include <vector>
 #include <algorithm>
 
@@ -133,10 +134,14 @@ int run(const char* name, int waves_per_simd, int n_cu, int per_iter) {
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
     hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
     const int n_cu = p.multiProcessorCount;
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_rate_khz\": %d}\n", p.gcnArchName, n_cu, p.clockRate);
+    if (argc > 1 && std::string(argv[1]) == "quick") {      // bench.py: only the rate the forward DP is priced against (~0.2 s)
+        for (int w : {4, 8}) if (run<0>("pk_i16_independent", w, n_cu, 16)) return 1;
+        return 0;
+    }
     for (int w : {1, 2, 4, 8}) if (run<0>("pk_i16_independent", w, n_cu, 16)) return 1;
     for (int w : {1, 4}) if (run<4>("i32_independent", w, n_cu, 16)) return 1;
     for (int w : {1, 4}) if (run<3>("v_perm_independent", w, n_cu, 16)) return 1;

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -923,6 +924,7 @@ void* vc_stream(vc_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int vc_set_profile(vc_ctx* c, int profile) {
     if (!c || profile < 0 || profile > 2) return VC_ERR_ARG;
+    join_workers(c);                     // the chunk threads of a running batch read prm.profile and write the event records
     c->prm.profile = profile;
     return VC_OK;
 }
@@ -1182,8 +1184,14 @@ int vc_run(vc_ctx* c) {
         c->next_chunk = 0; c->run_rc = VC_OK;
         for (uint32_t s = 0; s < S; ++s) c->works[s].active = false;
         const uint32_t n_chunks = (b.n_windows + CW - 1) / CW;
-        for (uint32_t s = 0; s < S && s < n_chunks; ++s) c->workers[s] = std::thread(chunk_worker, c, s, pl);
         c->workers_running = true;
+        try {
+            for (uint32_t s = 0; s < S && s < n_chunks; ++s) c->workers[s] = std::thread(chunk_worker, c, s, pl);
+        } catch (const std::exception& e) {                  // (no exception may cross the C boundary) the threads that did start finish the batch
+            bool any = false;
+            for (uint32_t s = 0; s < S; ++s) any = any || c->workers[s].joinable();
+            if (!any) { c->workers_running = false; return fail(c, VC_ERR_STATE, "cannot start a chunk thread: %s", e.what()); }
+        }
         c->ran = true;                      // vc_sync joins the threads and reports what they met
         return VC_OK;
     }
@@ -1251,7 +1259,8 @@ int vc_sync(vc_ctx* c) {
 
 static int fetch_lengths(vc_ctx* c) {
     join_workers(c);
-    if (!c->ran || c->run_rc.load() != VC_OK) return fail(c, VC_ERR_STATE, "no finished run");
+    if (c->run_rc.load() != VC_OK) return c->run_rc.load();                  // the run failed: its own error text stands (vc_last_error)
+    if (!c->ran) return fail(c, VC_ERR_STATE, "no finished run");
     for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s]));
     const uint32_t nw = c->b.n_windows;
     c->h_cons_len.resize(nw); c->h_status.resize(nw);
@@ -1323,6 +1332,7 @@ int vc_collect(vc_ctx* c, vc_result* r) {
 int vc_debug_errinfo(vc_ctx* c, uint32_t* out) {
     if (!c || !out || !c->have_batch) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    sync_ctx(c);
     HIPCHK(c, hipMemcpy(out, c->b.errinfo, (size_t)c->b.n_windows * 4, hipMemcpyDeviceToHost));
     return VC_OK;
 }
@@ -1496,6 +1506,7 @@ int vc_debug_pipe_prof(vc_ctx* c, unsigned long long* out) {
 int vc_get_stats(vc_ctx* c, vc_stats* s) {
     if (!c || !s) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    join_workers(c);                     // launch counters and event records belong to the chunk threads until they are done
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, raw[8 * VC_STAT_SLOTS];
     HIPCHK(c, hipMemcpy(raw, c->d_stat, sizeof(raw), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8 * VC_STAT_SLOTS; ++i) st[i % 8] += raw[i];

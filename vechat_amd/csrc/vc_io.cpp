@@ -1,0 +1,555 @@
+// File formats either side of the hot path, on the host side of the C ABI: what the reference's Polisher
+// does with bioparser before a single window exists.  No device code; built into libvechat_hip.so and libvechat_host.so.
+//
+//   vc_io_read_sequences  <- src/polisher.cpp:77-138 (parser selection by extension) + vendor/spoa/vendor/bioparser
+//                            (FASTA / FASTQ records, names cut at the first whitespace) + src/sequence.cpp:19-42
+//                            (upper-casing; a quality string that is all '!' counts as none)
+//   vc_io_read_overlaps   <- src/overlap.cpp:14-27 (MHAP), :29-42 (PAF), :44-110 (SAM: unmapped flag, strand, clips, lengths,
+//                            error) -- the record constructors; a PAF `cg:Z:` tag supplies the CIGAR, without one the record
+//                            is aligned on the device first (vc_align; the reference calls edlib there, overlap.cpp:205-220)
+//   vc_io_load            <- src/polisher.cpp:207-352 (Polisher::initialize: reads that are also targets share one record,
+//                            self-overlaps and overlaps above the error threshold are dropped, window type from the mean
+//                            read length, name -> id resolution of overlap.cpp:129-177)
+//
+// Sequence ingest is pinned against the reference's own bioparser + racon::Sequence (oracle/ref_seqparse.cpp,
+// tests/test_seqio.py); the overlap constructors are restatements (src/overlap.cpp needs edlib.h, which is not in the tree),
+// cross-checked against the independent Python restatement in vechat_amd/seqio.py on every format.
+// Files are read whole (mmap, or zlib for .gz) and cut into records by memchr; plain files are parsed by several threads.
+#include "vechat_hip.h"
+
+#include <zlib.h>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ file contents
+struct Blob {
+    const char* p = nullptr; size_t n = 0;
+    std::string owned;          // .gz: inflated here
+    void* map = nullptr; size_t map_n = 0;
+    ~Blob() { if (map) munmap(map, map_n); }
+};
+
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t k = std::strlen(suf);
+    return s.size() >= k && s.compare(s.size() - k, k, suf) == 0;
+}
+
+bool load_file(const char* path, Blob& b, std::string& err) {
+    const std::string ps(path);
+    if (ends_with(ps, ".gz")) {
+        gzFile f = gzopen(path, "rb");
+        if (!f) { err = ps + ": cannot open"; return false; }
+        gzbuffer(f, 1 << 20);
+        std::string& o = b.owned;
+        std::vector<char> buf(1 << 22);
+        for (;;) {
+            const int k = gzread(f, buf.data(), (unsigned)buf.size());
+            if (k < 0) { err = ps + ": gzip read error"; gzclose(f); return false; }
+            if (k == 0) break;
+            o.append(buf.data(), (size_t)k);
+        }
+        gzclose(f);
+        b.p = o.data(); b.n = o.size();
+        return true;
+    }
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { err = ps + ": cannot open"; return false; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); err = ps + ": cannot stat"; return false; }
+    if (st.st_size == 0) { close(fd); b.p = ""; b.n = 0; return true; }
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { err = ps + ": cannot map"; return false; }
+    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    b.map = m; b.map_n = (size_t)st.st_size; b.p = (const char*)m; b.n = b.map_n;
+    return true;
+}
+
+inline const char* line_end(const char* p, const char* e) {
+    const char* q = (const char*)memchr(p, '\n', (size_t)(e - p));
+    return q ? q : e;
+}
+inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
+// [p, e) without leading / trailing whitespace (Python's bytes.strip())
+inline void strip(const char*& p, const char*& e) {
+    while (p < e && is_space(*p)) ++p;
+    while (e > p && is_space(e[-1])) --e;
+}
+inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+
+unsigned n_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (const char* e = getenv("VC_IO_THREADS")) n = (unsigned)std::max(1, atoi(e));
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<unsigned>(n, (unsigned)CPU_COUNT(&set));
+    // cgroup CPU quota (a container may see 256 cores and own 16)
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32]; long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1L, atol(q) / period));
+        fclose(f);
+    }
+    return std::max(1u, std::min(n, 32u));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ sequences
+struct vc_seqset {
+    std::string names, data, qual;                   // concatenated; qual has the data's offsets (empty stretch where none)
+    std::vector<uint64_t> name_off{0}, data_off{0};
+    std::vector<uint8_t> has_qual;
+    std::vector<uint64_t> length;                    // == data_off differences when the data is kept
+    bool names_only = false;
+    std::string err;
+    size_t size() const { return has_qual.size(); }
+    std::string name(size_t i) const { return names.substr(name_off[i], name_off[i + 1] - name_off[i]); }
+};
+
+namespace {
+
+struct SeqPart {                                     // what one thread made of its piece of the file
+    std::string names, data, qual;
+    std::vector<uint64_t> name_len, data_len;
+    std::vector<uint8_t> has_qual;
+    std::string err;
+};
+
+using KeepSet = std::unordered_map<std::string, char>;
+
+// one FASTA / FASTQ record starting at p (a '>' or '@' line); returns the position behind it, nullptr on error
+const char* parse_record(const char* p, const char* e, const std::string& path, const KeepSet* keep, bool names_only, SeqPart& o) {
+    const char* le = line_end(p, e);
+    const char kind = *p;
+    // name: the header line without its first byte, cut at the first whitespace (b"...".split()[0])
+    const char* ns = p + 1; const char* ne = le;
+    strip(ns, ne);
+    const char* nc = ns;
+    while (nc < ne && !is_space(*nc)) ++nc;
+    const bool want = !keep || keep->count(std::string(ns, (size_t)(nc - ns))) != 0;
+    const char* q = le < e ? le + 1 : e;
+    size_t dlen = 0;
+    const size_t d0 = o.data.size();
+    bool hq = false;
+    if (kind == '>') {
+        // sequence lines up to the next line that starts with '>' (or the end); every line stripped, blank lines contribute nothing
+        while (q < e && *q != '>') {
+            const char* l2 = line_end(q, e);
+            const char* a = q; const char* b = l2;
+            strip(a, b);
+            if (want && !names_only) for (const char* c = a; c < b; ++c) o.data += up(*c);
+            dlen += (size_t)(b - a);
+            q = l2 < e ? l2 + 1 : e;
+        }
+    } else {
+        // four-line FASTQ: sequence, separator, quality
+        const char* l2 = line_end(q, e);
+        const char* a = q; const char* b = l2;
+        strip(a, b);
+        dlen = (size_t)(b - a);
+        if (want && !names_only) for (const char* c = a; c < b; ++c) o.data += up(*c);
+        q = l2 < e ? l2 + 1 : e;
+        q = line_end(q, e); q = q < e ? q + 1 : e;                           // the '+' line
+        const char* l4 = line_end(q, e);
+        const char* qa = q; const char* qb = l4;
+        strip(qa, qb);
+        if ((size_t)(qb - qa) != dlen) { o.err = path + ": quality length differs from sequence length for " + std::string(ns, (size_t)(nc - ns)); return nullptr; }
+        // src/sequence.cpp:19-42: the sum of (c - '!') decides; all '!' -> no quality
+        unsigned long long sum = 0; bool below = false;
+        for (const char* c = qa; c < qb; ++c) { sum += (unsigned long long)((unsigned char)*c - 33u); below |= (unsigned char)*c < 33u; }
+        if (below) { long long s2 = 0; for (const char* c = qa; c < qb; ++c) s2 += (long long)(unsigned char)*c - 33; sum = (unsigned long long)(s2 != 0); }
+        hq = dlen > 0 && sum != 0;
+        if (want && !names_only && hq) { o.qual.resize(d0, '!'); o.qual.append(qa, (size_t)(qb - qa)); }
+        q = l4 < e ? l4 + 1 : e;
+    }
+    if (want) {
+        o.names.append(ns, (size_t)(nc - ns));
+        o.name_len.push_back((uint64_t)(nc - ns));
+        o.data_len.push_back(dlen);
+        o.has_qual.push_back(hq ? 1 : 0);
+    }
+    return q;
+}
+
+void parse_range(const char* p, const char* e, const std::string& path, const KeepSet* keep, bool names_only, SeqPart& o) {
+    while (p < e && o.err.empty()) {
+        const char* le = line_end(p, e);
+        const char* a = p; const char* b = le;
+        strip(a, b);
+        if (a == b) { p = le < e ? le + 1 : e; continue; }                  // blank line between records
+        if (*p != '>' && *p != '@') { o.err = path + ": unrecognised record"; return; }
+        p = parse_record(p, e, path, keep, names_only, o);
+        if (!p) return;
+    }
+}
+
+// a position at or behind `p` where a record certainly starts.  FASTA: a line starting with '>'.  FASTQ: '@' may open a
+// quality line too, so a start is an '@' line whose line after next starts with '+' and which is not itself preceded by a '+' line
+// ... simpler and exact for four-line files: count lines from a known record start.  Pieces are therefore cut by the main
+// thread, which walks the line structure once (memchr only).
+std::vector<size_t> cut_points(const Blob& f, unsigned parts) {
+    std::vector<size_t> cut{0};
+    if (parts <= 1 || f.n < (1u << 22)) { cut.push_back(f.n); return cut; }
+    const char* p = f.p; const char* e = f.p + f.n;
+    // first non-blank byte decides the format
+    const char* s = p;
+    while (s < e && is_space(*s)) ++s;
+    if (s == e) { cut.push_back(f.n); return cut; }
+    const size_t step = f.n / parts;
+    if (*s == '>') {
+        for (unsigned k = 1; k < parts; ++k) {
+            const char* q = p + k * step;
+            while (q < e) {                                                  // next line start with '>'
+                q = (const char*)memchr(q, '\n', (size_t)(e - q));
+                if (!q) { q = e; break; }
+                ++q;
+                if (q < e && *q == '>') break;
+            }
+            if (q < e && (size_t)(q - p) > cut.back()) cut.push_back((size_t)(q - p));
+        }
+    } else {
+        // four-line FASTQ: walk the lines, remember the record starts nearest to the targets
+        size_t line = 0; unsigned k = 1;
+        const char* q = s;
+        while (q < e && k < parts) {
+            if (line % 4 == 0 && (size_t)(q - p) >= k * step) { cut.push_back((size_t)(q - p)); ++k; continue; }
+            const char* l = (const char*)memchr(q, '\n', (size_t)(e - q));
+            if (!l) break;
+            // blank lines between records do not count (the parser skips them at record boundaries only)
+            if (!(line % 4 == 0 && l == q)) ++line;
+            q = l + 1;
+        }
+    }
+    cut.push_back(f.n);
+    return cut;
+}
+
+}  // namespace
+
+extern "C" {
+
+vc_seqset* vc_io_read_sequences(const char* path, const char* keep_names, int names_only) {
+    vc_seqset* s = new vc_seqset();
+    s->names_only = names_only != 0;
+    if (!path) { s->err = "null path"; return s; }
+    Blob f;
+    if (!load_file(path, f, s->err)) return s;
+    KeepSet keep;
+    if (keep_names) {
+        for (const char* p = keep_names; *p;) {
+            const char* e = strchr(p, '\n');
+            if (!e) e = p + strlen(p);
+            if (e > p) keep.emplace(std::string(p, (size_t)(e - p)), 1);
+            p = *e ? e + 1 : e;
+        }
+    }
+    const std::vector<size_t> cut = cut_points(f, n_threads());
+    std::vector<SeqPart> parts(cut.size() - 1);
+    std::vector<std::thread> th;
+    const std::string ps(path);
+    for (size_t k = 0; k + 1 < cut.size(); ++k)
+        th.emplace_back([&, k]() { parse_range(f.p + cut[k], f.p + cut[k + 1], ps, keep_names ? &keep : nullptr, names_only != 0, parts[k]); });
+    for (auto& t : th) t.join();
+    size_t nn = 0, nd = 0, nr = 0; bool anyq = false;
+    for (auto& p : parts) {
+        if (!p.err.empty() && s->err.empty()) s->err = p.err;
+        nn += p.names.size(); nd += p.data.size(); nr += p.has_qual.size(); anyq |= !p.qual.empty();
+    }
+    if (!s->err.empty()) return s;
+    s->names.reserve(nn); s->data.reserve(nd); if (anyq) s->qual.reserve(nd);
+    s->name_off.reserve(nr + 1); s->data_off.reserve(nr + 1); s->has_qual.reserve(nr); s->length.reserve(nr);
+    for (auto& p : parts) {
+        if (anyq) { s->qual.resize(s->data.size(), '!'); p.qual.resize(p.data.size(), '!'); s->qual += p.qual; }
+        s->names += p.names; s->data += p.data;
+        for (size_t i = 0; i < p.has_qual.size(); ++i) {
+            s->name_off.push_back(s->name_off.back() + p.name_len[i]);
+            s->data_off.push_back(s->data_off.back() + (names_only ? 0 : p.data_len[i]));
+            s->length.push_back(p.data_len[i]);
+            s->has_qual.push_back(p.has_qual[i]);
+        }
+        SeqPart().names.swap(p.names); std::string().swap(p.data); std::string().swap(p.qual);
+    }
+    return s;
+}
+
+void vc_seqset_free(vc_seqset* s) { delete s; }
+const char* vc_seqset_error(const vc_seqset* s) { return s && !s->err.empty() ? s->err.c_str() : nullptr; }
+uint64_t vc_seqset_size(const vc_seqset* s) { return s ? s->size() : 0; }
+const uint64_t* vc_seqset_name_off(const vc_seqset* s) { return s->name_off.data(); }
+const char* vc_seqset_names(const vc_seqset* s) { return s->names.data(); }
+const uint64_t* vc_seqset_data_off(const vc_seqset* s) { return s->data_off.data(); }
+const char* vc_seqset_data(const vc_seqset* s) { return s->data.data(); }
+const char* vc_seqset_qual(const vc_seqset* s) { return s->qual.empty() ? nullptr : s->qual.data(); }
+const uint8_t* vc_seqset_has_qual(const vc_seqset* s) { return s->has_qual.data(); }
+const uint64_t* vc_seqset_lengths(const vc_seqset* s) { return s->length.data(); }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ overlaps
+struct vc_ovlset {
+    // names as (offset, length) into `text`; MHAP records carry file positions instead (by_index)
+    std::string text;
+    std::vector<uint64_t> qn_off, tn_off; std::vector<uint32_t> qn_len, tn_len;
+    std::vector<uint8_t> by_index, strand, has_cigar, dropped;
+    std::vector<uint32_t> q_begin, q_end, q_length, t_begin, t_end, length, q_index, t_index;
+    std::vector<double> error;
+    std::vector<std::string> cigar;                  // per record (SAM / PAF cg:Z: / set by vc_ovlset_set_cigar)
+    std::string err;
+    size_t size() const { return strand.size(); }
+    void push_common(bool st, uint32_t qb, uint32_t qe, uint32_t ql, uint32_t tb, uint32_t te, uint32_t len, double er) {
+        strand.push_back(st); q_begin.push_back(qb); q_end.push_back(qe); q_length.push_back(ql); t_begin.push_back(tb); t_end.push_back(te);
+        length.push_back(len); error.push_back(er); dropped.push_back(0);
+    }
+};
+
+namespace {
+
+struct Fields {                                      // tab- (or whitespace-) separated fields of a line
+    std::vector<std::pair<const char*, const char*>> f;
+    void tabs(const char* p, const char* e) {
+        f.clear();
+        for (;;) {
+            const char* t = (const char*)memchr(p, '\t', (size_t)(e - p));
+            f.emplace_back(p, t ? t : e);
+            if (!t) break;
+            p = t + 1;
+        }
+    }
+    void blanks(const char* p, const char* e) {
+        f.clear();
+        while (p < e) {
+            while (p < e && is_space(*p)) ++p;
+            if (p == e) break;
+            const char* s = p;
+            while (p < e && !is_space(*p)) ++p;
+            f.emplace_back(s, p);
+        }
+    }
+};
+
+bool to_u64(const char* p, const char* e, uint64_t& v) {
+    if (p == e) return false;
+    v = 0;
+    for (; p < e; ++p) { if (*p < '0' || *p > '9') return false; v = v * 10 + (uint64_t)(*p - '0'); }
+    return true;
+}
+
+// src/overlap.cpp:44-110 on a CIGAR string
+bool sam_spans(const char* c, const char* e, uint64_t& q_begin_clip, uint64_t& q_aln, uint64_t& t_aln, uint64_t& clip) {
+    q_begin_clip = q_aln = t_aln = clip = 0;
+    bool first = true;
+    while (c < e) {
+        uint64_t n = 0; const char* d = c;
+        while (c < e && *c >= '0' && *c <= '9') { n = n * 10 + (uint64_t)(*c - '0'); ++c; }
+        if (c == d || c == e) return false;
+        switch (*c) {
+            case 'M': case '=': case 'X': q_aln += n; t_aln += n; break;
+            case 'I': q_aln += n; break;
+            case 'D': case 'N': t_aln += n; break;
+            case 'S': case 'H': clip += n; if (first) q_begin_clip = n; break;
+            case 'P': break;
+            default: return false;
+        }
+        first = false;
+        ++c;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+vc_ovlset* vc_io_read_overlaps(const char* path) {
+    vc_ovlset* o = new vc_ovlset();
+    if (!path) { o->err = "null path"; return o; }
+    const std::string ps(path);
+    enum { MHAP, PAF, SAM } fmt;
+    if (ends_with(ps, ".mhap") || ends_with(ps, ".mhap.gz")) fmt = MHAP;
+    else if (ends_with(ps, ".sam") || ends_with(ps, ".sam.gz")) fmt = SAM;
+    else if (ends_with(ps, ".paf") || ends_with(ps, ".paf.gz")) fmt = PAF;
+    else { o->err = ps + ": unsupported overlap format (valid extensions: .mhap, .mhap.gz, .paf, .paf.gz, .sam, .sam.gz)"; return o; }
+    Blob f;
+    if (!load_file(path, f, o->err)) return o;
+    o->text.assign(f.p, f.n);                        // names point into this copy (the mapping goes away with this call)
+    const char* base = o->text.data();
+    const char* p = base; const char* e = base + o->text.size();
+    Fields fl;
+    auto name = [&](std::vector<uint64_t>& off, std::vector<uint32_t>& len, const std::pair<const char*, const char*>& x) {
+        off.push_back((uint64_t)(x.first - base)); len.push_back((uint32_t)(x.second - x.first));
+    };
+    size_t lineno = 0;
+    while (p < e) {
+        const char* le = line_end(p, e);
+        ++lineno;
+        const char* a = p; const char* b = le;
+        p = le < e ? le + 1 : e;
+        const char* sa = a; const char* sb = b;
+        strip(sa, sb);
+        if (sa == sb) continue;
+        if (fmt == SAM) {
+            if (*a == '@') continue;
+            if (b > a && b[-1] == '\r') --b;
+            fl.tabs(a, b);
+            uint64_t flag = 0, pos = 0;
+            if (fl.f.size() < 6 || !to_u64(fl.f[1].first, fl.f[1].second, flag) || !to_u64(fl.f[3].first, fl.f[3].second, pos)) {
+                o->err = ps + ": malformed SAM record at line " + std::to_string(lineno); return o;
+            }
+            if (flag & 0x4) continue;                                          // unmapped
+            const char* cs = fl.f[5].first; const char* ce = fl.f[5].second;
+            if (ce - cs < 2) { o->err = "missing alignment from SAM object"; return o; }
+            uint64_t qbc, qa, ta, clip;
+            if (!sam_spans(cs, ce, qbc, qa, ta, clip)) { o->err = ps + ": malformed CIGAR at line " + std::to_string(lineno); return o; }
+            const bool st = (flag & 0x10) != 0;
+            uint64_t qb = qbc, qe = qbc + qa;
+            const uint64_t ql = clip + qa;
+            if (st) { const uint64_t nb = ql - qe, ne = ql - qb; qb = nb; qe = ne; }
+            const uint64_t tb = pos - 1, te = tb + ta, len = std::max(qa, ta);
+            name(o->qn_off, o->qn_len, fl.f[0]); name(o->tn_off, o->tn_len, fl.f[2]);
+            o->by_index.push_back(0); o->q_index.push_back(0); o->t_index.push_back(0);
+            o->push_common(st, (uint32_t)qb, (uint32_t)qe, (uint32_t)ql, (uint32_t)tb, (uint32_t)te, (uint32_t)len,
+                           len ? 1 - (double)std::min(qa, ta) / (double)len : 1.0);
+            o->has_cigar.push_back(1); o->cigar.emplace_back(cs, (size_t)(ce - cs));
+        } else if (fmt == PAF) {
+            if (b > a && b[-1] == '\r') --b;
+            fl.tabs(a, b);
+            uint64_t ql, qb, qe, tb, te;
+            if (fl.f.size() < 9 || !to_u64(fl.f[1].first, fl.f[1].second, ql) || !to_u64(fl.f[2].first, fl.f[2].second, qb) ||
+                !to_u64(fl.f[3].first, fl.f[3].second, qe) || !to_u64(fl.f[7].first, fl.f[7].second, tb) || !to_u64(fl.f[8].first, fl.f[8].second, te)) {
+                o->err = ps + ": malformed PAF record at line " + std::to_string(lineno); return o;
+            }
+            const uint64_t len = std::max(qe - qb, te - tb);
+            name(o->qn_off, o->qn_len, fl.f[0]); name(o->tn_off, o->tn_len, fl.f[5]);
+            o->by_index.push_back(0); o->q_index.push_back(0); o->t_index.push_back(0);
+            o->push_common(fl.f[4].second - fl.f[4].first == 1 && *fl.f[4].first == '-', (uint32_t)qb, (uint32_t)qe, (uint32_t)ql, (uint32_t)tb, (uint32_t)te,
+                           (uint32_t)len, len ? 1 - (double)std::min(qe - qb, te - tb) / (double)len : 1.0);
+            bool got = false;
+            for (size_t k = 12; k < fl.f.size() && !got; ++k)
+                if (fl.f[k].second - fl.f[k].first >= 5 && memcmp(fl.f[k].first, "cg:Z:", 5) == 0) { o->cigar.emplace_back(fl.f[k].first + 5, (size_t)(fl.f[k].second - fl.f[k].first - 5)); got = true; }
+            if (!got) o->cigar.emplace_back();
+            o->has_cigar.push_back(got ? 1 : 0);
+        } else {
+            fl.blanks(a, b);
+            uint64_t v[12];
+            bool ok = fl.f.size() >= 12;
+            for (int k : {0, 1, 4, 5, 6, 7, 8, 9, 10}) ok = ok && to_u64(fl.f[k].first, fl.f[k].second, v[k]);
+            if (!ok) { o->err = ps + ": malformed MHAP record at line " + std::to_string(lineno); return o; }
+            const uint64_t len = std::max(v[6] - v[5], v[10] - v[9]);
+            o->qn_off.push_back(0); o->qn_len.push_back(0); o->tn_off.push_back(0); o->tn_len.push_back(0);
+            o->by_index.push_back(1); o->q_index.push_back((uint32_t)(v[0] - 1)); o->t_index.push_back((uint32_t)(v[1] - 1));
+            o->push_common((v[4] ^ v[8]) != 0, (uint32_t)v[5], (uint32_t)v[6], (uint32_t)v[7], (uint32_t)v[9], (uint32_t)v[10], (uint32_t)len,
+                           len ? 1 - (double)std::min(v[6] - v[5], v[10] - v[9]) / (double)len : 1.0);
+            o->has_cigar.push_back(0); o->cigar.emplace_back();
+        }
+    }
+    return o;
+}
+
+void vc_ovlset_free(vc_ovlset* o) { delete o; }
+const char* vc_ovlset_error(const vc_ovlset* o) { return o && !o->err.empty() ? o->err.c_str() : nullptr; }
+uint64_t vc_ovlset_size(const vc_ovlset* o) { return o ? o->size() : 0; }
+
+int vc_ovlset_get(const vc_ovlset* o, uint64_t i, vc_overlap_rec* r) {
+    if (!o || !r || i >= o->size()) return VC_ERR_ARG;
+    r->q_name = o->text.data() + o->qn_off[i]; r->q_name_len = o->qn_len[i];
+    r->t_name = o->text.data() + o->tn_off[i]; r->t_name_len = o->tn_len[i];
+    r->by_index = o->by_index[i]; r->q_index = o->q_index[i]; r->t_index = o->t_index[i];
+    r->strand = o->strand[i]; r->q_begin = o->q_begin[i]; r->q_end = o->q_end[i]; r->q_length = o->q_length[i];
+    r->t_begin = o->t_begin[i]; r->t_end = o->t_end[i]; r->length = o->length[i]; r->error = o->error[i];
+    r->cigar = o->has_cigar[i] ? o->cigar[i].c_str() : nullptr;
+    r->dropped = o->dropped[i];
+    return VC_OK;
+}
+
+// give record i its CIGAR (the device aligner's result); NULL: the record cannot be aligned, drop it
+int vc_ovlset_set_cigar(vc_ovlset* o, uint64_t i, const char* cigar) {
+    if (!o || i >= o->size()) return VC_ERR_ARG;
+    if (cigar) { o->cigar[i] = cigar; o->has_cigar[i] = 1; }
+    else { o->cigar[i].clear(); o->has_cigar[i] = 1; o->dropped[i] = 1; }
+    return VC_OK;
+}
+
+// Polisher::initialize (src/polisher.cpp:207-352) in fragment-correction mode: sequences and overlaps into the window builder.
+// Returns the number of overlaps kept, or -1 (message through err).  window_type: 0 NGS (mean read length <= 1000), 1 TGS.
+int64_t vc_io_load(vc_wb* wb, const vc_seqset* targets, const vc_seqset* reads, vc_ovlset* ovl, double error_threshold, int allow_empty,
+                   int* window_type, char* err, uint64_t err_cap) {
+    auto fail = [&](const std::string& m) -> int64_t { if (err && err_cap) { snprintf(err, (size_t)err_cap, "%s", m.c_str()); } return -1; };
+    if (!wb || !targets || !reads || !ovl) return fail("null argument");
+    if (targets->size() == 0) return fail("empty target sequences set");
+    if (reads->size() == 0 && !allow_empty) return fail("empty sequences set");
+    auto add = [&](const vc_seqset* s, size_t i) -> int {
+        const uint64_t o0 = s->data_off[i], len = s->data_off[i + 1] - o0;
+        const std::string nm = s->name(i);
+        return vc_wb_add_sequence(wb, nm.c_str(), s->data.data() + o0, (uint32_t)len, s->has_qual[i] ? s->qual.data() + o0 : nullptr);
+    };
+    std::unordered_map<std::string, uint32_t> t_id, q_id;
+    t_id.reserve(targets->size() * 2); q_id.reserve(reads->size() * 2);
+    std::vector<uint32_t> t_ids(targets->size()), q_ids(reads->size());
+    for (size_t i = 0; i < targets->size(); ++i) {
+        const int id = add(targets, i);
+        if (id < 0) return fail("empty sequence");
+        t_ids[i] = (uint32_t)id;
+        t_id[targets->name(i)] = (uint32_t)id;       // (a repeated name: the last record wins, as a dict does)
+    }
+    unsigned long long total = 0;
+    for (size_t i = 0; i < reads->size(); ++i) {
+        const uint64_t len = reads->data_off[i + 1] - reads->data_off[i];
+        total += len;
+        const std::string nm = reads->name(i);
+        auto it = t_id.find(nm);
+        if (it != t_id.end()) {                      // a read that is also a target shares its record (polisher.cpp:262-283)
+            // the target record with that id
+            size_t ti = 0;
+            for (; ti < t_ids.size(); ++ti) if (t_ids[ti] == it->second) break;
+            const uint64_t tlen = targets->data_off[ti + 1] - targets->data_off[ti];
+            const uint64_t tq = targets->has_qual[ti] ? tlen : 0, rq = reads->has_qual[i] ? len : 0;
+            if (tlen != len || tq != rq) return fail("duplicate sequence " + nm + " with unequal data");
+            q_ids[i] = it->second; q_id[nm] = it->second;
+        } else {
+            const int id = add(reads, i);
+            if (id < 0) return fail("empty sequence");
+            q_ids[i] = (uint32_t)id; q_id[nm] = (uint32_t)id;
+        }
+    }
+    if (vc_wb_set_targets(wb, (uint32_t)targets->size()) != VC_OK) return fail("vc_wb_set_targets failed");
+    int64_t kept = 0;
+    for (size_t k = 0; k < ovl->size(); ++k) {
+        uint32_t q, t;
+        if (ovl->by_index[k]) {                      // MHAP: positions in the reads / targets files (overlap.cpp:129-166)
+            if (ovl->q_index[k] >= reads->size() || ovl->t_index[k] >= targets->size()) continue;
+            // ... resolved through the NAMES, like the other formats (a read that is also a target has one id)
+            auto qi = q_id.find(reads->name(ovl->q_index[k])); auto ti = t_id.find(targets->name(ovl->t_index[k]));
+            if (qi == q_id.end() || ti == t_id.end()) continue;
+            q = qi->second; t = ti->second;
+        } else {
+            auto qi = q_id.find(std::string(ovl->text.data() + ovl->qn_off[k], ovl->qn_len[k]));
+            auto ti = t_id.find(std::string(ovl->text.data() + ovl->tn_off[k], ovl->tn_len[k]));
+            if (qi == q_id.end() || ti == t_id.end()) continue;
+            q = qi->second; t = ti->second;
+        }
+        if (ovl->dropped[k] || ovl->error[k] > error_threshold || q == t) continue;
+        if (!ovl->has_cigar[k]) return fail("overlap without a CIGAR: align it first (vc_align / vc_ovlset_set_cigar)");
+        if (vc_wb_add_overlap(wb, q, t, ovl->strand[k], ovl->q_begin[k], ovl->q_end[k], ovl->q_length[k], ovl->t_begin[k], ovl->t_end[k],
+                              ovl->cigar[k].c_str()) != VC_OK)
+            return fail(vc_wb_last_error(wb));
+        ++kept;
+    }
+    if (kept == 0 && !allow_empty) return fail("empty overlap set");
+    if (window_type) *window_type = (double)total / (double)std::max<size_t>(reads->size(), 1) <= 1000 ? 0 : 1;
+    return kept;
+}
+
+}  // extern "C"

@@ -20,6 +20,7 @@ Nothing here computes on the CPU what the reference computes in vechat_racon; wi
 import argparse
 import gzip
 import os
+import re
 import shlex
 import shutil
 import subprocess
@@ -118,6 +119,10 @@ def extract_sub_sequences(sequences, overlap, chunk_targets, workdir):
     return out
 
 
+_FLOAT = re.compile(r"[0-9]+(\.[0-9]*)?([eE][-+]?[0-9]+)?|\.[0-9]+([eE][-+]?[0-9]+)?")
+_INT = re.compile(r"[0-9]+")
+
+
 def polisher_command(a):
     if a.polisher:
         return a.polisher
@@ -152,6 +157,8 @@ def run_error_correction(a, sequences, chunk_targets, corrected_file, iteration,
         # scripts/vechat:59-66,76-80,86-89: the accelerator switches reach the polisher only together with -b (the polisher
         # here is always the accelerated one and accepts them for what they are: hints for another device)
         flags += f" -b --cudaaligner-batches {a.cudaaligner_batches} -c {a.cudapoa_batches}"
+    if getattr(a, "keep_going", False) and not a.polisher:
+        flags += " --keep-going"                               # (only our own polisher knows the switch)
     _sh(f"{pol} {flags} {shlex.quote(sub_reads)} {shlex.quote(overlap)} {shlex.quote(chunk_targets)} >{shlex.quote(corrected_file)}", workdir)
     for f in os.listdir(workdir):
         if f.startswith("query_sequences.tmp."):
@@ -209,7 +216,18 @@ def main(argv=None):
     ap.add_argument("--overlapper-r1", default=None, help="command template replacing the minimap2|awk|fpa pipeline of round 1")
     ap.add_argument("--overlapper-r2", default=None, help="... of round 2")
     ap.add_argument("--polisher", default=None, help="command replacing `python -m vechat_amd.polish`")
+    ap.add_argument("--keep-going", action="store_true", help="handed to the polisher: a window the device cannot hold keeps its backbone "
+                    "(unpolished) instead of ending the run with exit status 3; VC_KEEP_GOING=1 in the environment does the same")
     a = ap.parse_args(argv)
+    # The pass-through values stay the strings the user typed (byte-identical commands, tests/golden/driver_cmds.json), but
+    # they go into `bash -c` command lines and an awk program: nothing but a plain number gets that far
+    for name, pat in (("min_identity", _FLOAT), ("min_confidence", _FLOAT), ("min_support", _FLOAT), ("min_identity_cns", _FLOAT),
+                      ("min_ovlplen_cns", _INT), ("threads", _INT), ("cudaaligner_batches", _INT), ("cudapoa_batches", _INT)):
+        if not pat.fullmatch(str(getattr(a, name))):
+            ap.error(f"--{name.replace('_', '-')}: {getattr(a, name)!r} is not a number")
+    if a.platform not in ("pb", "ont"):
+        ap.error("--platform must be pb or ont")
+    a.keep_going = a.keep_going or os.environ.get("VC_KEEP_GOING") == "1"
 
     workdir = os.path.abspath(a.workdir)
     os.makedirs(workdir, exist_ok=True)
