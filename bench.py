@@ -183,6 +183,36 @@ def short_config(device, seed, L, D, n, profile, frac_partial=0.0, n_haplotypes=
     return out
 
 
+def files_to_fasta(params):
+    """The path a user runs, from files: FASTQ + SAM on disk -> corrected FASTA text through the C++ readers (vc_io_*), the window
+    builder, the device and the stitcher (tools/gpu_files_e2e.py), with the Python readers beside it (must give the same text) and
+    the reference's CPU rate on a sample of the very windows those files make (CHECKER leg: byte comparison)."""
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("gpu_files_e2e", os.path.join(ROOT, "tools", "gpu_files_e2e.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    with tempfile.TemporaryDirectory(prefix="vc_files_", dir="/tmp") as d:
+        res = mod.main(nt=96, tl=10000, depth=64, out=d, python_too=True, quiet=True)
+    batch, text = res.pop("batch"), res.pop("text")
+    res.pop("_keep", None)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api as oa
+        if oa.have_ref("sse41"):
+            oa.load_ref("sse41")
+            cores = usable_cores()
+            p = capi.default_params(min_confidence=0.2, min_support=0.2, num_prune=3)
+            ws = list(range(0, batch.n_windows, max(1, batch.n_windows // 96)))[:96]
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                ref = list(ex.map(lambda w: oa.ref_window(batch, w, p)[0], ws))
+            dt = time.perf_counter() - t0
+            res["reference_cpu"] = {"windows_per_s": len(ws) / dt, "cores": cores, "sample": f"{len(ws)} of the {batch.n_windows} windows these files make (window.cpp through oracle/_ref; parsing not included)"}
+    except Exception as e:                                  # the checker leg must not take the bench line down
+        res["reference_cpu"] = {"error": repr(e)}
+    return res
+
+
 def stub_main(a, world):
     """Launch-plumbing check for boxes without a GPU (tests/test_shard.py): the same rank fan-out, barrier, MAX-over-ranks
     timing and gather, over gloo, with the kernels replaced by "consensus = backbone".  Never a measurement: the line says
@@ -431,6 +461,8 @@ def main():
                            "C_hap2": short_config(local, 1012, 500, 64, 16384, capi.PACBIO, n_haplotypes=2, snp_rate=0.01, check=256),
                            "D_shard": short_config(local, 1002, 500, 64, 125000, capi.PACBIO, first=3 * 125000, check=256),
                            "E_shard": short_config(local, 1005, 1000, 128, 6250, capi.ONT, first=5 * 6250, check=256)}
+    if rank == 0 and world == 1 and not a.no_extras and not a.ab and cfg_name == "C":
+        line["files_to_fasta"] = files_to_fasta(ctx_params)
     if rank == 0 and world == 1 and not a.no_cpu:
         cb, ref_out = cpu_baseline(batch, ctx_params, a.cpu_seconds)
         cons_np = cons_all.cpu().numpy()

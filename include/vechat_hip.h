@@ -184,10 +184,16 @@ void        vc_wb_destroy(vc_wb* b);
 const char* vc_wb_last_error(const vc_wb* b);
 /* returns the sequence id (>= 0) or -1; quality may be NULL (FASTA) */
 int         vc_wb_add_sequence(vc_wb* b, const char* name, const char* data, uint32_t length, const char* quality);
+/* the same without a copy: data / quality stay the caller's and must outlive the builder (vc_io_load passes its record buffers) */
+int         vc_wb_add_sequence_view(vc_wb* b, const char* name, uint32_t name_len, const char* data, uint32_t length, const char* quality);
 int         vc_wb_set_targets(vc_wb* b, uint32_t n_targets);
 /* coordinates as in a PAF/SAM record: q_* on the read's forward strand, strand != 0 = reverse complement */
 int         vc_wb_add_overlap(vc_wb* b, uint32_t q_id, uint32_t t_id, int strand, uint32_t q_begin, uint32_t q_end,
                               uint32_t q_length, uint32_t t_begin, uint32_t t_end, const char* cigar);
+/* n overlaps at once, kept in the order given (their breaking points are computed on several threads) */
+int         vc_wb_add_overlaps(vc_wb* b, uint64_t n, const uint32_t* q_id, const uint32_t* t_id, const uint8_t* strand, const uint32_t* q_begin,
+                               const uint32_t* q_end, const uint32_t* q_length, const uint32_t* t_begin, const uint32_t* t_end,
+                               const char* const* cigar);
 uint32_t    vc_wb_n_breaking_points(const vc_wb* b, uint32_t overlap);
 void        vc_wb_breaking_points(const vc_wb* b, uint32_t overlap, uint32_t* t_pos, uint32_t* q_pos);
 /* fills `out` with arrays owned by the builder (valid until the next build / destroy): every window of every
@@ -198,11 +204,54 @@ const uint32_t* vc_wb_seq_orig(const vc_wb* b);
 uint32_t    vc_wb_n_windows(const vc_wb* b);
 uint32_t    vc_wb_window_target(const vc_wb* b, uint32_t w);
 uint32_t    vc_wb_window_rank(const vc_wb* b, uint32_t w);
+void        vc_wb_window_ids(const vc_wb* b, uint32_t* target /*[n_windows]*/, uint32_t* rank /*[n_windows]*/);
 /* per-target concatenation of the window results with the LN/RC/XC tags; fragment_correction adds the "r" */
 int         vc_wb_stitch(vc_wb* b, const vc_result* res, int drop_unpolished, int fragment_correction);
 uint32_t    vc_wb_n_polished(const vc_wb* b);
 const char* vc_wb_polished_name(const vc_wb* b, uint32_t i);
 const char* vc_wb_polished_data(const vc_wb* b, uint32_t i, uint64_t* length);
+
+/* ------------------------------------------------------------------------------------------------
+ * File formats (host only).  Stands in for what Polisher::initialize does with bioparser before a window
+ * exists (src/polisher.cpp:77-138 parser selection, :207-352 loading and filtering) and for the record constructors of
+ * src/sequence.cpp:19-42 and src/overlap.cpp:14-110.  vechat_amd/csrc/vc_io.cpp.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vc_seqset vc_seqset;      /* the records of one FASTA / FASTQ (.gz) file */
+typedef struct vc_ovlset vc_ovlset;      /* the records of one MHAP / PAF / SAM (.gz) file */
+/* Always returns a set; vc_seqset_error() != NULL says what went wrong.  keep_names: NULL, or '\n'-separated names -- the other
+ * records are passed over.  names_only: names and lengths, no data (a rank of a multi-GPU run plans with that). */
+vc_seqset*      vc_io_read_sequences(const char* path, const char* keep_names, int names_only);
+void            vc_seqset_free(vc_seqset* s);
+const char*     vc_seqset_error(const vc_seqset* s);
+uint64_t        vc_seqset_size(const vc_seqset* s);
+const uint64_t* vc_seqset_name_off(const vc_seqset* s);   /* [n+1] into vc_seqset_names */
+const char*     vc_seqset_names(const vc_seqset* s);
+const uint64_t* vc_seqset_data_off(const vc_seqset* s);   /* [n+1] into vc_seqset_data / vc_seqset_qual */
+const char*     vc_seqset_data(const vc_seqset* s);       /* upper-cased (sequence.cpp:19-42) */
+const char*     vc_seqset_qual(const vc_seqset* s);       /* NULL when no record has a quality string */
+const uint8_t*  vc_seqset_has_qual(const vc_seqset* s);   /* [n]; an all-'!' quality string counts as none */
+const uint64_t* vc_seqset_lengths(const vc_seqset* s);    /* [n] */
+typedef struct {
+    const char* q_name; uint32_t q_name_len;              /* not NUL-terminated */
+    const char* t_name; uint32_t t_name_len;
+    uint8_t  by_index;                                    /* MHAP: q_index / t_index are positions in the reads / targets files */
+    uint32_t q_index, t_index;
+    uint8_t  strand;                                      /* 1 = reverse complement */
+    uint32_t q_begin, q_end, q_length, t_begin, t_end, length;
+    double   error;                                       /* 1 - min(spans) / max(spans) (overlap.cpp:21-26) */
+    const char* cigar;                                    /* NULL: none yet (plain PAF, MHAP) */
+    uint8_t  dropped;                                     /* could not be aligned (vc_ovlset_set_cigar(.., NULL)) */
+} vc_overlap_rec;
+vc_ovlset*  vc_io_read_overlaps(const char* path);        /* format from the extension, like the reference */
+void        vc_ovlset_free(vc_ovlset* o);
+const char* vc_ovlset_error(const vc_ovlset* o);
+uint64_t    vc_ovlset_size(const vc_ovlset* o);
+int         vc_ovlset_get(const vc_ovlset* o, uint64_t i, vc_overlap_rec* out);
+int         vc_ovlset_set_cigar(vc_ovlset* o, uint64_t i, const char* cigar);
+/* Polisher::initialize, fragment-correction mode: every target, every read (a read that is also a target shares its record),
+ * every overlap that survives the filters, into the window builder.  Returns the number of overlaps kept, -1 on error. */
+int64_t     vc_io_load(vc_wb* builder, const vc_seqset* targets, const vc_seqset* reads, vc_ovlset* overlaps, double error_threshold,
+                       int allow_empty, int* window_type, char* err, uint64_t err_cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Overlap alignment on the device.  Stands in for the edlib call the reference makes

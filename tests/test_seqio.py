@@ -159,3 +159,118 @@ def test_cigar_scan_fast_and_plain_paths_agree():
         for flag in (0, 16):
             o = seqio._sam_overlap("q", flag, "t", 101, cg)
             assert (o.q_begin, o.q_end, o.q_length, o.t_begin, o.t_end, o.length) == plain(cg, flag, 101), cg
+
+
+# ---- the C++ readers behind the C ABI (vechat_amd/csrc/vc_io.cpp) against the Python restatement above, format by format
+def _same_overlaps(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        for k in seqio.Overlap.__slots__:
+            assert getattr(x, k) == getattr(y, k), (k, getattr(x, k), getattr(y, k))
+
+
+@pytest.mark.parametrize("sam", [True, False])
+def test_native_readers_give_the_same_batch(built, tmp_path, sam):
+    fx, wb0 = fixtures.load_plumbing()
+    b0, ids0 = wb0.build()
+    rp, op, tp = write_inputs(fx, tmp_path, sam)
+    targets, reads, ovl = seqio.NativeSequences(tp), seqio.NativeSequences(rp), seqio.NativeOverlaps(op)
+    assert targets.records() == seqio.read_sequences(tp) and reads.records() == seqio.read_sequences(rp)
+    assert targets.index() == seqio.sequence_index(tp)
+    keep = {n for n, _, _ in seqio.read_sequences(rp)[::3]}
+    assert seqio.NativeSequences(rp, keep=keep).records() == seqio.read_sequences(rp, keep)
+    assert seqio.NativeSequences(rp, names_only=True).index() == seqio.sequence_index(rp)
+    _same_overlaps(ovl.records(), seqio.read_overlaps(op))
+    wb = WindowBuilder(fx["window_length"], fx["quality_threshold"])
+    kept, wtype = seqio.load_polisher_input_native(wb, targets, reads, ovl)
+    assert kept == len(fx["overlaps"]) and wtype == 1
+    b1, ids1 = wb.build()
+    assert ids1 == ids0
+    for k in ("win_seq_off", "seq_off", "seq_begin", "seq_end", "seq_has_qual", "bases", "quals", "win_fasta"):
+        assert np.array_equal(getattr(b0, k), getattr(b1, k)), k
+    wb.close(); wb0.close()
+
+
+def test_native_readers_odd_inputs_and_filters(built, tmp_path):
+    import random
+    rnd = random.Random(9)
+    # SAM records with odd CIGAR strings, both strands; MHAP; PAF without cg
+    cases = ["10M", "5S10M2I3D4H", "3H7M", "12=3X1I", "3MM", "1M2", "7N3M", "2P5M", "4H3S9M1S"]
+    for _ in range(60):
+        body = "".join("%d%s" % (rnd.randint(1, 5000), rnd.choice("MID=XN")) for _ in range(rnd.randint(1, 300)))
+        cases.append(rnd.choice(["", "12S", "3H"]) + body + rnd.choice(["", "9S", "40H"]))
+    with open(tmp_path / "o.sam", "w") as f:
+        f.write("@SQ\tSN:t\tLN:9\n\n")
+        for i, cg in enumerate(cases):
+            f.write(f"q{i}\t{16 * (i % 2)}\tt{i % 3}\t{101 + i}\t60\t{cg}\t*\t0\t0\t*\t*\n")
+    _same_overlaps(seqio.NativeOverlaps(tmp_path / "o.sam").records(), seqio.read_overlaps(tmp_path / "o.sam"))
+    (tmp_path / "x.mhap").write_text("2 1 0.1 10 0 0 40 40 1 4 44 120\n1 1 0.2 9 1 3 9 40 1 0 7 120\n")
+    _same_overlaps(seqio.NativeOverlaps(tmp_path / "x.mhap").records(), seqio.read_overlaps(tmp_path / "x.mhap"))
+    (tmp_path / "nocg.paf").write_text("r\t40\t0\t40\t+\tt\t120\t4\t44\t40\t40\t60\nr\t40\t0\t40\t-\tt\t120\t4\t44\t40\t40\t60\tcg:Z:40M\n")
+    _same_overlaps(seqio.NativeOverlaps(tmp_path / "nocg.paf").records(), seqio.read_overlaps(tmp_path / "nocg.paf"))
+    with pytest.raises(ValueError):
+        seqio.NativeOverlaps(tmp_path / "x.txt")
+    with pytest.raises(ValueError):
+        seqio.NativeSequences(tmp_path / "missing.fa")
+    # the filters of Polisher::initialize, and a read that is also a target
+    (tmp_path / "t.fa").write_text(">t\n" + "ACGT" * 30 + "\n")
+    (tmp_path / "r.fa").write_text(">t\n" + "ACGT" * 30 + "\n>r\n" + "ACGT" * 10 + "\n")
+    (tmp_path / "f.paf").write_text("t\t120\t0\t120\t+\tt\t120\t0\t120\t0\t0\t60\tcg:Z:120M\n"
+                                    "r\t40\t0\t40\t+\tt\t120\t0\t100\t0\t0\t60\tcg:Z:40M\n"
+                                    "r\t40\t0\t40\t+\tt\t120\t4\t44\t0\t0\t60\tcg:Z:40M\n"
+                                    "zz\t4\t0\t4\t+\tt\t120\t0\t4\t0\t0\t60\tcg:Z:4M\n")
+    wb = WindowBuilder(50, 10.0)
+    kept, wtype = seqio.load_polisher_input_native(wb, seqio.NativeSequences(tmp_path / "t.fa"), seqio.NativeSequences(tmp_path / "r.fa"),
+                                                  seqio.NativeOverlaps(tmp_path / "f.paf"))
+    assert kept == 1 and wtype == 0
+    wb.close()
+    wb = WindowBuilder(50, 10.0)
+    with pytest.raises(ValueError, match="CIGAR"):
+        seqio.load_polisher_input_native(wb, seqio.NativeSequences(tmp_path / "t.fa"), seqio.NativeSequences(tmp_path / "r.fa"),
+                                         seqio.NativeOverlaps(tmp_path / "nocg.paf"))
+    wb.close()
+
+
+def test_native_sequence_reader_large_file_in_pieces(built, tmp_path):
+    """Plain files beyond 4 MB are cut at record boundaries and parsed by several threads: same records as one thread, in order."""
+    import random
+    rnd = random.Random(3)
+    with open(tmp_path / "big.fastq", "w") as f, open(tmp_path / "big.fasta", "w") as g:
+        for i in range(9000):
+            n = rnd.choice([90, 500, 1200])
+            s = "".join(rnd.choice("ACGTacgtN") for _ in range(n))
+            q = "".join(chr(33 + rnd.randint(0, 50)) for _ in range(n)).replace("+", "@") if i % 7 else "!" * n
+            f.write(f"@r{i} d\n{s}\n+\n{q}\n")
+            g.write(f">r{i}\n" + "".join(s[k:k + 70] + "\n" for k in range(0, n, 70)) + ("\n" if i % 50 == 0 else ""))
+    for name in ("big.fastq", "big.fasta"):
+        assert seqio.NativeSequences(tmp_path / name).records() == seqio.read_sequences(tmp_path / name)
+
+
+@pytest.mark.parametrize("seed", [1])
+def test_native_sequence_ingest_matches_the_reference_parser(tmp_path, seed):
+    """the C++ reader against the reference's own bioparser + racon::Sequence, as test_sequence_ingest_matches_the_reference_parser does"""
+    import random
+
+    import oracle_api as oa
+    if not oa.have_seqparse():
+        pytest.skip("oracle/_ref/libvcseq.so not built (needs /root/reference)")
+    rng = random.Random(seed)
+    rs = lambda n: "".join(rng.choice("ACGTacgtNnRYKMSWBDHVUu-*.") for _ in range(n))
+    fa, fq = "", ""
+    for i in range(12):
+        body = rs(rng.choice([1, 5, 70, 71, 500, 3000]))
+        width = rng.choice([len(body), 60, 70])
+        fa += f">t{i}" + rng.choice(["", " some description", "\ttabbed text"]) + "\n" + "".join(body[k:k + width] + "\n" for k in range(0, len(body), width))
+        n = rng.choice([1, 2, 150, 2000])
+        q = "!" * n if i % 4 == 2 else "".join(chr(33 + rng.randint(0, 60)) for _ in range(n))
+        fq += f"@q{i}" + rng.choice(["", " len=%d" % n]) + f"\n{rs(n)}\n+\n{q}\n"
+    for name, text, is_fq in (("a.fasta", fa, 0), ("a.fastq", fq, 1)):
+        p = tmp_path / name
+        p.write_text(text)
+        pz = tmp_path / (name + ".gz")
+        with gzip.open(pz, "wt") as f:
+            f.write(text)
+        for path in (p, pz):
+            ref = oa.ref_parse_sequences(path, is_fq)
+            mine = seqio.NativeSequences(path).records()
+            assert [(n, d, q) for n, d, q, _, _ in ref] == mine

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vechat_amd import capi                                                     # noqa: E402
 from vechat_amd.engine import HipContext                                        # noqa: E402
-from vechat_amd.seqio import load_polisher_input, read_overlaps, read_sequences  # noqa: E402
+from vechat_amd.seqio import (load_polisher_input, load_polisher_input_native, read_inputs_native,  # noqa: E402
+                                read_overlaps, read_sequences)
 from vechat_amd.windows import WindowBuilder                                    # noqa: E402
 
 NT = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -45,11 +46,13 @@ def noisy_copy(rng, t, sub=0.05, ins=0.05, dele=0.05):
     return out, cigar
 
 
-def main():
-    nt = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    tl = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-    depth = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-    out = sys.argv[4] if len(sys.argv) > 4 else "/tmp/vc_files"
+def main(nt=None, tl=None, depth=None, out=None, python_too=True, quiet=False):
+    """-> dict(windows_per_s, ...) of the C++-reader path (and the Python-reader path beside it)"""
+    nt = nt or (int(sys.argv[1]) if len(sys.argv) > 1 else 200)
+    tl = tl or (int(sys.argv[2]) if len(sys.argv) > 2 else 10000)
+    depth = depth or (int(sys.argv[3]) if len(sys.argv) > 3 else 64)
+    out = out or (sys.argv[4] if len(sys.argv) > 4 else "/tmp/vc_files")
+    say = (lambda *a, **k: None) if quiet else print
     os.makedirs(out, exist_ok=True)
     rng = np.random.default_rng(7)
     t0 = time.time()
@@ -66,28 +69,60 @@ def main():
                 f_r.write(b"@" + rn.encode() + b"\n" + r.tobytes() + b"\n+\n" + q + b"\n")
                 f_s.write(f"{rn}\t0\t{tname}\t1\t60\t{cg}\t*\t0\t0\t*\t*\n")
     mb = (os.path.getsize(fq) + os.path.getsize(sam) + os.path.getsize(tg)) / 1e6
-    print(f"generated {nt} targets x {tl} bp x {depth} reads: {mb:.0f} MB of files in {time.time() - t0:.1f} s", flush=True)
+    say(f"generated {nt} targets x {tl} bp x {depth} reads: {mb:.0f} MB of files in {time.time() - t0:.1f} s", flush=True)
 
-    T = {}
-    t0 = time.time(); overlaps = read_overlaps(sam); T["parse overlaps (SAM)"] = time.time() - t0
-    t0 = time.time(); targets, reads = read_sequences(tg), read_sequences(fq); T["parse sequences (FASTQ)"] = time.time() - t0
-    t0 = time.time()
-    wb = WindowBuilder(500, 10.0)
-    kept, _ = load_polisher_input(wb, targets, reads, overlaps, 0.3)
-    batch, ids = wb.build()
-    T["window assembly"] = time.time() - t0
-    ctx = HipContext(device=0, mode=0, min_confidence=0.2, min_support=0.2, num_prune=3)
-    ctx.consensus(capi.synth_batch(capi.synth_cfg(1, 200, 8), 0, 64))           # context and workspaces exist before the clock starts
-    t0 = time.time(); cons, status = ctx.consensus(batch); T["device (submit + run + collect)"] = time.time() - t0
-    t0 = time.time()
-    text = b"".join(b">" + n.encode() + b"\n" + d + b"\n" for n, d in wb.stitch(cons, status, drop_unpolished=True, fragment_correction=True))
-    T["stitch"] = time.time() - t0
-    nw = batch.n_windows
-    tot = sum(T.values())
-    print(f"{nw} windows, {kept} overlaps, {len(text) / 1e6:.1f} MB of corrected FASTA; polished {sum(int(s) == capi.VC_WIN_OK for s in status)}")
-    for k, v in T.items():
-        print(f"  {k:34s} {v:8.2f} s  {nw / v:10.0f} windows/s")
-    print(f"  {'files -> FASTA':34s} {tot:8.2f} s  {nw / tot:10.0f} windows/s   ({mb / tot:.0f} MB/s of input)")
+    keep = []
+
+    def run(native, dev):
+        T = {}
+        if native:
+            t0 = time.time(); reads, overlaps, targets = read_inputs_native(fq, sam, tg); T["parse the three files (side by side)"] = time.time() - t0
+        else:
+            t0 = time.time(); overlaps = read_overlaps(sam); T["parse overlaps (SAM)"] = time.time() - t0
+            t0 = time.time(); targets, reads = read_sequences(tg), read_sequences(fq); T["parse sequences (FASTQ)"] = time.time() - t0
+        t0 = time.time()
+        wb = WindowBuilder(500, 10.0)
+        kept, _ = (load_polisher_input_native if native else load_polisher_input)(wb, targets, reads, overlaps, 0.3)
+        T["load (records -> window builder)"] = time.time() - t0
+        t0 = time.time()
+        batch, ids = wb.build(copy=not native)
+        T["window assembly (vc_wb_build)"] = time.time() - t0
+        nw = batch.n_windows
+        text = b""
+        if dev:
+            t0 = time.time(); cons, status = ctx.consensus(batch); T["device (submit + run + collect)"] = time.time() - t0
+            t0 = time.time()
+            text = b"".join(b">" + n.encode() + b"\n" + d + b"\n" for n, d in wb.stitch(cons, status, drop_unpolished=True, fragment_correction=True))
+            T["stitch"] = time.time() - t0
+            say(f"{nw} windows, {kept} overlaps, {len(text) / 1e6:.1f} MB of corrected FASTA; polished {sum(int(s) == capi.VC_WIN_OK for s in status)}")
+        keep.append((wb, targets, reads, overlaps))               # (the native batch is a view of the builder's buffers)
+        tot = sum(T.values())
+        say(("C++ readers (vc_io)" if native else "Python readers (seqio)") + (":" if dev else ", host side only:"))
+        for k, v in T.items():
+            say(f"  {k:34s} {v:8.2f} s  {nw / v:10.0f} windows/s")
+        say(f"  {'files -> FASTA' if dev else 'files -> batch':34s} {tot:8.2f} s  {nw / tot:10.0f} windows/s   ({mb / tot:.0f} MB/s of input)", flush=True)
+        return text, batch, nw / tot, T
+
+    dev = os.environ.get("VC_FILES_HOST_ONLY") != "1"
+    if dev:
+        ctx = HipContext(device=0, mode=0, min_confidence=0.2, min_support=0.2, num_prune=3)
+        ctx.consensus(capi.synth_batch(capi.synth_cfg(1, 200, 8), 0, 64))       # context and workspaces exist before the clock starts
+    t_nat, b_nat, rate_nat, T_nat = run(True, dev)
+    res = {"windows_per_s": rate_nat, "windows": int(b_nat.n_windows), "input_mb": mb, "seconds_by_phase": {k: round(v, 4) for k, v in T_nat.items()},
+           "workload": f"{nt} targets x {tl} bp x {depth} reads as FASTQ + SAM files -> corrected FASTA text (C++ readers vc_io_*, window builder, device, stitching; "
+                       "one process, phases in series)", "batch": b_nat, "text": t_nat}
+    if python_too:
+        t_py, b_py, rate_py, _ = run(False, dev)
+        same = all(np.array_equal(getattr(b_nat, k), getattr(b_py, k)) for k in ("win_seq_off", "seq_off", "seq_begin", "seq_end", "seq_has_qual", "bases", "quals", "win_fasta"))
+        say(f"batches identical: {same}; corrected FASTA identical: {t_nat == t_py}; files_to_fasta {rate_nat:.0f} windows/s (C++) vs {rate_py:.0f} (Python)")
+        res.update({"windows_per_s_python_readers": rate_py, "identical_to_python_path": bool(same and t_nat == t_py)})
+    if os.environ.get("VC_FILES_JSON"):
+        import json
+        json.dump({k: v for k, v in res.items() if k not in ("batch", "text")}, open(os.environ["VC_FILES_JSON"], "w"))
+    if dev:
+        ctx.close()
+    res["_keep"] = keep
+    return res
 
 
 if __name__ == "__main__":

@@ -67,6 +67,15 @@ class VcStats(C.Structure):
     ]
 
 
+class VcOverlapRec(C.Structure):
+    _fields_ = [
+        ("q_name", C.c_void_p), ("q_name_len", C.c_uint32), ("t_name", C.c_void_p), ("t_name_len", C.c_uint32),
+        ("by_index", C.c_uint8), ("q_index", C.c_uint32), ("t_index", C.c_uint32), ("strand", C.c_uint8),
+        ("q_begin", C.c_uint32), ("q_end", C.c_uint32), ("q_length", C.c_uint32), ("t_begin", C.c_uint32), ("t_end", C.c_uint32),
+        ("length", C.c_uint32), ("error", C.c_double), ("cigar", C.c_char_p), ("dropped", C.c_uint8),
+    ]
+
+
 class VcSynthCfg(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64),
@@ -202,10 +211,26 @@ def _declare_host(lib):
     lib.vc_wb_n_windows.argtypes = [vp]; lib.vc_wb_n_windows.restype = u32
     lib.vc_wb_window_target.argtypes = [vp, u32]; lib.vc_wb_window_target.restype = u32
     lib.vc_wb_window_rank.argtypes = [vp, u32]; lib.vc_wb_window_rank.restype = u32
+    lib.vc_wb_window_ids.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]; lib.vc_wb_window_ids.restype = None
     lib.vc_wb_stitch.argtypes = [vp, C.POINTER(VcResult), C.c_int, C.c_int]; lib.vc_wb_stitch.restype = C.c_int
     lib.vc_wb_n_polished.argtypes = [vp]; lib.vc_wb_n_polished.restype = u32
     lib.vc_wb_polished_name.argtypes = [vp, u32]; lib.vc_wb_polished_name.restype = C.c_char_p
     lib.vc_wb_polished_data.argtypes = [vp, u32, C.POINTER(C.c_uint64)]; lib.vc_wb_polished_data.restype = C.POINTER(C.c_char)
+    u64p = C.POINTER(C.c_uint64)
+    lib.vc_io_read_sequences.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; lib.vc_io_read_sequences.restype = vp
+    lib.vc_seqset_free.argtypes = [vp]; lib.vc_seqset_free.restype = None
+    lib.vc_seqset_error.argtypes = [vp]; lib.vc_seqset_error.restype = C.c_char_p
+    lib.vc_seqset_size.argtypes = [vp]; lib.vc_seqset_size.restype = C.c_uint64
+    for name, rt in (("vc_seqset_name_off", u64p), ("vc_seqset_data_off", u64p), ("vc_seqset_lengths", u64p), ("vc_seqset_names", C.c_void_p),
+                     ("vc_seqset_data", C.c_void_p), ("vc_seqset_qual", C.c_void_p), ("vc_seqset_has_qual", C.POINTER(C.c_uint8))):
+        getattr(lib, name).argtypes = [vp]; getattr(lib, name).restype = rt
+    lib.vc_io_read_overlaps.argtypes = [C.c_char_p]; lib.vc_io_read_overlaps.restype = vp
+    lib.vc_ovlset_free.argtypes = [vp]; lib.vc_ovlset_free.restype = None
+    lib.vc_ovlset_error.argtypes = [vp]; lib.vc_ovlset_error.restype = C.c_char_p
+    lib.vc_ovlset_size.argtypes = [vp]; lib.vc_ovlset_size.restype = C.c_uint64
+    lib.vc_ovlset_get.argtypes = [vp, C.c_uint64, C.POINTER(VcOverlapRec)]; lib.vc_ovlset_get.restype = C.c_int
+    lib.vc_ovlset_set_cigar.argtypes = [vp, C.c_uint64, C.c_char_p]; lib.vc_ovlset_set_cigar.restype = C.c_int
+    lib.vc_io_load.argtypes = [vp, vp, vp, vp, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_uint64]; lib.vc_io_load.restype = C.c_int64
     lib.vc_synth_generate.argtypes = [C.POINTER(VcSynthCfg), C.c_uint64, C.c_uint32, C.c_uint32]
     lib.vc_synth_generate.restype = C.c_void_p
     lib.vc_synth_batch.argtypes = [C.c_void_p, C.POINTER(VcBatch)]

@@ -33,6 +33,11 @@
 #include <unordered_map>
 #include <vector>
 
+#include <chrono>
+// development: VC_IO_TIMING=1 prints the time of every stage of a call to stderr
+#define VC_IO_T0 auto io_t0_ = std::chrono::steady_clock::now(); const bool io_tm_ = getenv("VC_IO_TIMING") != nullptr
+#define VC_IO_TICK(what) do { if (io_tm_) { auto n_ = std::chrono::steady_clock::now(); fprintf(stderr, "  [vc_io] %-10s %.3f s\n", what, std::chrono::duration<double>(n_ - io_t0_).count()); io_t0_ = n_; } } while (0)
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ file contents
@@ -71,7 +76,7 @@ bool load_file(const char* path, Blob& b, std::string& err) {
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); err = ps + ": cannot stat"; return false; }
     if (st.st_size == 0) { close(fd); b.p = ""; b.n = 0; return true; }
-    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);   // (pre-faulted in one go: parser threads faulting pages one by one serialise on the address space)
     close(fd);
     if (m == MAP_FAILED) { err = ps + ": cannot map"; return false; }
     madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
@@ -89,7 +94,12 @@ inline void strip(const char*& p, const char*& e) {
     while (p < e && is_space(*p)) ++p;
     while (e > p && is_space(e[-1])) --e;
 }
-inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+inline void append_upper(std::string& o, const char* a, const char* b) {             // sequence.cpp:19-42 upper-cases the bases
+    const size_t at = o.size(), n = (size_t)(b - a);
+    o.append(a, n);
+    char* p = &o[at];
+    for (size_t i = 0; i < n; ++i) { const char c = p[i]; p[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+}
 
 unsigned n_threads() {
     unsigned n = std::thread::hardware_concurrency();
@@ -108,8 +118,24 @@ unsigned n_threads() {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ sequences
+namespace {
+struct RawBuf {                                      // bytes without the zero fill of a std::string (every thread first-touches its own part)
+    char* p = nullptr; size_t n = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf&) = delete;
+    RawBuf& operator=(const RawBuf&) = delete;
+    ~RawBuf() { free(p); }
+    void alloc(size_t k) { free(p); p = (char*)malloc(k ? k : 1); n = k; }
+    const char* data() const { return p; }
+    char* data() { return p; }
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+};
+}  // namespace
+
 struct vc_seqset {
-    std::string names, data, qual;                   // concatenated; qual has the data's offsets (empty stretch where none)
+    std::string names;
+    RawBuf data, qual;                               // concatenated; qual has the data's offsets ('!' where a record has none)
     std::vector<uint64_t> name_off{0}, data_off{0};
     std::vector<uint8_t> has_qual;
     std::vector<uint64_t> length;                    // == data_off differences when the data is kept
@@ -150,7 +176,7 @@ const char* parse_record(const char* p, const char* e, const std::string& path, 
             const char* l2 = line_end(q, e);
             const char* a = q; const char* b = l2;
             strip(a, b);
-            if (want && !names_only) for (const char* c = a; c < b; ++c) o.data += up(*c);
+            if (want && !names_only) append_upper(o.data, a, b);
             dlen += (size_t)(b - a);
             q = l2 < e ? l2 + 1 : e;
         }
@@ -160,7 +186,7 @@ const char* parse_record(const char* p, const char* e, const std::string& path, 
         const char* a = q; const char* b = l2;
         strip(a, b);
         dlen = (size_t)(b - a);
-        if (want && !names_only) for (const char* c = a; c < b; ++c) o.data += up(*c);
+        if (want && !names_only) append_upper(o.data, a, b);
         q = l2 < e ? l2 + 1 : e;
         q = line_end(q, e); q = q < e ? q + 1 : e;                           // the '+' line
         const char* l4 = line_end(q, e);
@@ -185,6 +211,14 @@ const char* parse_record(const char* p, const char* e, const std::string& path, 
 }
 
 void parse_range(const char* p, const char* e, const std::string& path, const KeepSet* keep, bool names_only, SeqPart& o) {
+    if (!names_only && !keep) {                      // one allocation per buffer instead of a dozen regrowths of tens of megabytes
+        const size_t n = (size_t)(e - p);
+        const char* s = p;
+        while (s < e && is_space(*s)) ++s;
+        const bool fq = s < e && *s == '@';
+        o.data.reserve(fq ? n / 2 + 64 : n);
+        if (fq) o.qual.reserve(n / 2 + 64);
+    }
     while (p < e && o.err.empty()) {
         const char* le = line_end(p, e);
         const char* a = p; const char* b = le;
@@ -256,32 +290,52 @@ vc_seqset* vc_io_read_sequences(const char* path, const char* keep_names, int na
             p = *e ? e + 1 : e;
         }
     }
+    VC_IO_T0;
     const std::vector<size_t> cut = cut_points(f, n_threads());
+    VC_IO_TICK("cut");
     std::vector<SeqPart> parts(cut.size() - 1);
     std::vector<std::thread> th;
     const std::string ps(path);
     for (size_t k = 0; k + 1 < cut.size(); ++k)
         th.emplace_back([&, k]() { parse_range(f.p + cut[k], f.p + cut[k + 1], ps, keep_names ? &keep : nullptr, names_only != 0, parts[k]); });
     for (auto& t : th) t.join();
+    VC_IO_TICK("parse");
     size_t nn = 0, nd = 0, nr = 0; bool anyq = false;
     for (auto& p : parts) {
         if (!p.err.empty() && s->err.empty()) s->err = p.err;
         nn += p.names.size(); nd += p.data.size(); nr += p.has_qual.size(); anyq |= !p.qual.empty();
     }
     if (!s->err.empty()) return s;
-    s->names.reserve(nn); s->data.reserve(nd); if (anyq) s->qual.reserve(nd);
-    s->name_off.reserve(nr + 1); s->data_off.reserve(nr + 1); s->has_qual.reserve(nr); s->length.reserve(nr);
-    for (auto& p : parts) {
-        if (anyq) { s->qual.resize(s->data.size(), '!'); p.qual.resize(p.data.size(), '!'); s->qual += p.qual; }
-        s->names += p.names; s->data += p.data;
-        for (size_t i = 0; i < p.has_qual.size(); ++i) {
-            s->name_off.push_back(s->name_off.back() + p.name_len[i]);
-            s->data_off.push_back(s->data_off.back() + (names_only ? 0 : p.data_len[i]));
-            s->length.push_back(p.data_len[i]);
-            s->has_qual.push_back(p.has_qual[i]);
-        }
-        SeqPart().names.swap(p.names); std::string().swap(p.data); std::string().swap(p.qual);
+    // the pieces side by side into the final buffers (offsets first, then every thread copies its own piece)
+    std::vector<size_t> d_at(parts.size() + 1, 0), n_at(parts.size() + 1, 0), r_at(parts.size() + 1, 0);
+    for (size_t k = 0; k < parts.size(); ++k) {
+        d_at[k + 1] = d_at[k] + parts[k].data.size(); n_at[k + 1] = n_at[k] + parts[k].names.size(); r_at[k + 1] = r_at[k] + parts[k].has_qual.size();
     }
+    s->names.resize(nn); s->data.alloc(nd); if (anyq) s->qual.alloc(nd);
+    s->name_off.assign(nr + 1, 0); s->data_off.assign(nr + 1, 0); s->has_qual.assign(nr, 0); s->length.assign(nr, 0);
+    VC_IO_TICK("alloc");
+    std::vector<std::thread> cp;
+    for (size_t k = 0; k < parts.size(); ++k)
+        cp.emplace_back([&, k]() {
+            SeqPart& p = parts[k];
+            if (!p.names.empty()) std::memcpy(&s->names[n_at[k]], p.names.data(), p.names.size());
+            if (!p.data.empty()) std::memcpy(s->data.data() + d_at[k], p.data.data(), p.data.size());
+            if (anyq) {                              // (a piece's qual may stop short of its data: '!' behind it)
+                if (!p.qual.empty()) std::memcpy(s->qual.data() + d_at[k], p.qual.data(), p.qual.size());
+                if (p.qual.size() < p.data.size()) std::memset(s->qual.data() + d_at[k] + p.qual.size(), '!', p.data.size() - p.qual.size());
+            }
+            uint64_t no = n_at[k], dof = d_at[k];
+            for (size_t i = 0; i < p.has_qual.size(); ++i) {
+                const size_t r = r_at[k] + i;
+                s->name_off[r] = no; s->data_off[r] = dof;
+                no += p.name_len[i]; dof += names_only ? 0 : p.data_len[i];
+                s->length[r] = p.data_len[i]; s->has_qual[r] = p.has_qual[i];
+            }
+            std::string().swap(p.names); std::string().swap(p.data); std::string().swap(p.qual);
+        });
+    for (auto& t : cp) t.join();
+    VC_IO_TICK("concat");
+    s->name_off[nr] = nn; s->data_off[nr] = names_only ? 0 : nd;
     return s;
 }
 
@@ -347,72 +401,58 @@ bool to_u64(const char* p, const char* e, uint64_t& v) {
     return true;
 }
 
-// src/overlap.cpp:44-110 on a CIGAR string
-bool sam_spans(const char* c, const char* e, uint64_t& q_begin_clip, uint64_t& q_aln, uint64_t& t_aln, uint64_t& clip) {
+// src/overlap.cpp:44-110 on a CIGAR string: every <count><operation> token counts, anything else is passed over (the Python
+// restatement's `(\d+)([MIDNSHP=X])` scan); the leading clip is the FIRST token when that one is S or H
+void sam_spans(const char* c, const char* e, uint64_t& q_begin_clip, uint64_t& q_aln, uint64_t& t_aln, uint64_t& clip) {
     q_begin_clip = q_aln = t_aln = clip = 0;
     bool first = true;
     while (c < e) {
-        uint64_t n = 0; const char* d = c;
+        if (*c < '0' || *c > '9') { ++c; continue; }
+        uint64_t n = 0;
         while (c < e && *c >= '0' && *c <= '9') { n = n * 10 + (uint64_t)(*c - '0'); ++c; }
-        if (c == d || c == e) return false;
+        if (c == e) break;
         switch (*c) {
             case 'M': case '=': case 'X': q_aln += n; t_aln += n; break;
             case 'I': q_aln += n; break;
             case 'D': case 'N': t_aln += n; break;
             case 'S': case 'H': clip += n; if (first) q_begin_clip = n; break;
             case 'P': break;
-            default: return false;
+            default: continue;                       // not an operation: the digits before it were no token
         }
         first = false;
         ++c;
     }
-    return true;
 }
 
-}  // namespace
+enum OvlFmt { MHAP, PAF, SAM };
 
-extern "C" {
-
-vc_ovlset* vc_io_read_overlaps(const char* path) {
-    vc_ovlset* o = new vc_ovlset();
-    if (!path) { o->err = "null path"; return o; }
-    const std::string ps(path);
-    enum { MHAP, PAF, SAM } fmt;
-    if (ends_with(ps, ".mhap") || ends_with(ps, ".mhap.gz")) fmt = MHAP;
-    else if (ends_with(ps, ".sam") || ends_with(ps, ".sam.gz")) fmt = SAM;
-    else if (ends_with(ps, ".paf") || ends_with(ps, ".paf.gz")) fmt = PAF;
-    else { o->err = ps + ": unsupported overlap format (valid extensions: .mhap, .mhap.gz, .paf, .paf.gz, .sam, .sam.gz)"; return o; }
-    Blob f;
-    if (!load_file(path, f, o->err)) return o;
-    o->text.assign(f.p, f.n);                        // names point into this copy (the mapping goes away with this call)
-    const char* base = o->text.data();
-    const char* p = base; const char* e = base + o->text.size();
+// the records of the lines in [p, e) of `base` (names as offsets into base); first_line: number of the first line, for messages
+void parse_overlap_lines(vc_ovlset* o, OvlFmt fmt, const std::string& ps, const char* base, const char* p, const char* e) {
     Fields fl;
     auto name = [&](std::vector<uint64_t>& off, std::vector<uint32_t>& len, const std::pair<const char*, const char*>& x) {
         off.push_back((uint64_t)(x.first - base)); len.push_back((uint32_t)(x.second - x.first));
     };
-    size_t lineno = 0;
     while (p < e) {
         const char* le = line_end(p, e);
-        ++lineno;
         const char* a = p; const char* b = le;
         p = le < e ? le + 1 : e;
         const char* sa = a; const char* sb = b;
         strip(sa, sb);
         if (sa == sb) continue;
+        const std::string where = " in the record that starts at byte " + std::to_string((size_t)(a - base));
         if (fmt == SAM) {
             if (*a == '@') continue;
             if (b > a && b[-1] == '\r') --b;
             fl.tabs(a, b);
             uint64_t flag = 0, pos = 0;
             if (fl.f.size() < 6 || !to_u64(fl.f[1].first, fl.f[1].second, flag) || !to_u64(fl.f[3].first, fl.f[3].second, pos)) {
-                o->err = ps + ": malformed SAM record at line " + std::to_string(lineno); return o;
+                o->err = ps + ": malformed SAM record" + where; return;
             }
             if (flag & 0x4) continue;                                          // unmapped
             const char* cs = fl.f[5].first; const char* ce = fl.f[5].second;
-            if (ce - cs < 2) { o->err = "missing alignment from SAM object"; return o; }
+            if (ce - cs < 2) { o->err = "missing alignment from SAM object"; return; }
             uint64_t qbc, qa, ta, clip;
-            if (!sam_spans(cs, ce, qbc, qa, ta, clip)) { o->err = ps + ": malformed CIGAR at line " + std::to_string(lineno); return o; }
+            sam_spans(cs, ce, qbc, qa, ta, clip);
             const bool st = (flag & 0x10) != 0;
             uint64_t qb = qbc, qe = qbc + qa;
             const uint64_t ql = clip + qa;
@@ -429,7 +469,7 @@ vc_ovlset* vc_io_read_overlaps(const char* path) {
             uint64_t ql, qb, qe, tb, te;
             if (fl.f.size() < 9 || !to_u64(fl.f[1].first, fl.f[1].second, ql) || !to_u64(fl.f[2].first, fl.f[2].second, qb) ||
                 !to_u64(fl.f[3].first, fl.f[3].second, qe) || !to_u64(fl.f[7].first, fl.f[7].second, tb) || !to_u64(fl.f[8].first, fl.f[8].second, te)) {
-                o->err = ps + ": malformed PAF record at line " + std::to_string(lineno); return o;
+                o->err = ps + ": malformed PAF record" + where; return;
             }
             const uint64_t len = std::max(qe - qb, te - tb);
             name(o->qn_off, o->qn_len, fl.f[0]); name(o->tn_off, o->tn_len, fl.f[5]);
@@ -446,7 +486,7 @@ vc_ovlset* vc_io_read_overlaps(const char* path) {
             uint64_t v[12];
             bool ok = fl.f.size() >= 12;
             for (int k : {0, 1, 4, 5, 6, 7, 8, 9, 10}) ok = ok && to_u64(fl.f[k].first, fl.f[k].second, v[k]);
-            if (!ok) { o->err = ps + ": malformed MHAP record at line " + std::to_string(lineno); return o; }
+            if (!ok) { o->err = ps + ": malformed MHAP record" + where; return; }
             const uint64_t len = std::max(v[6] - v[5], v[10] - v[9]);
             o->qn_off.push_back(0); o->qn_len.push_back(0); o->tn_off.push_back(0); o->tn_len.push_back(0);
             o->by_index.push_back(1); o->q_index.push_back((uint32_t)(v[0] - 1)); o->t_index.push_back((uint32_t)(v[1] - 1));
@@ -454,6 +494,51 @@ vc_ovlset* vc_io_read_overlaps(const char* path) {
                            len ? 1 - (double)std::min(v[6] - v[5], v[10] - v[9]) / (double)len : 1.0);
             o->has_cigar.push_back(0); o->cigar.emplace_back();
         }
+    }
+}
+
+template <typename V> void append(V& a, V& b) { a.insert(a.end(), std::make_move_iterator(b.begin()), std::make_move_iterator(b.end())); }
+
+}  // namespace
+
+extern "C" {
+
+vc_ovlset* vc_io_read_overlaps(const char* path) {
+    vc_ovlset* o = new vc_ovlset();
+    if (!path) { o->err = "null path"; return o; }
+    const std::string ps(path);
+    OvlFmt fmt;
+    if (ends_with(ps, ".mhap") || ends_with(ps, ".mhap.gz")) fmt = MHAP;
+    else if (ends_with(ps, ".sam") || ends_with(ps, ".sam.gz")) fmt = SAM;
+    else if (ends_with(ps, ".paf") || ends_with(ps, ".paf.gz")) fmt = PAF;
+    else { o->err = ps + ": unsupported overlap format (valid extensions: .mhap, .mhap.gz, .paf, .paf.gz, .sam, .sam.gz)"; return o; }
+    {
+        Blob f;
+        if (!load_file(path, f, o->err)) return o;
+        o->text.assign(f.p, f.n);                    // names point into this copy (the mapping goes away with this call)
+    }
+    const char* base = o->text.data();
+    const size_t n = o->text.size();
+    // pieces at line boundaries, one per thread; the records of the pieces in file order
+    std::vector<size_t> cut{0};
+    const unsigned T = n < (1u << 22) ? 1u : n_threads();
+    for (unsigned k = 1; k < T; ++k) {
+        const char* q = (const char*)memchr(base + n * k / T, '\n', n - n * k / T);
+        const size_t at = q ? (size_t)(q - base) + 1 : n;
+        if (at > cut.back() && at < n) cut.push_back(at);
+    }
+    cut.push_back(n);
+    std::vector<vc_ovlset> part(cut.size() - 1);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k + 1 < cut.size(); ++k)
+        th.emplace_back([&, k]() { parse_overlap_lines(&part[k], fmt, ps, base, base + cut[k], base + cut[k + 1]); });
+    for (auto& t : th) t.join();
+    for (auto& p : part) {
+        if (!p.err.empty()) { if (o->err.empty()) o->err = p.err; continue; }
+        append(o->qn_off, p.qn_off); append(o->tn_off, p.tn_off); append(o->qn_len, p.qn_len); append(o->tn_len, p.tn_len);
+        append(o->by_index, p.by_index); append(o->strand, p.strand); append(o->has_cigar, p.has_cigar); append(o->dropped, p.dropped);
+        append(o->q_begin, p.q_begin); append(o->q_end, p.q_end); append(o->q_length, p.q_length); append(o->t_begin, p.t_begin); append(o->t_end, p.t_end);
+        append(o->length, p.length); append(o->q_index, p.q_index); append(o->t_index, p.t_index); append(o->error, p.error); append(o->cigar, p.cigar);
     }
     return o;
 }
@@ -488,21 +573,22 @@ int64_t vc_io_load(vc_wb* wb, const vc_seqset* targets, const vc_seqset* reads, 
                    int* window_type, char* err, uint64_t err_cap) {
     auto fail = [&](const std::string& m) -> int64_t { if (err && err_cap) { snprintf(err, (size_t)err_cap, "%s", m.c_str()); } return -1; };
     if (!wb || !targets || !reads || !ovl) return fail("null argument");
+    VC_IO_T0;
     if (targets->size() == 0) return fail("empty target sequences set");
     if (reads->size() == 0 && !allow_empty) return fail("empty sequences set");
-    auto add = [&](const vc_seqset* s, size_t i) -> int {
+    auto add = [&](const vc_seqset* s, size_t i) -> int {           // no copy: the record buffers outlive the builder (they are the caller's sets)
         const uint64_t o0 = s->data_off[i], len = s->data_off[i + 1] - o0;
-        const std::string nm = s->name(i);
-        return vc_wb_add_sequence(wb, nm.c_str(), s->data.data() + o0, (uint32_t)len, s->has_qual[i] ? s->qual.data() + o0 : nullptr);
+        return vc_wb_add_sequence_view(wb, s->names.data() + s->name_off[i], (uint32_t)(s->name_off[i + 1] - s->name_off[i]), s->data.data() + o0,
+                                       (uint32_t)len, s->has_qual[i] ? s->qual.data() + o0 : nullptr);
     };
     std::unordered_map<std::string, uint32_t> t_id, q_id;
     t_id.reserve(targets->size() * 2); q_id.reserve(reads->size() * 2);
-    std::vector<uint32_t> t_ids(targets->size()), q_ids(reads->size());
+    std::unordered_map<uint32_t, size_t> t_rec;      // builder id of a target -> its record
     for (size_t i = 0; i < targets->size(); ++i) {
         const int id = add(targets, i);
         if (id < 0) return fail("empty sequence");
-        t_ids[i] = (uint32_t)id;
         t_id[targets->name(i)] = (uint32_t)id;       // (a repeated name: the last record wins, as a dict does)
+        t_rec[(uint32_t)id] = i;
     }
     unsigned long long total = 0;
     for (size_t i = 0; i < reads->size(); ++i) {
@@ -511,21 +597,22 @@ int64_t vc_io_load(vc_wb* wb, const vc_seqset* targets, const vc_seqset* reads, 
         const std::string nm = reads->name(i);
         auto it = t_id.find(nm);
         if (it != t_id.end()) {                      // a read that is also a target shares its record (polisher.cpp:262-283)
-            // the target record with that id
-            size_t ti = 0;
-            for (; ti < t_ids.size(); ++ti) if (t_ids[ti] == it->second) break;
+            const size_t ti = t_rec[it->second];
             const uint64_t tlen = targets->data_off[ti + 1] - targets->data_off[ti];
             const uint64_t tq = targets->has_qual[ti] ? tlen : 0, rq = reads->has_qual[i] ? len : 0;
             if (tlen != len || tq != rq) return fail("duplicate sequence " + nm + " with unequal data");
-            q_ids[i] = it->second; q_id[nm] = it->second;
+            q_id[nm] = it->second;
         } else {
             const int id = add(reads, i);
             if (id < 0) return fail("empty sequence");
-            q_ids[i] = (uint32_t)id; q_id[nm] = (uint32_t)id;
+            q_id[nm] = (uint32_t)id;
         }
     }
     if (vc_wb_set_targets(wb, (uint32_t)targets->size()) != VC_OK) return fail("vc_wb_set_targets failed");
-    int64_t kept = 0;
+    VC_IO_TICK("sequences");
+    std::vector<uint32_t> oq, ot, oqb, oqe, oql, otb, ote;
+    std::vector<uint8_t> ost;
+    std::vector<const char*> ocg;
     for (size_t k = 0; k < ovl->size(); ++k) {
         uint32_t q, t;
         if (ovl->by_index[k]) {                      // MHAP: positions in the reads / targets files (overlap.cpp:129-166)
@@ -542,11 +629,15 @@ int64_t vc_io_load(vc_wb* wb, const vc_seqset* targets, const vc_seqset* reads, 
         }
         if (ovl->dropped[k] || ovl->error[k] > error_threshold || q == t) continue;
         if (!ovl->has_cigar[k]) return fail("overlap without a CIGAR: align it first (vc_align / vc_ovlset_set_cigar)");
-        if (vc_wb_add_overlap(wb, q, t, ovl->strand[k], ovl->q_begin[k], ovl->q_end[k], ovl->q_length[k], ovl->t_begin[k], ovl->t_end[k],
-                              ovl->cigar[k].c_str()) != VC_OK)
-            return fail(vc_wb_last_error(wb));
-        ++kept;
+        oq.push_back(q); ot.push_back(t); ost.push_back(ovl->strand[k]); oqb.push_back(ovl->q_begin[k]); oqe.push_back(ovl->q_end[k]);
+        oql.push_back(ovl->q_length[k]); otb.push_back(ovl->t_begin[k]); ote.push_back(ovl->t_end[k]); ocg.push_back(ovl->cigar[k].c_str());
     }
+    VC_IO_TICK("resolve");
+    const int64_t kept = (int64_t)oq.size();
+    if (kept && vc_wb_add_overlaps(wb, (uint64_t)kept, oq.data(), ot.data(), ost.data(), oqb.data(), oqe.data(), oql.data(), otb.data(), ote.data(),
+                                   ocg.data()) != VC_OK)
+        return fail(vc_wb_last_error(wb));
+    VC_IO_TICK("overlaps");
     if (kept == 0 && !allow_empty) return fail("empty overlap set");
     if (window_type) *window_type = (double)total / (double)std::max<size_t>(reads->size(), 1) <= 1000 ? 0 : 1;
     return kept;

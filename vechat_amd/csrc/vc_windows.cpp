@@ -18,14 +18,22 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
+
+#include <sched.h>
 
 namespace {
 
 struct Seq {
-    std::string name, data, qual, rc, rq;          // rc / rq built on demand (sequence.cpp:50-83)
+    std::string name;
+    const char* d = nullptr; const char* q = nullptr; size_t n = 0;   // bases / quality (nullptr: none): a view ...
+    std::vector<char> data, qual;                  // ... of these when the sequence was added by copy (vc_wb_add_sequence; a moved
+                                                   //     vector keeps its heap buffer, so the views survive the table's growth)
+    std::string rc, rq;                            // built on demand (sequence.cpp:50-83)
 };
 
 struct Ovl {
@@ -63,18 +71,37 @@ namespace {
 int fail(vc_wb* b, const char* msg) { b->err = msg; return VC_ERR_ARG; }
 
 void make_reverse(Seq& s) {
-    if (!s.rc.empty() || s.data.empty()) return;
-    s.rc.reserve(s.data.size());
-    for (size_t i = s.data.size(); i-- > 0;) {
-        switch (s.data[i]) {
-            case 'A': s.rc += 'T'; break;
-            case 'T': s.rc += 'A'; break;
-            case 'C': s.rc += 'G'; break;
-            case 'G': s.rc += 'C'; break;
-            default:  s.rc += s.data[i]; break;
-        }
+    if (!s.rc.empty() || s.n == 0) return;
+    s.rc.resize(s.n);
+    for (size_t i = 0; i < s.n; ++i) {
+        const char c = s.d[s.n - 1 - i];
+        s.rc[i] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
     }
-    s.rq.assign(s.qual.rbegin(), s.qual.rend());
+    if (s.q) s.rq.assign(std::reverse_iterator<const char*>(s.q + s.n), std::reverse_iterator<const char*>(s.q));
+}
+
+unsigned wb_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (const char* e = getenv("VC_IO_THREADS")) n = (unsigned)std::max(1, atoi(e));
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<unsigned>(n, (unsigned)CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                 // a container may see 256 cores and own 16
+        char q[32]; long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1L, atol(q) / period));
+        fclose(f);
+    }
+    return std::max(1u, std::min(n, 32u));
+}
+
+// fn(k) for k in [0, n), on several threads when there is enough to do (contiguous ranges: results keep their order)
+template <typename F>
+void parallel_for(size_t n, size_t min_per_thread, F fn) {
+    const size_t T = std::min<size_t>(wb_threads(), std::max<size_t>(1, n / std::max<size_t>(1, min_per_thread)));
+    if (T <= 1) { for (size_t k = 0; k < n; ++k) fn(k); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; ++t)
+        th.emplace_back([=]() { for (size_t k = n * t / T; k < n * (t + 1) / T; ++k) fn(k); });
+    for (auto& x : th) x.join();
 }
 
 // Breaking points of an overlap from its CIGAR (what src/overlap.cpp:222-292 computes base by base): for every
@@ -114,9 +141,11 @@ bool breaking_points_from_cigar(Ovl& o, const char* cigar, uint32_t window_lengt
             if (w < ends.size() && tpos == ends[w]) close_window();
         }
     };
+    o.bp.reserve(2 * ends.size());
     for (const char* p = cigar; *p;) {
-        char* e = nullptr;
-        const uint64_t len = std::strtoull(p, &e, 10);
+        const char* e = p;
+        uint64_t len = 0;
+        while (*e >= '0' && *e <= '9') { len = len * 10 + (uint64_t)(*e - '0'); ++e; }
         if (e == p || !*e) break;                        // no run length / no operation: stop like atoi-driven parsing would
         switch (*e) {
             case 'M': case '=': case 'X': advance(len, true); break;
@@ -148,11 +177,23 @@ const char* vc_wb_last_error(const vc_wb* b) { return b ? b->err.c_str() : "null
 
 int vc_wb_add_sequence(vc_wb* b, const char* name, const char* data, uint32_t length, const char* quality) {
     if (!b || !data || length == 0) return -1;
-    Seq s;
+    b->seqs.emplace_back();
+    Seq& s = b->seqs.back();
     s.name = name ? name : "";
-    s.data.assign(data, length);
-    if (quality) s.qual.assign(quality, length);
-    b->seqs.emplace_back(std::move(s));
+    s.data.assign(data, data + length);
+    if (quality) s.qual.assign(quality, quality + length);
+    s.d = s.data.data(); s.q = quality ? s.qual.data() : nullptr; s.n = length;
+    return (int)b->seqs.size() - 1;
+}
+
+// the same without a copy: `data` / `quality` stay owned by the caller and must outlive the builder (vc_io_load hands in the
+// buffers of its vc_seqset)
+int vc_wb_add_sequence_view(vc_wb* b, const char* name, uint32_t name_len, const char* data, uint32_t length, const char* quality) {
+    if (!b || !data || length == 0) return -1;
+    b->seqs.emplace_back();
+    Seq& s = b->seqs.back();
+    s.name.assign(name ? name : "", name ? name_len : 0);
+    s.d = data; s.q = quality; s.n = length;
     return (int)b->seqs.size() - 1;
 }
 
@@ -162,18 +203,39 @@ int vc_wb_set_targets(vc_wb* b, uint32_t n_targets) {
     return VC_OK;
 }
 
+namespace {
+// the checks of one overlap record (overlap.cpp:139-146,161-167) and its breaking points; nullptr or the complaint
+const char* make_overlap(const vc_wb* b, Ovl& o, const char* cigar) {
+    if (o.q_id >= b->seqs.size() || o.t_id >= b->n_targets) return "overlap refers to an unknown sequence";
+    if (o.q_length != b->seqs[o.q_id].n) return "unequal lengths in sequence and overlap record";
+    if (o.q_begin > o.q_end || o.q_end > o.q_length || o.t_begin > o.t_end || o.t_end > b->seqs[o.t_id].n) return "overlap coordinates out of range";
+    if (!breaking_points_from_cigar(o, cigar, b->window_length)) return "CIGAR does not match the overlap's query / target spans";
+    return nullptr;
+}
+}  // namespace
+
 int vc_wb_add_overlap(vc_wb* b, uint32_t q_id, uint32_t t_id, int strand, uint32_t q_begin, uint32_t q_end,
                       uint32_t q_length, uint32_t t_begin, uint32_t t_end, const char* cigar) {
     if (!b || !cigar) return VC_ERR_ARG;
-    if (q_id >= b->seqs.size() || t_id >= b->n_targets) return fail(b, "overlap refers to an unknown sequence");
-    // overlap.cpp:139-146,161-167: the lengths in the overlap record must match the sequences
-    if (q_length != b->seqs[q_id].data.size()) return fail(b, "unequal lengths in sequence and overlap record");
-    if (q_begin > q_end || q_end > q_length || t_begin > t_end || t_end > b->seqs[t_id].data.size())
-        return fail(b, "overlap coordinates out of range");
     Ovl o{q_id, t_id, q_begin, q_end, q_length, t_begin, t_end, strand ? 1 : 0, {}};
-    if (!breaking_points_from_cigar(o, cigar, b->window_length))
-        return fail(b, "CIGAR does not match the overlap's query / target spans");
+    if (const char* m = make_overlap(b, o, cigar)) return fail(b, m);
     b->ovls.emplace_back(std::move(o));
+    return VC_OK;
+}
+
+// n overlaps at once, in the order given (the breaking points of different overlaps are independent: several threads)
+int vc_wb_add_overlaps(vc_wb* b, uint64_t n, const uint32_t* q_id, const uint32_t* t_id, const uint8_t* strand, const uint32_t* q_begin,
+                       const uint32_t* q_end, const uint32_t* q_length, const uint32_t* t_begin, const uint32_t* t_end, const char* const* cigar) {
+    if (!b || (n && (!q_id || !t_id || !strand || !q_begin || !q_end || !q_length || !t_begin || !t_end || !cigar))) return VC_ERR_ARG;
+    const size_t base = b->ovls.size();
+    b->ovls.resize(base + n);
+    std::vector<const char*> msg(n, nullptr);
+    parallel_for(n, 256, [&](size_t k) {
+        Ovl& o = b->ovls[base + k];
+        o = Ovl{q_id[k], t_id[k], q_begin[k], q_end[k], q_length[k], t_begin[k], t_end[k], strand[k] ? 1 : 0, {}};
+        msg[k] = cigar[k] ? make_overlap(b, o, cigar[k]) : "overlap without a CIGAR";
+    });
+    for (size_t k = 0; k < n; ++k) if (msg[k]) { b->ovls.resize(base); return fail(b, msg[k]); }
     return VC_OK;
 }
 
@@ -194,23 +256,32 @@ int vc_wb_build(vc_wb* b, vc_batch* out) {
     // polisher.cpp:389-404: windows of every target in order
     std::vector<uint64_t> first_window(b->n_targets + 1, 0);
     for (uint32_t t = 0; t < b->n_targets; ++t) {
-        const uint32_t len = (uint32_t)b->seqs[t].data.size();
+        const uint32_t len = (uint32_t)b->seqs[t].n;
         uint32_t k = 0;
         for (uint32_t j = 0; j < len; j += W, ++k) b->wins.push_back(Win{t, k, j, std::min(j + W, len) - j, {}});
         first_window[t + 1] = first_window[t] + k;
     }
     b->coverage.assign(b->n_targets, 0);
-    // polisher.cpp:408-459: layers, in overlap order
-    for (auto& o : b->ovls) {
-        ++b->coverage[o.t_id];
-        Seq& s = b->seqs[o.q_id];
-        if (o.strand) make_reverse(s);
+    // reverse complements of the reads some overlap needs on the other strand (sequence.cpp:50-83), each made once
+    {
+        std::vector<uint32_t> need;
+        std::vector<uint8_t> mark(b->seqs.size(), 0);
+        for (const auto& o : b->ovls) if (o.strand && !mark[o.q_id]) { mark[o.q_id] = 1; need.push_back(o.q_id); }
+        parallel_for(need.size(), 16, [&](size_t k) { make_reverse(b->seqs[need[k]]); });
+    }
+    // polisher.cpp:408-459: the layers every overlap contributes (independent of each other: several threads) ...
+    struct Made { uint64_t wid; Layer l; };
+    std::vector<std::vector<Made>> made(b->ovls.size());
+    std::vector<const char*> msg(b->ovls.size(), nullptr);
+    parallel_for(b->ovls.size(), 64, [&](size_t oi) {
+        const Ovl& o = b->ovls[oi];
+        const Seq& s = b->seqs[o.q_id];
         for (size_t j = 0; j + 1 < o.bp.size(); j += 2) {
             const uint32_t q0 = o.bp[j].second, q1 = o.bp[j + 1].second;
-            if (q1 < q0 || q1 > b->seqs[o.q_id].data.size()) return fail(b, "breaking point beyond the end of the read");
+            if (q1 < q0 || q1 > s.n) { msg[oi] = "breaking point beyond the end of the read"; return; }
             if ((double)(q1 - q0) < 0.02 * W) continue;                                   // :416
-            if (!s.qual.empty()) {                                                        // :420-434
-                const std::string& q = o.strand ? s.rq : s.qual;
+            if (s.q) {                                                                    // :420-434
+                const char* q = o.strand ? s.rq.data() : s.q;
                 double average_quality = 0;
                 for (uint32_t k = q0; k < q1; ++k) average_quality += (uint32_t)(uint8_t)q[k] - 33;
                 average_quality /= q1 - q0;
@@ -219,58 +290,78 @@ int vc_wb_build(vc_wb* b, vc_batch* out) {
             const uint64_t wid = first_window[o.t_id] + o.bp[j].first / W;                // :436-439
             const uint32_t wstart = (o.bp[j].first / W) * W;
             const uint32_t begin = o.bp[j].first - wstart, end = o.bp[j + 1].first - wstart - 1;
-            Win& win = b->wins[wid];
+            const Win& win = b->wins[wid];
             // window.cpp:47-72 (add_layer): empty or single-column layers are dropped, bad positions are fatal
             if (q1 == q0 || begin == end) continue;
-            if (begin >= end || begin > win.length || end > win.length) return fail(b, "layer begin and end positions are invalid");
-            win.layers.push_back(Layer{o.q_id, o.strand, q0, q1, begin, end});
+            if (begin >= end || begin > win.length || end > win.length) { msg[oi] = "layer begin and end positions are invalid"; return; }
+            made[oi].push_back(Made{wid, Layer{o.q_id, o.strand, q0, q1, begin, end}});
         }
+    });
+    // ... appended to their windows in overlap order
+    for (size_t oi = 0; oi < b->ovls.size(); ++oi) {
+        if (msg[oi]) return fail(b, msg[oi]);
+        ++b->coverage[b->ovls[oi].t_id];
+        for (const Made& m : made[oi]) b->wins[m.wid].layers.push_back(m.l);
     }
-    // flatten, layers in the reference's rank order (window.cpp:203-210 via vc_rank_layers)
+    // flatten, layers in the reference's rank order (window.cpp:203-210 via vc_rank_layers): sizes first, then the bytes of the
+    // windows side by side
     auto& B = *b;
-    B.win_seq_off.assign(1, 0); B.seq_off.assign(1, 0);
-    B.seq_begin.clear(); B.seq_end.clear(); B.seq_has_qual.clear(); B.bases.clear(); B.quals.clear(); B.win_fasta.clear(); B.seq_orig.clear();
-    std::vector<uint32_t> begins, rank;
-    for (const Win& win : b->wins) {
+    const size_t nw = b->wins.size();
+    std::vector<uint64_t> wbytes(nw + 1, 0), wseqs(nw + 1, 0);
+    for (size_t w = 0; w < nw; ++w) {
+        const Win& win = b->wins[w];
+        uint64_t by = win.length;
+        for (const Layer& l : win.layers) by += l.q1 - l.q0;
+        wbytes[w + 1] = wbytes[w] + by;
+        wseqs[w + 1] = wseqs[w] + win.layers.size() + 1;
+    }
+    const uint64_t ns = wseqs[nw], nb = wbytes[nw];
+    B.win_seq_off.assign(nw + 1, 0); B.seq_off.assign(ns + 1, 0);
+    B.seq_begin.assign(ns, 0); B.seq_end.assign(ns, 0); B.seq_has_qual.assign(ns, 0); B.seq_orig.assign(ns, 0);
+    B.bases.resize(nb); B.quals.resize(nb); B.win_fasta.assign(nw, 0);
+    for (size_t w = 0; w <= nw; ++w) B.win_seq_off[w] = (uint32_t)wseqs[w];
+    B.seq_off[ns] = nb;
+    parallel_for(nw, 8, [&](size_t w) {
+        const Win& win = b->wins[w];
         const Seq& t = b->seqs[win.target];
         const uint32_t n = (uint32_t)win.layers.size() + 1;
-        begins.assign(n, 0);
+        std::vector<uint32_t> begins(n, 0), rank(n);
         for (uint32_t i = 1; i < n; ++i) begins[i] = win.layers[i - 1].begin;
-        rank.resize(n);
         vc_rank_layers(begins.data(), n, rank.data());
         // window.cpp:223 on the pointers polisher.cpp:397-400 hands over: a FASTA target gets the shared
         // dummy string of window_length '!' (equal only for a full-length window); a FASTQ target gets a
         // pointer into its own quality string, whose C-string runs to the end of that read
         bool fasta;
-        if (t.qual.empty()) fasta = win.length == W;
+        if (!t.q) fasta = win.length == W;
         else {
-            fasta = win.start + win.length == t.qual.size();
-            for (uint32_t i = 0; fasta && i < win.length; ++i) fasta = t.qual[win.start + i] == '!';
+            fasta = win.start + win.length == t.n;
+            for (uint32_t i = 0; fasta && i < win.length; ++i) fasta = t.q[win.start + i] == '!';
         }
-        B.win_fasta.push_back(fasta ? 1 : 0);
-        for (uint32_t k = 0; k < n; ++k) {
+        B.win_fasta[w] = fasta ? 1 : 0;
+        uint64_t off = wbytes[w], si = wseqs[w];
+        for (uint32_t k = 0; k < n; ++k, ++si) {
             const uint32_t i = rank[k];
-            B.seq_orig.push_back(i);
+            B.seq_orig[si] = i;
+            B.seq_off[si] = off;
             if (i == 0) {
-                B.bases.insert(B.bases.end(), t.data.begin() + win.start, t.data.begin() + win.start + win.length);
-                if (t.qual.empty()) B.quals.insert(B.quals.end(), win.length, (uint8_t)'!');
-                else B.quals.insert(B.quals.end(), t.qual.begin() + win.start, t.qual.begin() + win.start + win.length);
-                B.seq_begin.push_back(0); B.seq_end.push_back(0); B.seq_has_qual.push_back(1);
-                B.seq_off.push_back(B.seq_off.back() + win.length);
+                std::memcpy(B.bases.data() + off, t.d + win.start, win.length);
+                if (!t.q) std::memset(B.quals.data() + off, '!', win.length);
+                else std::memcpy(B.quals.data() + off, t.q + win.start, win.length);
+                B.seq_has_qual[si] = 1;
+                off += win.length;
             } else {
                 const Layer& l = win.layers[i - 1];
                 const Seq& s = b->seqs[l.q_id];
-                const std::string& d = l.strand ? s.rc : s.data;
-                B.bases.insert(B.bases.end(), d.begin() + l.q0, d.begin() + l.q1);
-                if (s.qual.empty()) B.quals.insert(B.quals.end(), l.q1 - l.q0, (uint8_t)'!');
-                else { const std::string& q = l.strand ? s.rq : s.qual; B.quals.insert(B.quals.end(), q.begin() + l.q0, q.begin() + l.q1); }
-                B.seq_begin.push_back(l.begin); B.seq_end.push_back(l.end); B.seq_has_qual.push_back(s.qual.empty() ? 0 : 1);
-                B.seq_off.push_back(B.seq_off.back() + (l.q1 - l.q0));
+                const uint32_t len = l.q1 - l.q0;
+                std::memcpy(B.bases.data() + off, (l.strand ? s.rc.data() : s.d) + l.q0, len);
+                if (!s.q) std::memset(B.quals.data() + off, '!', len);
+                else std::memcpy(B.quals.data() + off, (l.strand ? s.rq.data() : s.q) + l.q0, len);
+                B.seq_begin[si] = l.begin; B.seq_end[si] = l.end; B.seq_has_qual[si] = s.q ? 1 : 0;
+                off += len;
             }
         }
-        B.win_seq_off.push_back((uint32_t)B.seq_begin.size());
-    }
-    out->n_windows = (uint32_t)b->wins.size();
+    });
+    out->n_windows = (uint32_t)nw;
     out->win_seq_off = B.win_seq_off.data(); out->seq_off = B.seq_off.data();
     out->seq_begin = B.seq_begin.data(); out->seq_end = B.seq_end.data(); out->seq_has_qual = B.seq_has_qual.data();
     out->bases = B.bases.data(); out->quals = B.quals.data(); out->win_fasta = B.win_fasta.data();
@@ -280,6 +371,11 @@ int vc_wb_build(vc_wb* b, vc_batch* out) {
 const uint32_t* vc_wb_seq_orig(const vc_wb* b) { return b ? b->seq_orig.data() : nullptr; }
 uint32_t vc_wb_n_windows(const vc_wb* b) { return b ? (uint32_t)b->wins.size() : 0; }
 uint32_t vc_wb_window_target(const vc_wb* b, uint32_t w) { return b && w < b->wins.size() ? b->wins[w].target : 0; }
+// (target, rank) of every window of the last build at once
+void vc_wb_window_ids(const vc_wb* b, uint32_t* target, uint32_t* rank) {
+    if (!b) return;
+    for (size_t w = 0; w < b->wins.size(); ++w) { if (target) target[w] = b->wins[w].target; if (rank) rank[w] = b->wins[w].rank; }
+}
 uint32_t vc_wb_window_rank(const vc_wb* b, uint32_t w) { return b && w < b->wins.size() ? b->wins[w].rank : 0; }
 
 // polisher.cpp:520-547.  status[w] == VC_WIN_OK counts as polished; anything above VC_WIN_UNPOLISHED is an error

@@ -20,7 +20,8 @@ import numpy as np
 
 from . import capi
 from .engine import HipContext
-from .seqio import align_missing, load_polisher_input, read_overlaps, read_sequences, sequence_index
+from .seqio import (NativeOverlaps, NativeSequences, align_missing, align_missing_native, load_polisher_input, load_polisher_input_native,
+                    native_parsers, read_inputs_native, read_overlaps, read_sequences, sequence_index)
 from .windows import WindowBuilder
 
 
@@ -73,18 +74,30 @@ def main(argv=None):
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     distributed = world > 1 or os.environ.get("VC_FORCE_DIST") == "1"
     device = int(os.environ.get("LOCAL_RANK", a.device)) if distributed else a.device
-    overlaps = read_overlaps(a.overlaps)
+    # One process: the C++ readers behind the C ABI (vc_io_read_sequences / vc_io_read_overlaps / vc_io_load) hold the records and
+    # feed the window builder directly.  A rank of a multi-GPU run plans on names and lengths and filters by target first: that
+    # path (and VC_PY_PARSERS=1) goes through the Python readers, which give the same records (tests/test_seqio.py).
+    native = native_parsers() and not distributed
+    native_targets = None
+    if native:
+        native_reads, overlaps, native_targets = read_inputs_native(a.sequences, a.overlaps, a.targets)
+    else:
+        overlaps = read_overlaps(a.overlaps)
     # window type comes from the mean length of ALL reads (polisher.cpp:300-306).  One process reads the file once and keeps
     # the records; a rank of a multi-GPU run only needs names and lengths here and loads its own share of the reads below
     all_reads = None
     if distributed:
         r_index = sequence_index(a.sequences)
+        lengths = [l for _, l in r_index]
+    elif native:
+        all_reads = native_reads
+        lengths = all_reads.lengths
     else:
         all_reads = read_sequences(a.sequences)
-        r_index = [(n, len(d)) for n, d, _ in all_reads]
-    if not r_index:
+        lengths = [len(d) for _, d, _ in all_reads]
+    if not len(lengths):
         raise ValueError("empty sequences set")
-    window_type = 0 if sum(l for _, l in r_index) / float(len(r_index)) <= 1000 else 1
+    window_type = 0 if float(sum(int(x) for x in lengths)) / float(len(lengths)) <= 1000 else 1
     keep_t = keep_r = None
     if distributed:
         import torch
@@ -107,21 +120,27 @@ def main(argv=None):
     n_targets = n_windows = n_polished = kept = n_aligned = 0
     failure = None                                                # (exit code, message): reported by every rank through the collective below
     try:
-        targets = read_sequences(a.targets, keep_t)
+        targets = native_targets if native else read_sequences(a.targets, keep_t)
         reads = all_reads if all_reads is not None else read_sequences(a.sequences, keep_r)
         n_targets = len(targets)
-        if not distributed and not (targets and reads and overlaps):
+        if not distributed and not (len(targets) and len(reads) and len(overlaps)):
             raise ValueError("empty overlap set")
-        if targets:
+        if len(targets):
             wb = WindowBuilder(a.window_length, a.quality_threshold)
-            if reads and overlaps:
-                n_aligned = align_missing(targets, reads, overlaps, a.error_threshold, device)   # PAF / MHAP without a CIGAR (overlap.cpp:205-220)
-            # A rank of a multi-GPU run may own targets that keep no overlap at all (skewed input, the round-2 filters).  The
-            # reference builds windows for EVERY target (polisher.cpp:389-411), so such targets still come out -- unpolished,
-            # i.e. only with -u -- exactly as the single-rank run emits them.
-            kept, _ = load_polisher_input(wb, targets, reads, overlaps, a.error_threshold, allow_empty=distributed)
+            if native:
+                n_aligned = align_missing_native(targets, reads, overlaps, a.error_threshold, device)
+                kept, _ = load_polisher_input_native(wb, targets, reads, overlaps, a.error_threshold)
+                target_name = None
+            else:
+                if reads and overlaps:
+                    n_aligned = align_missing(targets, reads, overlaps, a.error_threshold, device)   # PAF / MHAP without a CIGAR (overlap.cpp:205-220)
+                # A rank of a multi-GPU run may own targets that keep no overlap at all (skewed input, the round-2 filters).  The
+                # reference builds windows for EVERY target (polisher.cpp:389-411), so such targets still come out -- unpolished,
+                # i.e. only with -u -- exactly as the single-rank run emits them.
+                kept, _ = load_polisher_input(wb, targets, reads, overlaps, a.error_threshold, allow_empty=distributed)
+                target_name = lambda t: targets[t][0]
             if kept or a.include_unpolished:
-                batch, ids = wb.build()
+                batch, ids = wb.build(copy=False)              # (the builder lives until the text is stitched)
                 ctx = HipContext(device=device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
                                  num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
                                  window_type=window_type, max_nodes=a.max_nodes, n_streams=a.streams)
@@ -134,7 +153,10 @@ def main(argv=None):
                 # --keep-going asks for their backbones to be kept as unpolished stretches.
                 bad = [w for w in range(batch.n_windows) if int(status[w]) > capi.VC_WIN_UNPOLISHED]
                 if bad:
-                    names = ", ".join(f"target {targets[ids[w][0]][0]} window {ids[w][1]} (status {int(status[w])})" for w in bad[:8])
+                    if target_name is None:
+                        tn = targets.names()
+                        target_name = lambda t: tn[t]
+                    names = ", ".join(f"target {target_name(ids[w][0])} window {ids[w][1]} (status {int(status[w])})" for w in bad[:8])
                     msg = f"{len(bad)} window(s) could not be computed on the device: {names}{' ...' if len(bad) > 8 else ''}"
                     if not a.keep_going:
                         raise DeviceWindowError(msg + "; rerun with --keep-going to emit them unpolished")

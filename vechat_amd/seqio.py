@@ -14,7 +14,9 @@ read_sequences is pinned against the reference's own bioparser + racon::Sequence
 place; tests/test_seqio.py).  The overlap readers are unpinned restatements (src/overlap.cpp needs edlib.h, which is
 not in the tree).
 """
+import ctypes as C
 import gzip
+import os
 import re
 
 import numpy as np
@@ -268,3 +270,160 @@ def load_polisher_input(builder, targets, reads, overlaps, error_threshold=0.3, 
     if kept == 0 and not allow_empty:
         raise ValueError("empty overlap set")
     return kept, 0 if total / float(max(len(reads), 1)) <= 1000 else 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The same layer in C++ behind the C ABI (vechat_amd/csrc/vc_io.cpp: vc_io_read_sequences / vc_io_read_overlaps / vc_io_load):
+# what `python -m vechat_amd.polish` uses.  The Python functions above stay as the independent restatement the tests compare
+# it with (and serve the multi-rank path, which plans on names and lengths).  VC_PY_PARSERS=1 selects them everywhere.
+# ---------------------------------------------------------------------------------------------------------------------------
+def native_parsers():
+    return os.environ.get("VC_PY_PARSERS") != "1"
+
+
+class NativeSequences:
+    """The records of one FASTA / FASTQ(.gz) file, held by the library (vc_seqset)."""
+
+    def __init__(self, path, keep=None, names_only=False, lib=None):
+        from . import capi
+        self.lib = lib or capi.load_host()
+        kn = None if keep is None else "\n".join(sorted(keep)).encode()
+        self.h = self.lib.vc_io_read_sequences(os.fsencode(str(path)), kn, 1 if names_only else 0)
+        err = self.lib.vc_seqset_error(self.h)
+        if err:
+            msg = err.decode()
+            self.close()
+            raise ValueError(msg)
+        self.n = int(self.lib.vc_seqset_size(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vc_seqset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __len__(self):
+        return self.n
+
+    def _arr(self, fn, k):
+        return np.ctypeslib.as_array(fn(self.h), shape=(max(k, 1),))[:k]
+
+    @property
+    def lengths(self):
+        return self._arr(self.lib.vc_seqset_lengths, self.n).copy()
+
+    def names(self):
+        off = self._arr(self.lib.vc_seqset_name_off, self.n + 1)
+        blob = C.string_at(self.lib.vc_seqset_names(self.h), int(off[-1])) if self.n else b""
+        return [blob[int(off[i]):int(off[i + 1])].decode() for i in range(self.n)]
+
+    def index(self):
+        return list(zip(self.names(), (int(x) for x in self.lengths)))
+
+    def records(self):
+        """[(name, data, quality|None)] -- the Python readers' shape (tests, small inputs)."""
+        names = self.names()
+        off = self._arr(self.lib.vc_seqset_data_off, self.n + 1)
+        tot = int(off[-1]) if self.n else 0
+        data = C.string_at(self.lib.vc_seqset_data(self.h), tot) if tot else b""
+        qp = self.lib.vc_seqset_qual(self.h)
+        qual = C.string_at(qp, tot) if (qp and tot) else None
+        hq = self._arr(self.lib.vc_seqset_has_qual, self.n)
+        return [(names[i], data[int(off[i]):int(off[i + 1])], qual[int(off[i]):int(off[i + 1])] if (qual is not None and hq[i]) else None)
+                for i in range(self.n)]
+
+
+class NativeOverlaps:
+    """The records of one MHAP / PAF / SAM(.gz) file, held by the library (vc_ovlset)."""
+
+    def __init__(self, path, lib=None):
+        from . import capi
+        self.lib = lib or capi.load_host()
+        self.h = self.lib.vc_io_read_overlaps(os.fsencode(str(path)))
+        err = self.lib.vc_ovlset_error(self.h)
+        if err:
+            msg = err.decode()
+            self.close()
+            raise ValueError(msg)
+        self.n = int(self.lib.vc_ovlset_size(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vc_ovlset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __len__(self):
+        return self.n
+
+    def get(self, i):
+        from . import capi
+        r = capi.VcOverlapRec()
+        if self.lib.vc_ovlset_get(self.h, i, C.byref(r)) != 0:
+            raise IndexError(i)
+        if r.by_index:
+            qn, tn = f"#{r.q_index}", f"#{r.t_index}"
+        else:
+            qn, tn = C.string_at(r.q_name, r.q_name_len).decode(), C.string_at(r.t_name, r.t_name_len).decode()
+        return Overlap(q_name=qn, t_name=tn, strand=bool(r.strand), q_begin=r.q_begin, q_end=r.q_end, q_length=r.q_length, t_begin=r.t_begin,
+                       t_end=r.t_end, cigar=None if r.cigar is None else r.cigar.decode(), error=2.0 if r.dropped else r.error, length=r.length)
+
+    def records(self):
+        return [self.get(i) for i in range(self.n)]
+
+    def set_cigar(self, i, cigar):
+        self.lib.vc_ovlset_set_cigar(self.h, i, None if cigar is None else cigar.encode())
+
+
+def align_missing_native(targets, reads, overlaps, error_threshold=0.3, device=0):
+    """align_missing() for the library-held records: every overlap without a CIGAR that load would keep is aligned on the device."""
+    todo = [(i, o) for i, o in ((i, overlaps.get(i)) for i in range(len(overlaps))) if o.cigar is None]
+    if not todo:
+        return 0
+    from .align import align_pairs
+    trec, rrec = targets.records(), reads.records()
+    pseudo = [o for _, o in todo]
+    _resolve_indices(trec, rrec, pseudo)
+    seq = {n: d for n, d, _ in rrec}
+    tgt = {n: d for n, d, _ in trec}
+    sel = [(i, o) for i, o in todo if o.q_name in seq and o.t_name in tgt and o.error <= error_threshold and o.q_name != o.t_name]
+    pairs = []
+    for _, o in sel:
+        q = seq[o.q_name][o.q_begin:o.q_end]
+        pairs.append((q.translate(_COMP)[::-1] if o.strand else q, tgt[o.t_name][o.t_begin:o.t_end]))
+    cigars, dist = align_pairs(pairs, device=device)
+    n_ok = 0
+    for (i, _), cg, d in zip(sel, cigars, dist):
+        overlaps.set_cigar(i, cg if d >= 0 else None)          # beyond the aligner's envelope: dropped rather than guessed
+        n_ok += d >= 0
+    done = {i for i, _ in sel}
+    for i, _ in todo:
+        if i not in done:
+            overlaps.set_cigar(i, "")                          # load filters it out anyway (unknown names, error, self-overlap)
+    return n_ok
+
+
+def load_polisher_input_native(builder, targets, reads, overlaps, error_threshold=0.3, allow_empty=False):
+    """load_polisher_input() in the library (vc_io_load): (overlaps kept, window type)."""
+    wt = C.c_int(0)
+    err = C.create_string_buffer(512)
+    kept = builder.lib.vc_io_load(builder.h, targets.h, reads.h, overlaps.h, error_threshold, 1 if allow_empty else 0, C.byref(wt), err, 512)
+    if kept < 0:
+        raise ValueError(err.value.decode())
+    builder.n_overlaps += int(kept)
+    return int(kept), int(wt.value)
+
+
+def read_inputs_native(sequences, overlaps, targets):
+    """The three input files at once (the readers release the interpreter lock; each cuts its file into pieces for its own threads):
+    -> (NativeSequences reads, NativeOverlaps, NativeSequences targets)"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(3) as ex:
+        fo = ex.submit(NativeOverlaps, overlaps)
+        ft = ex.submit(NativeSequences, targets)
+        fr = ex.submit(NativeSequences, sequences)
+        return fr.result(), fo.result(), ft.result()

@@ -51,12 +51,16 @@ class WindowBuilder:
         self.lib.vc_wb_breaking_points(self.h, overlap, t, q)
         return [(int(t[i]), int(q[i])) for i in range(n)]
 
-    def build(self):
-        """-> capi.Batch of every window of every target, plus (target, rank) per window."""
+    def build(self, copy=True):
+        """-> capi.Batch of every window of every target, plus (target, rank) per window.  copy=False: the batch's arrays are
+        views of the builder's buffers (valid until the next build / close) -- half a gigabyte not copied for a large input."""
         vb = capi.VcBatch()
         self._check(self.lib.vc_wb_build(self.h, C.byref(vb)))
         n = int(vb.n_windows)
-        arr = lambda p, k, dt: np.ctypeslib.as_array(p, shape=(max(int(k), 1),))[:int(k)].astype(dt, copy=True)
+
+        def arr(p, k, dt):
+            a = np.ctypeslib.as_array(p, shape=(max(int(k), 1),))[:int(k)]
+            return a.astype(dt, copy=True) if copy else a
         wso = arr(vb.win_seq_off, n + 1, np.uint32)
         ns = int(wso[-1])
         so = arr(vb.seq_off, ns + 1, np.uint64)
@@ -64,7 +68,9 @@ class WindowBuilder:
         batch = capi.Batch(wso, so, arr(vb.seq_begin, ns, np.uint32), arr(vb.seq_end, ns, np.uint32),
                            arr(vb.seq_has_qual, ns, np.uint8), arr(vb.bases, nb, np.uint8), arr(vb.quals, nb, np.uint8),
                            arr(vb.win_fasta, n, np.uint8), arr(self.lib.vc_wb_seq_orig(self.h), ns, np.uint32))
-        ids = [(int(self.lib.vc_wb_window_target(self.h, w)), int(self.lib.vc_wb_window_rank(self.h, w))) for w in range(n)]
+        tg, rk = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+        self.lib.vc_wb_window_ids(self.h, tg.ctypes.data_as(C.POINTER(C.c_uint32)), rk.ctypes.data_as(C.POINTER(C.c_uint32)))
+        ids = list(zip(tg[:n].tolist(), rk[:n].tolist()))
         return batch, ids
 
     def stitch(self, consensus, status, drop_unpolished=True, fragment_correction=True):
