@@ -194,7 +194,7 @@ def files_to_fasta(params):
     with tempfile.TemporaryDirectory(prefix="vc_files_", dir="/tmp") as d:
         res = mod.main(nt=96, tl=10000, depth=64, out=d, python_too=True, quiet=True)
     batch, text = res.pop("batch"), res.pop("text")
-    res.pop("_keep", None)
+    keep = res.pop("_keep", None)                           # the batch is a view of the window builder's buffers: the builder stays until the end
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_api as oa
@@ -210,6 +210,7 @@ def files_to_fasta(params):
             res["reference_cpu"] = {"windows_per_s": len(ws) / dt, "cores": cores, "sample": f"{len(ws)} of the {batch.n_windows} windows these files make (window.cpp through oracle/_ref; parsing not included)"}
     except Exception as e:                                  # the checker leg must not take the bench line down
         res["reference_cpu"] = {"error": repr(e)}
+    del batch, keep
     return res
 
 

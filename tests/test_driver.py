@@ -241,3 +241,31 @@ def test_both_rounds_on_the_device(built, tmp_path):
     after = sum(_fit_distance(got[n], truth[n]) for n, _ in picks) / sum(len(got[n]) for n, _ in picks)
     assert all(len(got[n]) > 0.7 * len(truth[n]) for n, _ in picks)
     assert after * 3 < before, (before, after)               # ~10 % raw error rate
+
+
+@pytest.mark.gpu
+def test_two_rounds_on_the_device_match_the_reference(built, tmp_path):
+    """Row N4 as a parity test: tests/golden/two_rounds.json.gz (make_two_rounds.py) holds a read set, the overlaps an external
+    overlapper would deliver for round 1 and -- computed on the reference's round-1 result -- for round 2, and both rounds' FASTA
+    with every window's consensus taken from the reference itself (oracle/_ref: window.cpp, both overloads).  The driver runs the
+    two rounds through the real polisher on the device; the final text must be identical (it can only be if round 1 was, too:
+    round 2's overlaps address the reference's round-1 sequences base by base)."""
+    import gzip
+    fx = json.load(gzip.open(os.path.join(os.path.dirname(__file__), "golden", "two_rounds.json.gz"), "rt"))
+    reads = tmp_path / "reads.fastq"
+    reads.write_text(fx["reads_fastq"])
+    for k in ("round1_paf", "round2_paf"):
+        (tmp_path / (k + ".paf")).write_text(fx[k])
+    out = tmp_path / "out.fa"
+    rc = driver.main([str(reads), "-o", str(out), "--workdir", str(tmp_path / "work"),
+                      "--overlapper-r1", f"cp {tmp_path / 'round1_paf.paf'} {{out}}", "--overlapper-r2", f"cp {tmp_path / 'round2_paf.paf'} {{out}}"])
+    assert rc == 0
+    assert open(out).read() == fx["round2_fasta"]
+    # and the haplotype-aware round alone (--linear would be the other overload; here: one explicit polisher call on round 1)
+    from vechat_amd import polish
+    import io
+    import contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert polish.main(["-f", "-p", "-d", "0.2", "-s", "0.2", str(reads), str(tmp_path / "round1_paf.paf"), str(reads)]) == 0
+    assert buf.getvalue() == fx["round1_fasta"]
