@@ -126,6 +126,27 @@ def main():
             seqs.append((f"read{t}_{r}", data, qual))
             overlaps.append((len(seqs) - 1, t, int(strand), qb, qe, len(data), ta, tb, cigar))
 
+    # assembly edge cases (src/polisher.cpp:408-459, src/overlap.cpp:222-292), crafted rather than left to chance: overlaps that
+    # begin / end exactly on a window boundary, a reverse-strand read that ends with the target, a span that leaves less than
+    # 2 % of a window in its last window (that layer is dropped, :416), a low-quality read (mean quality < 10: dropped, :420-434),
+    # a read that covers one window only
+    for t, (hapA, hapB, target) in enumerate(truths):
+        def crafted(tag, ta, tb, strand, qual_lo=5, qual_hi=24, has_qual=True):
+            a = int(round(ta * len(hapA) / len(target))); b = int(round(tb * len(hapA) / len(target)))
+            piece = mutate(rng, hapA[a:b], 0.15)
+            cigar = nw_cigar(piece, target[ta:tb])
+            data = wr.revcomp(piece) if strand else piece
+            qual = bytes(rng.randint(33 + qual_lo, 33 + qual_hi) for _ in data) if has_qual else None
+            seqs.append((f"edge{t}_{tag}", data, qual))
+            overlaps.append((len(seqs) - 1, t, int(strand), 0, len(piece), len(data), ta, tb, cigar))
+        crafted("on_boundaries", W, 2 * W, False)                        # exactly one whole window
+        crafted("ends_on_boundary", 130, W, True)                        # reverse strand, last aligned base is the window's last
+        crafted("starts_on_boundary", W, W + 333, False)
+        crafted("rc_to_target_end", len(target) - 620, len(target), True)
+        crafted("sliver", 40, W + 6, False)                              # 6 bases into the second window: < 2 % of W, dropped there
+        crafted("low_quality", 100, 2 * W + 100, False, 1, 7)            # mean quality ~4 < 10
+        crafted("one_window_fasta", W + 20, 2 * W - 20, True, has_qual=False)
+
     wb = WindowBuilder(W, 10.0)
     for name, d, q in seqs:
         wb.add_sequence(name, d, q)
