@@ -324,6 +324,24 @@ def test_sequences_beyond_2048_columns_and_int32_scores(built):
     c.close()
 
 
+def test_a_layer_too_long_for_the_device_takes_only_its_window_out(built):
+    """a single ~38 k-base layer made vc_run fail for the whole batch (k_addaln's per-pair notes did not fit the LDS).
+    Such a window is now reported VC_WIN_OVERFLOW at submit and the rest of the batch is computed."""
+    good = capi.synth_batch(capi.synth_cfg(83, 300, 8), 0, 4)
+    wins = [good.window(w) for w in range(4)]
+    seqs, quals, b, e = wins[2]
+    huge = (seqs[1] * 200)[:40000]
+    wins[2] = (seqs[:2] + [huge] + seqs[2:], quals[:2] + [b"5" * len(huge)] + quals[2:], b[:2] + [0] + b[2:], e[:2] + [len(seqs[0]) - 1] + e[2:])
+    batch = capi.Batch.from_windows(wins, [int(good.win_fasta[w]) for w in range(4)])
+    c = HipContext(device=0)
+    cons, status = c.consensus(batch, retry_overflow=False)
+    ref, pol, _ = oa.oracle_run(good, c.params)
+    assert int(status[2]) == capi.VC_WIN_OVERFLOW and cons[2] == b""
+    for w in (0, 1, 3):
+        assert int(status[w]) == (capi.VC_WIN_OK if pol[w] else capi.VC_WIN_UNPOLISHED) and cons[w] == ref[w]
+    c.close()
+
+
 def test_overflow_is_reported_not_hidden(built):
     batch = capi.synth_batch(capi.synth_cfg(71, 200, 30), 0, 4)
     c = HipContext(device=0, max_nodes=256, max_edges=640)

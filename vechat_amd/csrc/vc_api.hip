@@ -320,7 +320,14 @@ int h2d(vc_ctx* c, void* dst, const void* src, size_t bytes) {
     while (off < bytes) {
         const size_t n = std::min(kStageBytes, bytes - off);
         HIPCHK(c, hipEventSynchronize(c->stage_ev[k]));                 // buffer k free again
-        std::memcpy(c->h_stage[k], (const char*)src + off, n);
+        {   // one thread copies ~6 GB/s, the link takes ten times that: the staging copy, not the DMA, was what a 1 GB submit waited for
+            const size_t T = n >= (8u << 20) ? 4 : 1;
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < T; ++t)
+                th.emplace_back([=]() { std::memcpy((char*)c->h_stage[k] + n * t / T, (const char*)src + off + n * t / T, n * (t + 1) / T - n * t / T); });
+            std::memcpy(c->h_stage[k], (const char*)src + off, n / T);
+            for (auto& x : th) x.join();
+        }
         HIPCHK(c, hipMemcpyAsync((char*)dst + off, c->h_stage[k], n, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipEventRecord(c->stage_ev[k], c->stream));
         off += n; k ^= 1;
@@ -951,6 +958,9 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     std::vector<uint8_t> layer_partial;
     std::vector<uint8_t> pre(nw, 0);          // windows outside the device envelope: reported, not run
     bool any_pre = false;
+    for (int pass = 0; pass < 2; ++pass) {
+    max_layers = max_len = max_nseq = max_backbone = 0; min_len = 0xFFFFFFFFu; need_nodes = 0; any_pre = false;
+    std::fill(layer_partial.begin(), layer_partial.end(), 0);
     for (uint32_t w = 0; w < nw; ++w) {
         const uint32_t s0 = hb->win_seq_off[w], s1 = hb->win_seq_off[w + 1];
         if (s1 <= s0) return fail(c, VC_ERR_ARG, "window %u has no backbone", w);
@@ -985,6 +995,18 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         const double depth = (double)(s1 - s0 - 1);
         const double est = depth > 0 ? 0.33 * ((double)sum / depth) * std::pow(depth, 0.55) : 0.0;
         need_nodes = std::max<uint64_t>(need_nodes, L + (uint64_t)std::ceil(est) + 64);
+    }
+    // k_addaln keeps two 16-bit notes per alignment pair in LDS (2 * PC + 2 * longest sequence bytes): a layer too long for that
+    // beside this batch's graph capacity takes ITS window out -- reported as VC_WIN_OVERFLOW like any other capacity limit --
+    // instead of failing the whole batch (one 38 k-base layer used to do that)
+    if (pass == 0) {
+        const uint64_t nc0 = c->prm.max_nodes ? c->prm.max_nodes : std::min<uint64_t>((need_nodes + 63) & ~63ull, 59968);
+        const int64_t allowed = ((int64_t)kLdsCap - 64 - 48 - 2 * (int64_t)std::max<uint64_t>(nc0, c->chunk_allocs.empty() ? 0 : c->NC)) / 4;
+        if ((int64_t)max_len <= allowed) break;
+        for (uint32_t w = 0; w < nw; ++w)
+            for (uint32_t q = hb->win_seq_off[w]; q < hb->win_seq_off[w + 1]; ++q)
+                if ((int64_t)(hb->seq_off[q + 1] - hb->seq_off[q]) > std::max<int64_t>(allowed, 0)) pre[w] = VC_WIN_OVERFLOW;
+    }
     }
     sync_ctx(c);                                          // only this context's streams: another context may be running
     c->have_batch = false; c->ran = false;
