@@ -524,7 +524,10 @@ struct VcOtf {
     uint32_t N, EC;
 };
 template <int U>
-__device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_t ring, uint32_t& ovf_base, int& bad, bool plain_frec) {
+__device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_t ring, uint32_t& ovf_base, int& bad, bool plain_frec,
+                                            uint32_t* s_keep = nullptr) {
+    // s_keep != nullptr (kept-row ring): mark, bit per row in LDS, the rows some row reads back at distance 2..64 -- the first pass
+    // of vc_frec_kept, done here where the distances are in registers anyway (that pass was a global load per row on a chain)
     // U blocks of 64 rows at once, level by level: every load of a level is issued before the first result is used, so a lane
     // has U (then 6 U) independent loads in flight instead of one chain
     const uint32_t lane = (uint32_t)vc_lane();
@@ -560,6 +563,7 @@ __device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_
                 const uint32_t delta = r[u] - pp[u][k];
                 dl[k] = (uint16_t)delta;
                 hasprev |= delta == 1;
+                if (s_keep && npu <= VC_INLINE_PRED && delta >= 2 && delta <= 64 && delta <= r[u]) atomicOr(&s_keep[(r[u] - delta) >> 5], 1u << ((r[u] - delta) & 31));
             }
         }
         const bool is_ovf = npu > VC_INLINE_PRED;
@@ -576,6 +580,7 @@ __device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_
                         const uint32_t delta = r[u] - o.pos[tn & 0xFFFF];
                         o.ovf[my_ovf + k] = (uint16_t)delta;
                         hasprev |= delta == 1;
+                        if (s_keep && delta >= 2 && delta <= 64 && delta <= r[u]) atomicOr(&s_keep[(r[u] - delta) >> 5], 1u << ((r[u] - delta) & 31));
                         k++;
                     }
                 }
@@ -612,15 +617,22 @@ __device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline uint32_t vc_kept_lds_bytes(uint32_t NC) { return 8u * (NC / 32 + 2) + 2u * (NC + 2) + 16u; }
 
-__device__ __forceinline__ void vc_frec_kept(const uint4* rec, uint4* frec, uint16_t* ovf, uint32_t nrows, uint32_t K, uint8_t* lds) {
+// the two bitmaps of vc_frec_kept (keep, full) at the head of its LDS scratch: cleared by whoever marks the keep bits
+__device__ __forceinline__ uint32_t* vc_frec_kept_clear(uint32_t nrows, uint8_t* lds) {
+    uint32_t* s_keep = reinterpret_cast<uint32_t*>(lds);
+    for (uint32_t i = (uint32_t)vc_lane(); i < 2 * (nrows / 32 + 2); i += 64) s_keep[i] = 0;
+    __syncthreads();
+    return s_keep;
+}
+// marked: the keep bits stand already (vc_otf_rows set them while it made the records)
+__device__ __forceinline__ void vc_frec_kept(const uint4* rec, uint4* frec, uint16_t* ovf, uint32_t nrows, uint32_t K, uint8_t* lds, bool marked = false) {
     const uint32_t lane = (uint32_t)vc_lane();
     uint32_t* s_keep = reinterpret_cast<uint32_t*>(lds);                           // bit per row
     uint32_t* s_full = s_keep + (nrows / 32 + 2);                                   // bit per row: read back from the stored matrix (VC_RF_FULL)
     uint16_t* s_kix = reinterpret_cast<uint16_t*>(s_full + (nrows / 32 + 2));       // [nrows + 1] kept rows before row r
-    for (uint32_t i = lane; i < 2 * (nrows / 32 + 2); i += 64) s_keep[i] = 0;
-    __syncthreads();
+    if (!marked) (void)vc_frec_kept_clear(nrows, lds);
     // which rows are read back
-    for (uint32_t r = lane; r < nrows; r += 64) {
+    for (uint32_t r = lane; r < nrows && !marked; r += 64) {
         const uint4 q = rec[r];
         const uint32_t fl = (q.x >> 8) & 0xFF, np = (q.x >> 16) & 0xFF;
         if (fl & VC_RF_OVF) {                                                      // a long list (VcDp::ovf): its rows are read back all the same
@@ -647,8 +659,16 @@ __device__ __forceinline__ void vc_frec_kept(const uint4* rec, uint4* frec, uint
     }
     if (lane == 0) s_kix[nrows] = (uint16_t)base;
     __syncthreads();
-    for (uint32_t r = lane; r < nrows; r += 64) {
-        const uint4 q = rec[r];
+    // (four rows per lane per trip: the records of a trip are requested together -- one load per row on a chain was 35 round trips)
+    for (uint32_t rb = lane; rb < nrows; rb += 256) {
+      uint4 qq[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) qq[u] = rb + 64 * u < nrows ? rec[rb + 64 * u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t r = rb + 64 * u;
+        if (r >= nrows) continue;
+        const uint4 q = qq[u];
         const uint32_t code = q.x & 0xFF, fl = (q.x >> 8) & 0xFF, np = (q.x >> 16) & 0xFF;
         const bool is_ovf = (fl & VC_RF_OVF) != 0, hasprev = (fl & VC_RF_PREV) != 0;
         const uint32_t dl[VC_INLINE_PRED] = {q.y & 0xFFFF, q.y >> 16, q.z & 0xFFFF, q.z >> 16, q.w & 0xFFFF, q.w >> 16};
@@ -705,6 +725,7 @@ __device__ __forceinline__ void vc_frec_kept(const uint4* rec, uint4* frec, uint
         o.z = out[2] | (out[3] << 16);
         o.w = out[4] | (out[5] << 16);
         frec[r] = o;
+      }
     }
     __syncthreads();
     for (uint32_t r = lane; r < nrows; r += 64)
@@ -735,8 +756,9 @@ __device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph&
     uint32_t ovf_base = 0;
     int bad = 0;
     // VC_ROWS_U blocks of 64 rows per iteration: more independent load chains in flight per lane
-    for (uint32_t r0 = 0; r0 < N; r0 += 64 * VC_ROWS_U) vc_otf_rows<VC_ROWS_U>(ot, r0, ring, ovf_base, bad, kept == 0);
-    if (kept) { __syncthreads(); vc_frec_kept(ot.rec, ot.frec, ot.ovf, N, kept, lds); }
+    uint32_t* const s_keep = kept ? vc_frec_kept_clear(N, lds) : nullptr;
+    for (uint32_t r0 = 0; r0 < N; r0 += 64 * VC_ROWS_U) vc_otf_rows<VC_ROWS_U>(ot, r0, ring, ovf_base, bad, kept == 0, s_keep);
+    if (kept) { __syncthreads(); vc_frec_kept(ot.rec, ot.frec, ot.ovf, N, kept, lds, true); }
     bad = __any(bad & 1) | (__any(bad & 2) ? 2 : 0);
     if (bad & 2) { if (lane == 0) vc_fail(b, w, VC_WIN_INVALID, 12, 0); return; }   // order invariant violated
     if (lane == 0) {
