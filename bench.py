@@ -76,7 +76,7 @@ def valu_peak_now(device):
         out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=120, env=env).stdout
         rates = [json.loads(l)["inst_per_us_per_simd"] for l in out.splitlines() if l.startswith('{"test"')]
         if rates:
-            return max(rates), "this run (vechat_amd/lib/valu_peak.bin quick, after the timed region on the same device: best of independent v_pk_max_i16 / v_pk_add_i16 chains at 4 and 8 waves per SIMD)"
+            return max(rates), "this run (vechat_amd/lib/valu_peak.bin quick, after the timed region on the same device: best of three passes of independent v_pk_max_i16 / v_pk_add_i16 chains at 4 and 8 waves per SIMD)"
     except Exception as e:
         return None, f"calibration failed: {e!r}"
     return None, "calibration printed nothing"

@@ -1,18 +1,15 @@
 #!/bin/bash
-# One GPU-box call per measurement round: gpu tests, the bench line, rocprofv3 kernel stats of the same command, PMC passes,
-# VALU calibration.  Everything lands in gpurun_out/$TAG/.   usage: tools/gpu_round.sh TAG [skip-tests]
-TAG=${1:-r2}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
+# One GPU-box call per measurement round: gpu tests, PMC passes (own runs, kernel-trace only) + VALU calibration -> traffic / count
+# files, THEN the bench line (its roofline reads those counts), then rocprofv3 kernel stats of the same command.
+# Everything lands in gpurun_out/$TAG/.   usage: tools/gpu_round.sh TAG [skip-tests]
+TAG=${1:-r4}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 if [ "$2" != "skip-tests" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 fi
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; tail -c 1500 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_stats
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --no-cpu --no-extras > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
-f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv; head -12 $O/kernel_stats.csv
-# PMC passes (own runs, kernel-trace only)
 i=0
+rm -f $O/pmc_counters.txt
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1)); rm -rf /tmp/pmc/p$i
   VC_STATS_JSON=$O/pmc_stats.json timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc/p$i -- python $R/tools/gpu_scale.py 4096 64 500 4096 1 > $O/pmc$i.log 2>&1
@@ -21,3 +18,10 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_
 done
 $R/vechat_amd/lib/valu_peak.bin > $O/valu_peak.txt
 python $R/tools/make_traffic_json.py /tmp/pmc $O/pmc_stats.json $O/valu_peak.txt $O
+cp $O/r4_hbm_traffic.json $R/profiles/r4_hbm_traffic.json      # (on this box: the bench below prices its step against these counts)
+cd $R
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; tail -c 1500 $O/bench.json
+cd /tmp
+rm -rf /tmp/prof_stats
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --no-cpu --no-extras > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv; head -12 $O/kernel_stats.csv

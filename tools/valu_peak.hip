@@ -139,7 +139,8 @@ int main(int argc, char** argv) {
     const int n_cu = p.multiProcessorCount;
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_rate_khz\": %d}\n", p.gcnArchName, n_cu, p.clockRate);
     if (argc > 1 && std::string(argv[1]) == "quick") {      // bench.py: only the rate the forward DP is priced against (~0.2 s)
-        for (int w : {4, 8}) if (run<0>("pk_i16_independent", w, n_cu, 16)) return 1;
+        for (int rep = 0; rep < 3; ++rep)                    // (the clock needs a moment after the bench's last kernel: best of three)
+            for (int w : {4, 8}) if (run<0>("pk_i16_independent", w, n_cu, 16)) return 1;
         return 0;
     }
     for (int w : {1, 2, 4, 8}) if (run<0>("pk_i16_independent", w, n_cu, 16)) return 1;
