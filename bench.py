@@ -110,17 +110,23 @@ def cpu_baseline(batch, params, budget_s):
 
 def e2e_rate(batch, device, reps=1):
     """Host memory in, host memory out: two contexts, each with its own host thread, alternate over batches of E2E_BATCH
-    windows, so one batch's H2D / D2H overlaps the other's kernels.  Returns (windows/s, consensus bytes by window)."""
+    windows, so one batch's submit (validation, H2D) and collect (D2H) overlap the other's kernels; the kernels of the two
+    take turns.  Returns (windows/s, consensus bytes by window)."""
     n = batch.n_windows
     parts = [batch.slice(lo, min(lo + E2E_BATCH, n)) for lo in range(0, n, E2E_BATCH)]
     free_b, _ = torch.cuda.mem_get_info(device)
     ctxs = [HipContext(device=device, scratch_bytes=min(int(0.42 * free_b), 96 << 30)) for _ in range(2)]
     out = [None] * len(parts)
 
+    device_turn = threading.Lock()                      # one context's kernels at a time: a batch fills the device by itself, what the
+                                                        # second context hides is the other batch's validation + H2D and its D2H
+
     def worker(k):
         for i in range(k, len(parts), 2):
             c = ctxs[k]
-            c.submit(parts[i]); c.run(); c.sync()
+            c.submit(parts[i])
+            with device_turn:
+                c.run(); c.sync()
             out[i] = c.collect()
 
     def once():
