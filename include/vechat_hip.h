@@ -136,6 +136,14 @@ int   vc_set_profile(vc_ctx* ctx, int profile);       /* change vc_params.profil
  * Results are identical either way; the environment variable VC_PIPE=0/1 sets the default of a new context.
  * forward_waves / backtrack_waves: resident workgroups of the two kernels (0: 15 and 5 per CU). */
 int   vc_set_pipeline(vc_ctx* ctx, int on, uint32_t forward_waves, uint32_t backtrack_waves);
+/* Allocates the workspaces' memory now, in one piece (bytes = 0: the default budget, vc_params.scratch_bytes or 60 % of the free
+ * memory up to 96 GiB), instead of under the first vc_submit; batches of any shape are then laid out inside it without further
+ * allocations.  The counterpart of createCUDABatch sizing a batch's device memory at construction (mem_per_batch, src/cuda/cudapolisher.cpp:229-243):
+ * a caller does it while its input is still being parsed.  Optional; without it vc_submit allocates what a batch needs. */
+int   vc_reserve(vc_ctx* ctx, uint64_t bytes);
+/* The window type is known only after the reads are (Polisher::initialize, src/polisher.cpp:300-306); a context created before that
+ * takes it here.  0 = kNGS, 1 = kTGS. */
+int   vc_set_window_type(vc_ctx* ctx, int window_type);
 
 /* -- host helpers that keep reference semantics on the host side of the boundary ---------------- */
 /* rank[] as produced by window.cpp:203-210: rank[0]=0, rank[1..] = std::sort of 1..n-1 by begin

@@ -231,6 +231,30 @@ def test_threaded_and_single_thread_host_schedulers_agree(built, monkeypatch):
     assert st["band_redo"] > 0          # the redo list (and its counter reset) really was in use
 
 
+def test_reserved_workspace_serves_batches_of_any_shape(built):
+    """vc_reserve: the workspaces' memory in one piece, batches of different shapes (and the window type set after creation, as
+    a caller does that starts the device while its reads are still being parsed) laid out inside it -- same bytes as a context
+    that allocates per batch, and the reservation is what the context holds."""
+    shapes = [capi.synth_cfg(61, 150, 8), capi.synth_cfg(62, 500, 24, frac_partial=0.2), capi.synth_cfg(63, 260, 40, n_haplotypes=2, snp_rate=0.02),
+              capi.synth_cfg(61, 150, 8)]
+    batches = [capi.synth_batch(cfg, 0, n) for cfg, n in zip(shapes, (40, 24, 12, 40))]
+    plain = HipContext(device=0, window_type=1)
+    want = [plain.consensus(b) for b in batches]
+    plain.close()
+    res = HipContext(device=0, reserve=3 << 30)
+    res.set_window_type(1)
+    for b, (cons, status) in zip(batches, want):
+        c2, s2 = res.consensus(b)
+        assert c2 == cons and list(s2) == list(status)
+        assert (3 << 30) <= res.stats()["device_bytes"] < (3 << 30) + (256 << 20)       # the arena + the batch's own arrays, no second set of workspaces
+    res.close()
+    # a reservation too small for the batch: the rest is allocated the usual way, the results do not change
+    tiny = HipContext(device=0, window_type=1, reserve=8 << 20)
+    c3, s3 = tiny.consensus(batches[1])
+    assert c3 == want[1][0] and list(s3) == list(want[1][1])
+    tiny.close()
+
+
 def test_prune_parameters_and_rounds(built):
     batch = capi.synth_batch(capi.synth_cfg(41, 180, 14, n_haplotypes=2, snp_rate=0.03), 0, 6)
     for kw in (dict(num_prune=1), dict(num_prune=2), dict(num_prune=4, min_confidence=0.22, min_support=0.19),

@@ -242,8 +242,15 @@ def test_native_sequence_reader_large_file_in_pieces(built, tmp_path):
             q = "".join(chr(33 + rnd.randint(0, 50)) for _ in range(n)).replace("+", "@") if i % 7 else "!" * n
             f.write(f"@r{i} d\n{s}\n+\n{q}\n")
             g.write(f">r{i}\n" + "".join(s[k:k + 70] + "\n" for k in range(0, n, 70)) + ("\n" if i % 50 == 0 else ""))
-    for name in ("big.fastq", "big.fasta"):
+    # a file that defeats the mid-file guess of a record start (every quality line opens with '@' and every sequence with '+', so a
+    # quality line looks like a header): the pieces do not chain and one thread walks the file
+    with open(tmp_path / "odd.fastq", "w") as f:
+        for i in range(9000):
+            n = rnd.choice([300, 800])
+            f.write(f"@o{i}\n+{''.join(rnd.choice('ACGT') for _ in range(n - 1))}\n+\n@{''.join(chr(34 + rnd.randint(0, 40)) for _ in range(n - 1))}\n")
+    for name in ("big.fastq", "big.fasta", "odd.fastq"):
         assert seqio.NativeSequences(tmp_path / name).records() == seqio.read_sequences(tmp_path / name)
+    assert seqio.NativeSequences(tmp_path / "big.fastq", names_only=True).index() == seqio.sequence_index(tmp_path / "big.fastq")
 
 
 @pytest.mark.parametrize("seed", [1])

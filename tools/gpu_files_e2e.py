@@ -105,8 +105,10 @@ def main(nt=None, tl=None, depth=None, out=None, python_too=True, quiet=False):
 
     dev = os.environ.get("VC_FILES_HOST_ONLY") != "1"
     if dev:
-        ctx = HipContext(device=0, mode=0, min_confidence=0.2, min_support=0.2, num_prune=3)
-        ctx.consensus(capi.synth_batch(capi.synth_cfg(1, 200, 8), 0, 64))       # context and workspaces exist before the clock starts
+        # context and workspaces exist before the clock starts, as they do in `python -m vechat_amd.polish`, which starts the device
+        # and reserves its workspaces (vc_reserve) on a thread while the files are parsed
+        ctx = HipContext(device=0, mode=0, min_confidence=0.2, min_support=0.2, num_prune=3, reserve=0)
+        ctx.consensus(capi.synth_batch(capi.synth_cfg(1, 200, 8), 0, 64))
     t_nat, b_nat, rate_nat, T_nat = run(True, dev)
     res = {"windows_per_s": rate_nat, "windows": int(b_nat.n_windows), "input_mb": mb, "seconds_by_phase": {k: round(v, 4) for k, v in T_nat.items()},
            "workload": f"{nt} targets x {tl} bp x {depth} reads as FASTQ + SAM files -> corrected FASTA text (C++ readers vc_io_*, window builder, device, stitching; "

@@ -108,6 +108,9 @@ struct vc_ctx {
     Slot slots[16];
     std::vector<void*> chunk_allocs;    // workspaces (re-created when capacities change)
     uint64_t chunk_bytes = 0;           // what they hold: counts as available when the next batch is planned
+    char* arena = nullptr;              // vc_reserve: one allocation the workspaces are carved from (a change of shape then costs no hipFree / hipMalloc)
+    size_t arena_bytes = 0, arena_used = 0;
+    bool have_ws = false;               // workspaces exist (out of the arena or allocated piece by piece)
 
     bool have_batch = false, ran = false;
     VcBatchDev b{};
@@ -190,6 +193,10 @@ template <typename T>
 int dalloc(vc_ctx* c, std::vector<void*>& list, T** out, size_t n) {
     void* p = nullptr;
     size_t bytes = std::max<size_t>(n * sizeof(T), 256);
+    if (&list == &c->chunk_allocs && c->arena) {          // workspaces come out of the reserved arena while it lasts
+        const size_t at = (c->arena_used + 255) & ~(size_t)255;
+        if (at + bytes <= c->arena_bytes) { c->arena_used = at + bytes; *out = reinterpret_cast<T*>(c->arena + at); return VC_OK; }
+    }
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return fail(c, VC_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     list.push_back(p);
@@ -232,6 +239,12 @@ int salloc(vc_ctx* c, int slot, T** out, size_t n) {
 void free_list(std::vector<void*>& l) {
     for (void* p : l) (void)hipFree(p);
     l.clear();
+}
+void free_workspaces(vc_ctx* c) {         // the chunk workspaces: what was allocated piece by piece, and the arena's bump pointer
+    free_list(c->chunk_allocs);
+    c->arena_used = 0;
+    c->chunk_bytes = 0;
+    c->have_ws = false;
 }
 
 int alloc_graph(vc_ctx* c, VcGraph* g) {
@@ -912,7 +925,8 @@ void vc_destroy(vc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     sync_ctx(c);
-    free_list(c->chunk_allocs);
+    free_workspaces(c);
+    if (c->arena) (void)hipFree(c->arena);
     free_list(c->batch_allocs);
     for (auto& sl : c->slots) if (sl.p) (void)hipFree(sl.p);
     free_list(c->allocs);
@@ -940,6 +954,35 @@ int vc_set_pipeline(vc_ctx* c, int on, uint32_t forward_waves, uint32_t backtrac
     if (!c) return VC_ERR_ARG;
     join_workers(c);
     c->pipe = on != 0; c->pipe_f = forward_waves; c->pipe_t = backtrack_waves;
+    return VC_OK;
+}
+
+int vc_reserve(vc_ctx* c, uint64_t bytes) {
+    if (!c) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    sync_ctx(c);
+    free_workspaces(c);
+    if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+    if (!bytes) {                                         // the default budget of vc_submit
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        bytes = c->prm.scratch_bytes ? c->prm.scratch_bytes : std::min<uint64_t>((uint64_t)(free_b * 0.6), 96ull << 30);
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(c, VC_ERR_HIP, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    // first touch now, not under the first batch: the driver hands out cleared memory and clears it when it has to
+    e = hipMemsetAsync(p, 0, bytes, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(p); return fail(c, VC_ERR_HIP, "clearing the reserved workspace failed: %s", hipGetErrorString(e)); }
+    c->arena = (char*)p; c->arena_bytes = bytes; c->arena_used = 0;
+    return VC_OK;
+}
+
+int vc_set_window_type(vc_ctx* c, int window_type) {
+    if (!c || (window_type != 0 && window_type != 1)) return VC_ERR_ARG;
+    join_workers(c);
+    c->prm.window_type = window_type;
     return VC_OK;
 }
 
@@ -1001,7 +1044,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     // instead of failing the whole batch (one 38 k-base layer used to do that)
     if (pass == 0) {
         const uint64_t nc0 = c->prm.max_nodes ? c->prm.max_nodes : std::min<uint64_t>((need_nodes + 63) & ~63ull, 59968);
-        const int64_t allowed = ((int64_t)kLdsCap - 64 - 48 - 2 * (int64_t)std::max<uint64_t>(nc0, c->chunk_allocs.empty() ? 0 : c->NC)) / 4;
+        const int64_t allowed = ((int64_t)kLdsCap - 64 - 48 - 2 * (int64_t)std::max<uint64_t>(nc0, !c->have_ws ? 0 : c->NC)) / 4;
         if ((int64_t)max_len <= allowed) break;
         for (uint32_t w = 0; w < nw; ++w)
             for (uint32_t q = hb->win_seq_off[w]; q < hb->win_seq_off[w + 1]; ++q)
@@ -1061,7 +1104,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     // Workspaces are grow-only across batches: a batch whose own estimate is a little smaller than its predecessor's keeps
     // the capacities that exist (a few percent of difference would otherwise re-create ~100 GB of buffers, seconds per
     // batch).  Results do not depend on capacities; pinned capacities (max_nodes / max_edges) are taken literally.
-    const bool have_ws = !c->chunk_allocs.empty();
+    const bool have_ws = c->have_ws;
     if (have_ws && !c->prm.max_nodes) NC = std::max(NC, c->NC);
     if (have_ws) { MA = std::max(MA, c->MA); max_nseq = std::max(max_nseq, c->max_nseq); }
     const uint32_t ws_max_len = have_ws ? std::max(max_len, c->ws_max_len) : max_len;
@@ -1095,6 +1138,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     // default budget: 60 % of what is free, but no more than 96 GiB -- config C runs at 97 % of its unrestricted rate with 64 GiB
     // (chunks of 4 096 windows) and at 86 % with 32 GiB (2 048), so holding more than that buys nothing (profiles/r3c_footprint.txt)
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : std::min<uint64_t>((uint64_t)(free_b * 0.6), 96ull << 30)) / S;
+    if (c->arena) budget = (c->arena_bytes - std::min<size_t>(c->arena_bytes, 1u << 20)) / S;      // vc_reserve: the arena IS the budget (less the padding between its pieces)
     const uint64_t rowd = 64ull * (c->packed ? (uint64_t)vc_nds((int)cpl) : cpl / 2);      // dwords per stored row: byte-packed (NDS per lane) or raw int16 pairs
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6 + 16) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2) + EC * 2ull + 32) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
@@ -1110,7 +1154,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint32_t wcols = maybe_wide ? ((ws_max_len + 64 * VC_WIDE_CPL - 1) / (64 * VC_WIDE_CPL)) * (64 * VC_WIDE_CPL) : 0;
     // (the int32 matrices of k_fwd_wide are 86 MB per alignment at 7 040 rows x 3 072 columns: there the chunk size IS the budget,
     // and the 96-GiB cap above would halve it)
-    if (maybe_wide && !c->prm.scratch_bytes) budget = (uint64_t)(free_b * 0.6) / S;
+    if (maybe_wide && !c->prm.scratch_bytes && !c->arena) budget = (uint64_t)(free_b * 0.6) / S;
     const uint64_t per_job = NC * rowd * 5 + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);
@@ -1128,8 +1172,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const bool same = have_ws && c->wcols == wcols && c->MA == MA && c->NC == NC && c->EC == EC && c->CW >= CW && c->ws_cpl == cpl && c->PC == PC &&
                       c->big_ws_stride == big && c->max_nseq == max_nseq;
     if (!same) {
-        free_list(c->chunk_allocs);
-        c->chunk_bytes = 0;
+        free_workspaces(c);
         c->wcols = wcols; c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->ws_cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
         c->ws_max_len = ws_max_len;
         c->big_ws_stride = big;
@@ -1144,6 +1187,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
             if ((rc = alloc_work(c, &c->works[s]))) return rc;
         (void)hipMemGetInfo(&f1, &tt);
         c->chunk_bytes = f0 > f1 ? f0 - f1 : 0;
+        c->have_ws = true;
     }
     b.cons_cap = NC;
     c->kept = (kKept && NC < 32768 && !getenv("VC_PLAIN_RING")) ? (uint32_t)kKept : 0u;
@@ -1537,7 +1581,7 @@ int vc_get_stats(vc_ctx* c, vc_stats* s) {
     c->stats.trace_steps = st[4]; c->stats.trace_spec = st[5]; c->stats.trace_rounds = st[6];
     c->stats.band_redo = st[7];
     {
-        uint64_t held = c->chunk_bytes;
+        uint64_t held = c->chunk_bytes + c->arena_bytes;
         for (auto& sl : c->slots) held += sl.cap;
         c->stats.device_bytes = held;
     }

@@ -16,6 +16,7 @@
 // cross-checked against the independent Python restatement in vechat_amd/seqio.py on every format.
 // Files are read whole (mmap, or zlib for .gz) and cut into records by memchr; plain files are parsed by several threads.
 #include "vechat_hip.h"
+#include "vc_hostbuf.h"
 
 #include <zlib.h>
 
@@ -25,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +48,15 @@ struct Blob {
     std::string owned;          // .gz: inflated here
     void* map = nullptr; size_t map_n = 0;
     ~Blob() { if (map) munmap(map, map_n); }
+    // a thread about to read [a, b) of a mapped file asks for its pages in one call (threads faulting page by page queue up behind
+    // each other); a kernel without MADV_POPULATE_READ just says no and the pages come as they are touched
+    void populate(const char* a, const char* b) const {
+        if (!map || b <= a) return;
+        const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE), lo = (uintptr_t)a & ~(pg - 1), hi = std::min(((uintptr_t)b + pg - 1) & ~(pg - 1), (uintptr_t)map + ((map_n + pg - 1) & ~(pg - 1)));
+#ifdef MADV_POPULATE_READ
+        if (hi > lo) (void)madvise((void*)lo, (size_t)(hi - lo), MADV_POPULATE_READ);
+#endif
+    }
 };
 
 bool ends_with(const std::string& s, const char* suf) {
@@ -76,10 +87,9 @@ bool load_file(const char* path, Blob& b, std::string& err) {
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); err = ps + ": cannot stat"; return false; }
     if (st.st_size == 0) { close(fd); b.p = ""; b.n = 0; return true; }
-    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);   // (pre-faulted in one go: parser threads faulting pages one by one serialise on the address space)
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);                  // (pages: Blob::populate, by the threads that read them)
     close(fd);
     if (m == MAP_FAILED) { err = ps + ": cannot map"; return false; }
-    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
     b.map = m; b.map_n = (size_t)st.st_size; b.p = (const char*)m; b.n = b.map_n;
     return true;
 }
@@ -94,13 +104,6 @@ inline void strip(const char*& p, const char*& e) {
     while (p < e && is_space(*p)) ++p;
     while (e > p && is_space(e[-1])) --e;
 }
-inline void append_upper(std::string& o, const char* a, const char* b) {             // sequence.cpp:19-42 upper-cases the bases
-    const size_t at = o.size(), n = (size_t)(b - a);
-    o.append(a, n);
-    char* p = &o[at];
-    for (size_t i = 0; i < n; ++i) { const char c = p[i]; p[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
-}
-
 unsigned n_threads() {
     unsigned n = std::thread::hardware_concurrency();
     if (const char* e = getenv("VC_IO_THREADS")) n = (unsigned)std::max(1, atoi(e));
@@ -119,18 +122,7 @@ unsigned n_threads() {
 
 // ------------------------------------------------------------------------------------------------ sequences
 namespace {
-struct RawBuf {                                      // bytes without the zero fill of a std::string (every thread first-touches its own part)
-    char* p = nullptr; size_t n = 0;
-    RawBuf() = default;
-    RawBuf(const RawBuf&) = delete;
-    RawBuf& operator=(const RawBuf&) = delete;
-    ~RawBuf() { free(p); }
-    void alloc(size_t k) { free(p); p = (char*)malloc(k ? k : 1); n = k; }
-    const char* data() const { return p; }
-    char* data() { return p; }
-    bool empty() const { return n == 0; }
-    size_t size() const { return n; }
-};
+using RawBuf = VcHostBuf;                            // bytes without the zero fill of a std::string (every thread first-touches its own part)
 }  // namespace
 
 struct vc_seqset {
@@ -147,128 +139,113 @@ struct vc_seqset {
 
 namespace {
 
-struct SeqPart {                                     // what one thread made of its piece of the file
-    std::string names, data, qual;
-    std::vector<uint64_t> name_len, data_len;
-    std::vector<uint8_t> has_qual;
+struct RecRef {                                      // one record as pass 1 found it: spans into the file image, nothing copied yet
+    const char* name; uint32_t name_len;
+    char kind;                                       // '>' or '@'
+    const char* seq; const char* seq_end;            // '@': the stripped sequence line; '>': first sequence line .. start of the next record
+    const char* qual;                                // '@': the stripped quality line (dlen bytes)
+    uint64_t dlen;
+};
+
+struct SeqIndex {                                    // what one thread made of its byte range of the file
+    std::vector<RecRef> recs;
+    const char* first = nullptr;                     // where its first record starts (nullptr: none starts inside the range)
+    const char* end = nullptr;                       // where the record behind its last one starts (blank lines skipped)
     std::string err;
 };
 
 using KeepSet = std::unordered_map<std::string, char>;
 
-// one FASTA / FASTQ record starting at p (a '>' or '@' line); returns the position behind it, nullptr on error
-const char* parse_record(const char* p, const char* e, const std::string& path, const KeepSet* keep, bool names_only, SeqPart& o) {
-    const char* le = line_end(p, e);
-    const char kind = *p;
-    // name: the header line without its first byte, cut at the first whitespace (b"...".split()[0])
-    const char* ns = p + 1; const char* ne = le;
-    strip(ns, ne);
-    const char* nc = ns;
-    while (nc < ne && !is_space(*nc)) ++nc;
-    const bool want = !keep || keep->count(std::string(ns, (size_t)(nc - ns))) != 0;
-    const char* q = le < e ? le + 1 : e;
-    size_t dlen = 0;
-    const size_t d0 = o.data.size();
-    bool hq = false;
-    if (kind == '>') {
-        // sequence lines up to the next line that starts with '>' (or the end); every line stripped, blank lines contribute nothing
-        while (q < e && *q != '>') {
-            const char* l2 = line_end(q, e);
-            const char* a = q; const char* b = l2;
-            strip(a, b);
-            if (want && !names_only) append_upper(o.data, a, b);
-            dlen += (size_t)(b - a);
-            q = l2 < e ? l2 + 1 : e;
-        }
-    } else {
-        // four-line FASTQ: sequence, separator, quality
-        const char* l2 = line_end(q, e);
-        const char* a = q; const char* b = l2;
-        strip(a, b);
-        dlen = (size_t)(b - a);
-        if (want && !names_only) append_upper(o.data, a, b);
-        q = l2 < e ? l2 + 1 : e;
-        q = line_end(q, e); q = q < e ? q + 1 : e;                           // the '+' line
-        const char* l4 = line_end(q, e);
-        const char* qa = q; const char* qb = l4;
-        strip(qa, qb);
-        if ((size_t)(qb - qa) != dlen) { o.err = path + ": quality length differs from sequence length for " + std::string(ns, (size_t)(nc - ns)); return nullptr; }
-        // src/sequence.cpp:19-42: the sum of (c - '!') decides; all '!' -> no quality
-        unsigned long long sum = 0; bool below = false;
-        for (const char* c = qa; c < qb; ++c) { sum += (unsigned long long)((unsigned char)*c - 33u); below |= (unsigned char)*c < 33u; }
-        if (below) { long long s2 = 0; for (const char* c = qa; c < qb; ++c) s2 += (long long)(unsigned char)*c - 33; sum = (unsigned long long)(s2 != 0); }
-        hq = dlen > 0 && sum != 0;
-        if (want && !names_only && hq) { o.qual.resize(d0, '!'); o.qual.append(qa, (size_t)(qb - qa)); }
-        q = l4 < e ? l4 + 1 : e;
-    }
-    if (want) {
-        o.names.append(ns, (size_t)(nc - ns));
-        o.name_len.push_back((uint64_t)(nc - ns));
-        o.data_len.push_back(dlen);
-        o.has_qual.push_back(hq ? 1 : 0);
-    }
-    return q;
-}
-
-void parse_range(const char* p, const char* e, const std::string& path, const KeepSet* keep, bool names_only, SeqPart& o) {
-    if (!names_only && !keep) {                      // one allocation per buffer instead of a dozen regrowths of tens of megabytes
-        const size_t n = (size_t)(e - p);
-        const char* s = p;
-        while (s < e && is_space(*s)) ++s;
-        const bool fq = s < e && *s == '@';
-        o.data.reserve(fq ? n / 2 + 64 : n);
-        if (fq) o.qual.reserve(n / 2 + 64);
-    }
-    while (p < e && o.err.empty()) {
+inline const char* skip_blank_lines(const char* p, const char* e) {
+    while (p < e) {
         const char* le = line_end(p, e);
         const char* a = p; const char* b = le;
         strip(a, b);
-        if (a == b) { p = le < e ? le + 1 : e; continue; }                  // blank line between records
-        if (*p != '>' && *p != '@') { o.err = path + ": unrecognised record"; return; }
-        p = parse_record(p, e, path, keep, names_only, o);
-        if (!p) return;
+        if (a != b) break;
+        p = le < e ? le + 1 : e;
     }
+    return p;
 }
 
-// a position at or behind `p` where a record certainly starts.  FASTA: a line starting with '>'.  FASTQ: '@' may open a
-// quality line too, so a start is an '@' line whose line after next starts with '+' and which is not itself preceded by a '+' line
-// ... simpler and exact for four-line files: count lines from a known record start.  Pieces are therefore cut by the main
-// thread, which walks the line structure once (memchr only).
-std::vector<size_t> cut_points(const Blob& f, unsigned parts) {
-    std::vector<size_t> cut{0};
-    if (parts <= 1 || f.n < (1u << 22)) { cut.push_back(f.n); return cut; }
-    const char* p = f.p; const char* e = f.p + f.n;
-    // first non-blank byte decides the format
-    const char* s = p;
-    while (s < e && is_space(*s)) ++s;
-    if (s == e) { cut.push_back(f.n); return cut; }
-    const size_t step = f.n / parts;
-    if (*s == '>') {
-        for (unsigned k = 1; k < parts; ++k) {
-            const char* q = p + k * step;
-            while (q < e) {                                                  // next line start with '>'
-                q = (const char*)memchr(q, '\n', (size_t)(e - q));
-                if (!q) { q = e; break; }
-                ++q;
-                if (q < e && *q == '>') break;
+// pass 1: the records that START in [p, range_end), p being a record start (or blank lines before one); reads on to the end of the
+// last one.  Only memchr and strip: no byte of sequence or quality is looked at.
+void index_records(const char* p, const char* range_end, const char* e, const std::string& path, const KeepSet* keep, SeqIndex& o) {
+    p = skip_blank_lines(p, e);
+    while (p < range_end && p < e) {
+        if (*p != '>' && *p != '@') { o.err = path + ": unrecognised record"; return; }
+        const char* le = line_end(p, e);
+        RecRef r;
+        r.kind = *p;
+        // name: the header line without its first byte, cut at the first whitespace (b"...".split()[0])
+        const char* ns = p + 1; const char* ne = le;
+        strip(ns, ne);
+        const char* nc = ns;
+        while (nc < ne && !is_space(*nc)) ++nc;
+        r.name = ns; r.name_len = (uint32_t)(nc - ns);
+        const bool want = !keep || keep->count(std::string(ns, (size_t)(nc - ns))) != 0;
+        const char* q = le < e ? le + 1 : e;
+        r.qual = nullptr; r.dlen = 0;
+        if (r.kind == '>') {
+            // sequence lines up to the next line that starts with '>' (or the end); every line stripped, blank lines contribute nothing
+            r.seq = q;
+            while (q < e && *q != '>') {
+                const char* l2 = line_end(q, e);
+                const char* a = q; const char* b = l2;
+                strip(a, b);
+                r.dlen += (uint64_t)(b - a);
+                q = l2 < e ? l2 + 1 : e;
             }
-            if (q < e && (size_t)(q - p) > cut.back()) cut.push_back((size_t)(q - p));
+            r.seq_end = q;
+        } else {
+            // four-line FASTQ: sequence, separator, quality
+            const char* l2 = line_end(q, e);
+            const char* a = q; const char* b = l2;
+            strip(a, b);
+            r.seq = a; r.seq_end = b; r.dlen = (uint64_t)(b - a);
+            q = l2 < e ? l2 + 1 : e;
+            q = line_end(q, e); q = q < e ? q + 1 : e;                       // the '+' line
+            const char* l4 = line_end(q, e);
+            const char* qa = q; const char* qb = l4;
+            strip(qa, qb);
+            if ((uint64_t)(qb - qa) != r.dlen) { o.err = path + ": quality length differs from sequence length for " + std::string(ns, (size_t)(nc - ns)); return; }
+            r.qual = qa;
+            q = l4 < e ? l4 + 1 : e;
         }
-    } else {
-        // four-line FASTQ: walk the lines, remember the record starts nearest to the targets
-        size_t line = 0; unsigned k = 1;
-        const char* q = s;
-        while (q < e && k < parts) {
-            if (line % 4 == 0 && (size_t)(q - p) >= k * step) { cut.push_back((size_t)(q - p)); ++k; continue; }
-            const char* l = (const char*)memchr(q, '\n', (size_t)(e - q));
-            if (!l) break;
-            // blank lines between records do not count (the parser skips them at record boundaries only)
-            if (!(line % 4 == 0 && l == q)) ++line;
-            q = l + 1;
-        }
+        if (want) o.recs.push_back(r);
+        p = skip_blank_lines(q, e);
     }
-    cut.push_back(f.n);
-    return cut;
+    o.end = p;
+}
+
+// A position at or behind x where a record probably starts, for a thread that begins in the middle of the file.  FASTA: a line
+// starting with '>' (exact: the parser itself ends a record there).  FASTQ: an '@' line whose line after next starts with '+' ('@'
+// may open a quality line too, but then the line after next is a sequence line).  A guess only: the caller accepts the pieces only
+// when every piece ends exactly where the next one starts, and reads the file in one piece otherwise.
+const char* guess_record_start(const char* base, const char* x, const char* e, bool fastq) {
+    const char* q = x;
+    if (q > base && q[-1] != '\n') { q = line_end(q, e); q = q < e ? q + 1 : e; }
+    while (q < e) {
+        const char* le = line_end(q, e);
+        if (!fastq) { if (*q == '>') return q; }
+        else if (*q == '@') {
+            const char* l1 = le < e ? le + 1 : e;
+            const char* l2 = line_end(l1, e); l2 = l2 < e ? l2 + 1 : e;
+            if (l2 < e && *l2 == '+') return q;
+        }
+        q = le < e ? le + 1 : e;
+    }
+    return e;
+}
+
+// sequence.cpp:19-42: the sum of (c - '!') decides whether a quality string counts; all '!' -> none
+inline bool quality_counts(const char* qa, uint64_t n) {
+    unsigned long long sum = 0; bool below = false;
+    for (uint64_t i = 0; i < n; ++i) { sum += (unsigned long long)((unsigned char)qa[i] - 33u); below |= (unsigned char)qa[i] < 33u; }
+    if (below) { long long s2 = 0; for (uint64_t i = 0; i < n; ++i) s2 += (long long)(unsigned char)qa[i] - 33; sum = (unsigned long long)(s2 != 0); }
+    return n > 0 && sum != 0;
+}
+inline void copy_upper(char* o, const char* a, size_t n) {                            // sequence.cpp:19-42 upper-cases the bases
+    for (size_t i = 0; i < n; ++i) { const char c = a[i]; o[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
 }
 
 }  // namespace
@@ -279,8 +256,10 @@ vc_seqset* vc_io_read_sequences(const char* path, const char* keep_names, int na
     vc_seqset* s = new vc_seqset();
     s->names_only = names_only != 0;
     if (!path) { s->err = "null path"; return s; }
+    VC_IO_T0;
     Blob f;
     if (!load_file(path, f, s->err)) return s;
+    VC_IO_TICK("map");
     KeepSet keep;
     if (keep_names) {
         for (const char* p = keep_names; *p;) {
@@ -290,52 +269,104 @@ vc_seqset* vc_io_read_sequences(const char* path, const char* keep_names, int na
             p = *e ? e + 1 : e;
         }
     }
-    VC_IO_T0;
-    const std::vector<size_t> cut = cut_points(f, n_threads());
-    VC_IO_TICK("cut");
-    std::vector<SeqPart> parts(cut.size() - 1);
-    std::vector<std::thread> th;
+    const KeepSet* kp = keep_names ? &keep : nullptr;
     const std::string ps(path);
-    for (size_t k = 0; k + 1 < cut.size(); ++k)
-        th.emplace_back([&, k]() { parse_range(f.p + cut[k], f.p + cut[k + 1], ps, keep_names ? &keep : nullptr, names_only != 0, parts[k]); });
-    for (auto& t : th) t.join();
-    VC_IO_TICK("parse");
-    size_t nn = 0, nd = 0, nr = 0; bool anyq = false;
-    for (auto& p : parts) {
-        if (!p.err.empty() && s->err.empty()) s->err = p.err;
-        nn += p.names.size(); nd += p.data.size(); nr += p.has_qual.size(); anyq |= !p.qual.empty();
+    const char* const base = f.p; const char* const fe = f.p + f.n;
+    // ---- pass 1: where the records are.  Byte ranges side by side; a thread that starts mid-file guesses its first record start,
+    // and the pieces count only if they chain (piece k ends exactly where piece k+1 begins) -- then they are what one thread
+    // walking the whole file finds.  Otherwise (a file the guess does not fit, or an error anywhere) one thread walks it.
+    const char* s0 = base;
+    while (s0 < fe && is_space(*s0)) ++s0;
+    const bool fastq = s0 < fe && *s0 == '@';
+    unsigned parts = f.n < (1u << 22) ? 1u : n_threads();
+    std::vector<SeqIndex> idx(parts);
+    if (parts > 1) {
+        const size_t step = f.n / parts;
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < parts; ++k)
+            th.emplace_back([&, k]() {
+                const char* lo = base + (size_t)k * step; const char* hi = k + 1 == parts ? fe : base + (size_t)(k + 1) * step;
+                f.populate(lo, hi);
+                const char* st = k == 0 ? base : guess_record_start(base, lo, fe, fastq);
+                idx[k].first = st;
+                if (st < hi || k == 0) index_records(st, hi, fe, ps, kp, idx[k]); else idx[k].end = st;
+            });
+        for (auto& t : th) t.join();
+        bool chained = true;
+        for (unsigned k = 0; k < parts && chained; ++k) {
+            if (!idx[k].err.empty()) chained = false;
+            else if (k + 1 < parts && idx[k].end != idx[k + 1].first) {
+                // a piece in which no record starts hands its neighbour's start on; anything else is a seam that does not fit
+                chained = false;
+            }
+        }
+        if (!chained) { parts = 1; idx.assign(1, SeqIndex()); }
     }
-    if (!s->err.empty()) return s;
-    // the pieces side by side into the final buffers (offsets first, then every thread copies its own piece)
-    std::vector<size_t> d_at(parts.size() + 1, 0), n_at(parts.size() + 1, 0), r_at(parts.size() + 1, 0);
-    for (size_t k = 0; k < parts.size(); ++k) {
-        d_at[k + 1] = d_at[k] + parts[k].data.size(); n_at[k + 1] = n_at[k] + parts[k].names.size(); r_at[k + 1] = r_at[k] + parts[k].has_qual.size();
-    }
-    s->names.resize(nn); s->data.alloc(nd); if (anyq) s->qual.alloc(nd);
+    if (parts == 1) index_records(base, fe, fe, ps, kp, idx[0]);
+    if (io_tm_) fprintf(stderr, "  [vc_io] %u piece(s)\n", parts);
+    VC_IO_TICK("index");
+    for (auto& p : idx) if (!p.err.empty()) { s->err = p.err; return s; }
+    size_t nr = 0;
+    for (auto& p : idx) nr += p.recs.size();
+    std::vector<RecRef> recs;
+    recs.reserve(nr);
+    for (auto& p : idx) { recs.insert(recs.end(), p.recs.begin(), p.recs.end()); std::vector<RecRef>().swap(p.recs); }
+    // ---- offsets
     s->name_off.assign(nr + 1, 0); s->data_off.assign(nr + 1, 0); s->has_qual.assign(nr, 0); s->length.assign(nr, 0);
+    std::vector<uint64_t> at(nr + 1, 0);                                   // data offsets as if the data were kept (work split of pass 2)
+    bool any_fastq = false;
+    for (size_t i = 0; i < nr; ++i) {
+        s->name_off[i + 1] = s->name_off[i] + recs[i].name_len;
+        at[i + 1] = at[i] + recs[i].dlen;
+        s->length[i] = recs[i].dlen;
+        any_fastq |= recs[i].kind == '@' && recs[i].dlen > 0;
+    }
+    const uint64_t nd = at[nr];
+    if (!names_only) { s->data_off = at; s->data.alloc(nd); if (any_fastq) s->qual.alloc(nd); }
+    s->names.resize(s->name_off[nr]);
     VC_IO_TICK("alloc");
-    std::vector<std::thread> cp;
-    for (size_t k = 0; k < parts.size(); ++k)
-        cp.emplace_back([&, k]() {
-            SeqPart& p = parts[k];
-            if (!p.names.empty()) std::memcpy(&s->names[n_at[k]], p.names.data(), p.names.size());
-            if (!p.data.empty()) std::memcpy(s->data.data() + d_at[k], p.data.data(), p.data.size());
-            if (anyq) {                              // (a piece's qual may stop short of its data: '!' behind it)
-                if (!p.qual.empty()) std::memcpy(s->qual.data() + d_at[k], p.qual.data(), p.qual.size());
-                if (p.qual.size() < p.data.size()) std::memset(s->qual.data() + d_at[k] + p.qual.size(), '!', p.data.size() - p.qual.size());
+    // ---- pass 2: the bytes, records side by side (pieces of about equal size), every thread straight into the final buffers
+    const unsigned T = (unsigned)std::min<size_t>(nd + nr < (1u << 20) ? 1u : n_threads(), std::max<size_t>(nr, 1));
+    std::vector<uint8_t> anyq(T, 0);
+    auto fill = [&](unsigned t) {
+        size_t i0 = (size_t)(std::lower_bound(at.begin(), at.end(), nd / T * t) - at.begin()), i1 = (size_t)(std::lower_bound(at.begin(), at.end(), nd / T * (t + 1)) - at.begin());
+        if (t == 0) i0 = 0;
+        if (t + 1 == T) i1 = nr;
+        i0 = std::min(i0, nr); i1 = std::min(i1, nr);
+        for (size_t i = i0; i < i1; ++i) {
+            const RecRef& r = recs[i];
+            if (r.name_len) std::memcpy(&s->names[s->name_off[i]], r.name, r.name_len);
+            char* d = names_only ? nullptr : s->data.data() + at[i];
+            if (r.kind == '@') {
+                if (d) copy_upper(d, r.seq, (size_t)r.dlen);
+                const bool hq = quality_counts(r.qual, r.dlen);
+                s->has_qual[i] = hq ? 1 : 0;
+                if (hq) anyq[t] = 1;
+                if (d && any_fastq) { if (hq) std::memcpy(s->qual.data() + at[i], r.qual, (size_t)r.dlen); else std::memset(s->qual.data() + at[i], '!', (size_t)r.dlen); }
+            } else {
+                if (d) {
+                    for (const char* q = r.seq; q < r.seq_end;) {
+                        const char* l2 = line_end(q, r.seq_end);
+                        const char* a = q; const char* b = l2;
+                        strip(a, b);
+                        copy_upper(d, a, (size_t)(b - a)); d += b - a;
+                        q = l2 < r.seq_end ? l2 + 1 : r.seq_end;
+                    }
+                    if (any_fastq) std::memset(s->qual.data() + at[i], '!', (size_t)r.dlen);
+                }
             }
-            uint64_t no = n_at[k], dof = d_at[k];
-            for (size_t i = 0; i < p.has_qual.size(); ++i) {
-                const size_t r = r_at[k] + i;
-                s->name_off[r] = no; s->data_off[r] = dof;
-                no += p.name_len[i]; dof += names_only ? 0 : p.data_len[i];
-                s->length[r] = p.data_len[i]; s->has_qual[r] = p.has_qual[i];
-            }
-            std::string().swap(p.names); std::string().swap(p.data); std::string().swap(p.qual);
-        });
-    for (auto& t : cp) t.join();
-    VC_IO_TICK("concat");
-    s->name_off[nr] = nn; s->data_off[nr] = names_only ? 0 : nd;
+        }
+    };
+    if (T <= 1) fill(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) th.emplace_back(fill, t);
+        for (auto& t : th) t.join();
+    }
+    bool some = false;
+    for (uint8_t a : anyq) some |= a != 0;
+    if (!some) s->qual.alloc(0);                             // no record with a quality that counts: no quality buffer at all
+    VC_IO_TICK("copy");
     return s;
 }
 

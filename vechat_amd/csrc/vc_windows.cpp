@@ -13,6 +13,7 @@
 //                                           src/sequence.cpp:50-83   (reverse complement / reverse quality)
 //   vc_wb_stitch                         <- src/polisher.cpp:520-547 (per-target concatenation, LN/RC/XC tags)
 #include "vechat_hip.h"
+#include "vc_hostbuf.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -60,7 +61,8 @@ struct vc_wb {
     // flattened batch (owned here, handed out through vc_batch)
     std::vector<uint32_t> win_seq_off, seq_begin, seq_end;
     std::vector<uint64_t> seq_off;
-    std::vector<uint8_t> seq_has_qual, bases, quals, win_fasta;
+    std::vector<uint8_t> seq_has_qual, win_fasta;
+    VcHostBuf bases, quals;                        // written once by the flatten threads: no zero fill, huge pages on request
     std::vector<uint32_t> seq_orig;                 // add_layer() index of every stored sequence (0 = backbone)
     // stitched output
     std::vector<std::string> out_name, out_data;
@@ -318,7 +320,7 @@ int vc_wb_build(vc_wb* b, vc_batch* out) {
     const uint64_t ns = wseqs[nw], nb = wbytes[nw];
     B.win_seq_off.assign(nw + 1, 0); B.seq_off.assign(ns + 1, 0);
     B.seq_begin.assign(ns, 0); B.seq_end.assign(ns, 0); B.seq_has_qual.assign(ns, 0); B.seq_orig.assign(ns, 0);
-    B.bases.resize(nb); B.quals.resize(nb); B.win_fasta.assign(nw, 0);
+    B.bases.alloc(nb); B.quals.alloc(nb); B.win_fasta.assign(nw, 0);
     for (size_t w = 0; w <= nw; ++w) B.win_seq_off[w] = (uint32_t)wseqs[w];
     B.seq_off[ns] = nb;
     parallel_for(nw, 8, [&](size_t w) {
@@ -364,7 +366,7 @@ int vc_wb_build(vc_wb* b, vc_batch* out) {
     out->n_windows = (uint32_t)nw;
     out->win_seq_off = B.win_seq_off.data(); out->seq_off = B.seq_off.data();
     out->seq_begin = B.seq_begin.data(); out->seq_end = B.seq_end.data(); out->seq_has_qual = B.seq_has_qual.data();
-    out->bases = B.bases.data(); out->quals = B.quals.data(); out->win_fasta = B.win_fasta.data();
+    out->bases = (const uint8_t*)B.bases.data(); out->quals = (const uint8_t*)B.quals.data(); out->win_fasta = B.win_fasta.data();
     return VC_OK;
 }
 

@@ -23,9 +23,11 @@ MAX_EDGES = 32000
 class HipContext:
     """Owns a vc_ctx (one device, one stream)."""
 
-    def __init__(self, params=None, pipeline=None, **kw):
+    def __init__(self, params=None, pipeline=None, reserve=None, **kw):
         """pipeline: None = the library's default (lock-step, or what VC_PIPE says); True / False = the persistent build
-        pipeline on / off (vc_set_pipeline); a (forward_waves, backtrack_waves) pair also sizes its two kernels."""
+        pipeline on / off (vc_set_pipeline); a (forward_waves, backtrack_waves) pair also sizes its two kernels.
+        reserve: None = workspaces are allocated under the first batch; a byte count (0 = the default budget) = allocated now,
+        in one piece, and laid out per batch without further allocations (vc_reserve)."""
         self.lib = capi.load_hip()
         self.params = params or capi.default_params(**kw)
         h = C.c_void_p()
@@ -37,6 +39,22 @@ class HipContext:
         if pipeline is not None:
             fw, bw = pipeline if isinstance(pipeline, tuple) else (0, 0)
             self._chk(self.lib.vc_set_pipeline(self.h, 1 if pipeline else 0, fw, bw), "vc_set_pipeline")
+        if reserve is not None:
+            self._chk(self.lib.vc_reserve(self.h, int(reserve)), "vc_reserve")
+
+    @classmethod
+    def in_background(cls, **kw):
+        """-> a future of a context: device start-up and vc_reserve run on a thread while the caller parses its input (the calls
+        release the GIL); `.result()` when the first batch is ready."""
+        from concurrent.futures import ThreadPoolExecutor
+        ex = ThreadPoolExecutor(1)
+        fut = ex.submit(lambda: cls(**kw))
+        ex.shutdown(wait=False)
+        return fut
+
+    def set_window_type(self, window_type):
+        self.params.window_type = int(window_type)
+        self._chk(self.lib.vc_set_window_type(self.h, int(window_type)), "vc_set_window_type")
 
     def close(self):
         if getattr(self, "h", None):

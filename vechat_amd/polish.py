@@ -79,7 +79,14 @@ def main(argv=None):
     # path (and VC_PY_PARSERS=1) goes through the Python readers, which give the same records (tests/test_seqio.py).
     native = native_parsers() and not distributed
     native_targets = None
+    ctx_kw = dict(device=device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
+                  num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
+                  max_nodes=a.max_nodes, n_streams=a.streams)
+    ctx_future = None
     if native:
+        # the device starts up and its workspaces are reserved (vc_reserve) while the files are parsed: the reference sizes its
+        # batches' device memory before the first window as well (cudapolisher.cpp:229-243)
+        ctx_future = HipContext.in_background(reserve=0, **ctx_kw)
         native_reads, overlaps, native_targets = read_inputs_native(a.sequences, a.overlaps, a.targets)
     else:
         overlaps = read_overlaps(a.overlaps)
@@ -141,9 +148,11 @@ def main(argv=None):
                 target_name = lambda t: targets[t][0]
             if kept or a.include_unpolished:
                 batch, ids = wb.build(copy=False)              # (the builder lives until the text is stitched)
-                ctx = HipContext(device=device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
-                                 num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
-                                 window_type=window_type, max_nodes=a.max_nodes, n_streams=a.streams)
+                if ctx_future is not None:
+                    ctx, ctx_future = ctx_future.result(), None
+                    ctx.set_window_type(window_type)
+                else:
+                    ctx = HipContext(window_type=window_type, **ctx_kw)
                 cons, status = ctx.consensus(batch, retry_overflow=not a.no_capacity_retry)
                 ctx.close()
                 # Every valid window is computed on the device.  What can remain is a graph beyond the 16-bit id space after the
@@ -175,6 +184,11 @@ def main(argv=None):
         if not distributed:
             raise
         failure = (1, f"{type(e).__name__}: {e}")
+    if ctx_future is not None:                                   # nothing reached the device: the context made in the background goes unused
+        try:
+            ctx_future.result().close()
+        except Exception:                                         # noqa: BLE001
+            pass
     print(f"[vechat_amd] rank {rank}/{world}: {n_targets} targets, {kept} overlaps ({n_aligned} aligned on the device), {n_windows} windows, "
           f"{n_polished} polished", file=sys.stderr)
     if distributed:
