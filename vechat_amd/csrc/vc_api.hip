@@ -140,6 +140,7 @@ struct vc_ctx {
     bool topo_hbm = false;          // k_topo of the pruned graphs from the HBM workspace
     uint32_t dbg_stop_kind = 0, dbg_stop_index = 0;   // vc_debug_stop_after: leave the chunk's graphs as they are after that stage
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
+    bool fold = true;             // launch_fwd: more than two width classes in one launch (development: VC_NO_FOLD=1 launches once per class)
     uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};
@@ -412,6 +413,14 @@ void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs, bool packed
     }
 }
 
+// lower class of a folded launch (launch_fwd), 0 when the batch's classes need no folding: what the backtrack reads the rows with
+uint32_t fold_lo(const vc_ctx* c) {
+    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
+    int lo = -1, hi = -1;
+    for (int i = 0; i < 9; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
+    return (c->fold && lo >= 0 && hi - lo > 1) ? opts[hi - 1] : 0u;
+}
+
 // One launch when the batch's sequences fall into one width class or two adjacent ones (the usual case:
 // read pieces of a window differ by a few percent in length); otherwise one launch per class.
 int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, const Work* wk = nullptr, bool nwonly = false) {
@@ -425,6 +434,9 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
     auto wide = [&]() {                     // alignments the packed-int16 kernels declined (their job_type is still 255)
         if (c->wcols && wk) { Timer t(c, KC_FWD, st); hipLaunchKernelGGL(k_fwd_wide, dim3(jobs), dim3(64), 0, st, a, wk->d_wmat, (uint64_t)c->NC * c->wcols, c->wcols, wk->d_c0w); }
     };
+    // more than two classes (partial-span layers: pieces of reads of any length): one launch built for the two widest ones, every
+    // narrower sequence in the lower of them -- four launches per layer, each waiting for its slowest alignment, become one
+    if (hi - lo > 1 && c->fold) { lo = hi - 1; a.fold = 1; }
     if (hi - lo == 1) {
         { Timer t(c, KC_FWD, st);
         switch (hi) {
@@ -528,6 +540,7 @@ struct Plan {
         fa.job_end = wk.d_job_end; fa.job_type = wk.d_job_type; fa.tie_rows = wk.d_tie_rows; fa.tie_cnt = wk.d_tie_cnt; fa.tie_list = wk.d_tie_list; fa.tie_n = wk.d_tie_n;
         fa.stat = c->d_stat; fa.wcols = c->wcols; fa.kept = c->kept;
         fa.bmat = wk.d_bmat; fa.band_par = wk.d_band_par; fa.band = c->band ? 1 : 0; fa.redo_list = nullptr; fa.redo_n = nullptr;
+        fa.fold = 0;                  // (launch_fwd decides)
         return fa;
     }
     VcTraceArgs trace_args(const Work& wk) const {
@@ -539,6 +552,7 @@ struct Plan {
         ta.stat = c->d_stat; ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC; ta.packed = c->packed ? 1 : 0; ta.kept = 0;
         ta.bmat = wk.d_bmat; ta.band_par = wk.d_band_par; ta.band = c->band ? 1 : 0; ta.redo_list = nullptr; ta.redo_n = nullptr;
         ta.redo_out = wk.d_redo_list; ta.redo_out_n = wk.d_redo_n;
+        ta.cpl_lo = fold_lo(c);       // (the pipeline sets its own)
         return ta;
     }
 
@@ -869,6 +883,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 4;      // measured: 2 -> 22.6 k, 3 -> 23.0 k, 4 -> 23.4 k windows/s on config C
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
+    c->fold = getenv("VC_NO_FOLD") == nullptr;
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
     if (const char* d = getenv("VC_PIPE")) c->pipe = std::atoi(d) != 0;
@@ -1138,6 +1153,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     // default budget: 60 % of what is free, but no more than 96 GiB -- config C runs at 97 % of its unrestricted rate with 64 GiB
     // (chunks of 4 096 windows) and at 86 % with 32 GiB (2 048), so holding more than that buys nothing (profiles/r3c_footprint.txt)
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : std::min<uint64_t>((uint64_t)(free_b * 0.6), 96ull << 30)) / S;
+    const uint64_t budget_default = budget;
     if (c->arena) budget = (c->arena_bytes - std::min<size_t>(c->arena_bytes, 1u << 20)) / S;      // vc_reserve: the arena IS the budget (less the padding between its pieces)
     const uint64_t rowd = 64ull * (c->packed ? (uint64_t)vc_nds((int)cpl) : cpl / 2);      // dwords per stored row: byte-packed (NDS per lane) or raw int16 pairs
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6 + 16) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2) + EC * 2ull + 32) +
@@ -1159,6 +1175,9 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);
     if (CW == 0) CW = 1;
+    // a reservation that cannot hold a sensible chunk of this batch does not bind the plan: the usual budget applies and what does
+    // not fit the arena is allocated piece by piece
+    if (c->arena && (per_slot_fixed + per_job) * std::min(CW, 64u) > budget) budget = std::max(budget, budget_default);
     if ((per_slot_fixed + per_job) * CW > budget) {          // as many windows per chunk as the budget holds (whole waves of 64 where it can)
         CW = (uint32_t)std::max<uint64_t>(budget / (per_slot_fixed + per_job), 1);
         if (CW > 64) CW &= ~63u;

@@ -1205,6 +1205,7 @@ struct VcFwdArgs {
     int band;                      // 1: global alignments store the band (+ whole rows where VC_RF_FULL asks for them)
     const uint32_t* redo_list;     // != nullptr: this launch re-runs the listed jobs with whole rows (the backtrack left the band)
     const uint32_t* redo_n;
+    uint32_t fold;                 // 1: the launch is built for the two widest classes of the batch and takes every narrower sequence in the lower one
 #ifdef VC_LAB
     uint32_t dbg;                  // development (tools/gpu_fwd_lab.py): parts of the row loop switched off, timing only
 #endif
@@ -1324,10 +1325,11 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     if (k >= ns) return VC_FWD_NONE;
     const uint64_t so = a.b.seq_off[s0 + k];
     const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k + 1] - so);
-    // another width class handles this sequence.  (The persistent pipeline is built for the two widest classes of a batch and
-    // takes everything narrower in the lower of them: a lane simply owns more columns than the sequence needs, the matrix is
-    // the same -- its backtrack reads the rows in the same class, VcTraceArgs::cpl_lo.)
-    if (PIPE ? len > 64u * CPL : vc_cpl_for(len) != (uint32_t)CPL) return VC_FWD_NONE;
+    // another width class handles this sequence.  (A folded launch -- the persistent pipeline always, a lock-step launch over more
+    // than two classes -- is built for the two widest classes of a batch and takes everything narrower in the lower of them: a lane
+    // simply owns more columns than the sequence needs, the matrix is the same -- its backtrack reads the rows in the same class,
+    // VcTraceArgs::cpl_lo.)
+    if ((PIPE || a.fold) ? len > 64u * CPL : vc_cpl_for(len) != (uint32_t)CPL) return VC_FWD_NONE;
     const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
     // NW or SW is fixed per instantiation (the caller looked at the layer, window.cpp:336-349): the row loop
     // then carries no alignment-type branches
@@ -1813,7 +1815,7 @@ __global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
         uint32_t cls = CB;
         if (jb.k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + jb.k + 1] - a.b.seq_off[s0 + jb.k]));
-        if (cls == (uint32_t)CA) { vc_fwd_any<CA, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb); return; }
+        if (cls == (uint32_t)CA || (a.fold && cls < (uint32_t)CA)) { vc_fwd_any<CA, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb); return; }
     }
     vc_fwd_any<CB, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb);
 }
@@ -2102,7 +2104,7 @@ __global__ void k_trace(VcTraceArgs a) {
     const uint32_t* hm32 = a.hmat + (uint64_t)job * a.hstride;
     const uint16_t* hm = (const uint16_t*)hm32;
     const int16_t* c0 = a.c0 + (uint64_t)job * a.NC;
-    const uint32_t cpl = vc_cpl_for((uint32_t)(a.b.seq_off[a.b.win_seq_off[w] + k + 1] - so)), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
+    const uint32_t cpl = max(vc_cpl_for((uint32_t)(a.b.seq_off[a.b.win_seq_off[w] + k + 1] - so)), a.cpl_lo), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
     const bool packed = a.packed != 0;
     // k_fwd stores the tilted matrix T[r][col] = H[r][col] - col*g; the tests of sisd :392-448 become
     // diagonal T == T' + (score - g), vertical T == T' + g, horizontal T == T', SW stop T == -col*g
