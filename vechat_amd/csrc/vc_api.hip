@@ -140,6 +140,7 @@ struct vc_ctx {
     bool topo_hbm = false;          // k_topo of the pruned graphs from the HBM workspace
     uint32_t dbg_stop_kind = 0, dbg_stop_index = 0;   // vc_debug_stop_after: leave the chunk's graphs as they are after that stage
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
+    uint32_t trace_tl = 8;        // lanes per alignment of the lock-step k_tracew (development: VC_TRACE_TL=16)
     bool fold = true;             // launch_fwd: more than two width classes in one launch (development: VC_NO_FOLD=1 launches once per class)
     uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
     Work works[kMaxStreams];
@@ -564,8 +565,12 @@ struct Plan {
             hipLaunchKernelGGL(k_trace, dim3((njobs + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta);
             return;
         }
-        ta.shared_table = gsz % VC_TG == 0; ta.tab_rows = std::min(max_rows, kTraceTabRows);
-        hipLaunchKernelGGL(k_tracew, dim3((njobs + VC_TG - 1) / VC_TG), dim3(VC_TG * VC_TL), vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0), wk.stream, ta);
+        // eight alignments per wave, eight lanes each (development: VC_TRACE_TL=16 -- four alignments of sixteen lanes, the form the pipeline uses)
+        const uint32_t tg = c->trace_tl == 16 ? 4u : 8u;
+        ta.shared_table = gsz % tg == 0; ta.tab_rows = std::min(max_rows, kTraceTabRows);
+        const uint32_t lds = vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0, tg);
+        if (tg == 4) hipLaunchKernelGGL(k_tracew<16>, dim3((njobs + 3) / 4), dim3(64), lds, wk.stream, ta);
+        else hipLaunchKernelGGL(k_tracew<8>, dim3((njobs + 7) / 8), dim3(64), lds, wk.stream, ta);
         if (c->wcols) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((njobs + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); ta.only_wide = 0; }
     }
 
@@ -884,6 +889,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     c->fold = getenv("VC_NO_FOLD") == nullptr;
+    if (const char* d = getenv("VC_TRACE_TL")) c->trace_tl = std::atoi(d) == 16 ? 16u : 8u;
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
     if (const char* d = getenv("VC_PIPE")) c->pipe = std::atoi(d) != 0;

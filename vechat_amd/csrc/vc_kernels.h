@@ -2209,7 +2209,7 @@ __global__ void k_trace(VcTraceArgs a) {
 // short of is LDS x time (k_fwd alone fills the LDS of every CU; a backtrack wave that waits on memory with 9 KB of tables
 // keeps a forward wave out), and distances beyond 15 are rare
 __host__ __device__ inline uint32_t vc_tracew_tab_len(uint32_t max_rows) { return (max_rows + 2 + 7) & ~7u; }     // entries per table
-__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table) { return (shared_table ? 1u : (uint32_t)VC_TG) * vc_tracew_tab_len(max_rows) / 2u; }
+__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table, uint32_t tg = VC_TG) { return (shared_table ? 1u : tg) * vc_tracew_tab_len(max_rows) / 2u; }
 __device__ __forceinline__ int vc_row_shr1(int v, int first) {          // value of the lane to the left inside a 16-lane row
     return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false);
 }
@@ -2219,13 +2219,20 @@ __device__ __forceinline__ int vc_row_shr1(int v, int first) {          // value
 // index (k_tracew), the persistent build pipeline (vc_pipe.h) from its work queue -- there the groups of a wave hold alignments
 // of different windows AND different layers.  Returns (per lane of the group) whether the alignment left the band; PIPE: the
 // caller puts it on its own redo queue instead of the launch's redo list.
-template <bool PIPE>
+template <bool PIPE, int TL = VC_TL>
 __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* smem, uint32_t job, const uint32_t slot, const uint32_t k,
                                                const uint64_t pj, bool valid, const bool redo) {
+    // TL lanes per alignment, TG = 64 / TL alignments per wave.  16 x 4: the general step looks at seven in-edges x {diagonal,
+    // vertical} + the horizontal move in one round trip.  8 x 8: three in-edges x {diagonal, vertical} + horizontal per round trip
+    // (in-degrees beyond three take another pass), the eight speculated positions of a round fill the group exactly, and a
+    // wave-instruction serves twice the alignments -- what the lock-step launches use.
+    static_assert(TL == 16 || TL == 8, "group width");
+    constexpr int TG = 64 / TL;
+    constexpr uint32_t ND_ = TL == 16 ? 7u : 3u;             // in-edges per pass of the general step; vertical candidates sit ND_ + 1 lanes up
     const int lane = vc_lane();
-    const uint32_t grp = (uint32_t)lane / VC_TL, gl = (uint32_t)lane % VC_TL, gbase = grp * VC_TL;
+    const uint32_t grp = (uint32_t)lane / TL, gl = (uint32_t)lane % TL, gbase = grp * TL;
     // first in-edge distance of row r (0: do not speculate).  In the re-alignment rounds the alignments of a
-    // wave belong to one window (group % VC_TG == 0) and share one table: a quarter of the LDS, more waves
+    // wave belong to one window (group % TG == 0) and share one table: a quarter of the LDS, more waves
     const bool shared_tab = a.shared_table != 0;
     uint8_t* tab = smem + (shared_tab ? 0u : grp) * (vc_tracew_tab_len(a.tab_rows) / 2u);       // two entries per byte
     auto tab_at = [&](uint32_t r) __attribute__((always_inline)) -> uint32_t { return ((uint32_t)tab[r >> 1] >> ((r & 1u) * 4u)) & 15u; };
@@ -2276,7 +2283,12 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
         return make_uint4((uint32_t)__shfl((int)v.x, (int)l, 64), (uint32_t)__shfl((int)v.y, (int)l, 64),
                           (uint32_t)__shfl((int)v.z, (int)l, 64), (uint32_t)__shfl((int)v.w, (int)l, 64));
     };
-    auto gmask = [&](unsigned long long mm) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(mm >> gbase) & 0xFFFFu; };
+    auto gmask = [&](unsigned long long mm) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(mm >> gbase) & ((1u << TL) - 1u); };
+    // value of the lane to the left inside the group; the group's first lane takes `first`
+    auto shr1 = [&](int v, int first) __attribute__((always_inline)) -> int {
+        const int x = vc_row_shr1(v, first);                  // (rows of 16 lanes: right for TL == 16, and for every lane but the first of an upper half-row)
+        return (TL == 8 && gl == 0) ? first : x;
+    };
 
     bool walking = valid && end != 0;
     bool gredo = false;                                       // this alignment goes on the redo list
@@ -2295,8 +2307,8 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
             return (((q.x >> 8) & VC_RF_OVF) || d0 > 15) ? 0u : d0;
         };
         // (two blocks of entries per pass: four record loads in flight per lane instead of two on a chain)
-        for (uint32_t k0 = lane; 2 * k0 <= nr; k0 += 2 * VC_TG * VC_TL) {
-            const uint32_t k1 = k0 + VC_TG * VC_TL;
+        for (uint32_t k0 = lane; 2 * k0 <= nr; k0 += 2 * TG * TL) {
+            const uint32_t k1 = k0 + TG * TL;
             const uint32_t e0 = entry(2 * k0), e1 = entry(2 * k0 + 1), e2 = entry(2 * k1), e3 = entry(2 * k1 + 1);
             tab[k0] = (uint8_t)(e0 | (e1 << 4));
             if (2 * k1 <= nr) tab[k1] = (uint8_t)(e2 | (e3 << 4));
@@ -2310,12 +2322,12 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
         };
         // (four blocks of entries per pass: eight record loads in flight per lane -- the table of a 2 200-row graph was 70 dependent
         // round trips per alignment, a sixth of a backtrack round)
-        for (uint32_t k0 = gl; walking && 2 * k0 <= nrows; k0 += 4 * VC_TL) {
+        for (uint32_t k0 = gl; walking && 2 * k0 <= nrows; k0 += 4 * TL) {
             uint32_t e[8];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) { const uint32_t k2 = k0 + u * VC_TL; e[2 * u] = entry(2 * k2); e[2 * u + 1] = entry(2 * k2 + 1); }
+            for (uint32_t u = 0; u < 4; ++u) { const uint32_t k2 = k0 + u * TL; e[2 * u] = entry(2 * k2); e[2 * u + 1] = entry(2 * k2 + 1); }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) { const uint32_t k2 = k0 + u * VC_TL; if (2 * k2 <= nrows) tab[k2] = (uint8_t)(e[2 * u] | (e[2 * u + 1] << 4)); }
+            for (uint32_t u = 0; u < 4; ++u) { const uint32_t k2 = k0 + u * TL; if (2 * k2 <= nrows) tab[k2] = (uint8_t)(e[2 * u] | (e[2 * u + 1] << 4)); }
         }
     }
     __syncthreads();
@@ -2337,7 +2349,7 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
             uint32_t ci = gi;
             bool can = walking && gi != 0 && gj != 0;
 #pragma unroll
-            for (uint32_t t = 0; t < VC_TL; t += 2) {                    // two links per iteration
+            for (uint32_t t = 0; t < TL; t += 2) {                    // two links per iteration
                 can = can && ci != 0 && gj > t && t < VC_SPECW;
                 const uint32_t d1 = (can && ci <= a.tab_rows) ? tab_at(ci) : 0u;
                 const uint32_t d2 = (can && d1 != 0 && ci - d1 != 0 && ci - d1 <= a.tab_rows) ? tab_at(ci - d1) : 0u;
@@ -2369,8 +2381,8 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
             tv = Tat(my_in, jk - 1);
             nrounds += gl == 0;
         }
-        const uint32_t codek = (uint32_t)vc_row_shr1((int)rnext.x, (int)grec.x) & 0xFF;       // code of position k's row
-        const int tprev = vc_row_shr1(tv, gT);                                               // T at position k
+        const uint32_t codek = (uint32_t)shr1((int)rnext.x, (int)grec.x) & 0xFF;       // code of position k's row
+        const int tprev = shr1(tv, gT);                                               // T at position k
         // a speculated cell outside the band confirms nothing: the walk stops in front of it and the general step decides
         bool ok = lb && !oob && tprev == tv + (((bs == codek) ? m : n) - g);
         if (!nw && tprev == -(int)jk * g) ok = false;                   // SW: the walk ends at this position
@@ -2378,7 +2390,7 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
         uint32_t f = 0;
         {
             const uint32_t gm = gmask(__ballot(ok));
-            f = (uint32_t)__ffs((int)(~gm & 0x1FFFFu)) - 1;
+            f = (uint32_t)__ffs((int)(~gm & ((2u << TL) - 1u))) - 1;
             if (!walking) f = 0;
             if (f && gnout + f > a.PC) { govf = true; walking = false; f = 0; }
         }
@@ -2406,14 +2418,14 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
             uint32_t v_pi = 0; int v_hv = 0; uint4 v_rec = zero4;
             int hz = 0;                                                  // lane 15 of the group: T[gi][gj-1]
             oob = false;
-            if (need && gl == VC_TL - 1 && gj != 0) hz = Tat(gi, gj - 1);
+            if (need && gl == TL - 1 && gj != 0) hz = Tat(gi, gj - 1);
             const bool isovf = ((grec.x >> 8) & VC_RF_OVF) != 0;
             const uint32_t np = (need && gi != 0) ? (isovf ? grec.z : ((grec.x >> 16) & 0xFF)) : 0u;
             int sc = 0;
             if (np && gj != 0) sc = ((a.b.bases[so + gj - 1] == (grec.x & 0xFF)) ? m : n) - g;
-            const bool isd = gl < 7, isv = gl >= 8 && gl < 15;
-            for (uint32_t base = 0; __any(!found && base < np); base += 7) {
-                const uint32_t p = base + (isd ? gl : gl - 8);
+            const bool isd = gl < ND_, isv = gl >= ND_ + 1 && gl < 2 * ND_ + 1;
+            for (uint32_t base = 0; __any(!found && base < np); base += ND_) {
+                const uint32_t p = base + (isd ? gl : gl - (ND_ + 1));
                 const bool act = !found && (isd || isv) && p < np && (!isd || gj != 0) && (isd || !have_v);
                 uint32_t delta = 0;
                 if (act) {
@@ -2432,9 +2444,9 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
                 }
                 const bool match = act && gT == cv + (isd ? sc : g);
                 const uint32_t gm = gmask(__ballot(match));
-                const uint32_t dm = gm & 0x7Fu, vm = (gm >> 8) & 0x7Fu;
+                const uint32_t dm = gm & ((1u << ND_) - 1u), vm = (gm >> (ND_ + 1)) & ((1u << ND_) - 1u);
                 const bool take_d = !found && dm != 0, take_v = !found && dm == 0 && vm != 0 && !have_v;
-                const uint32_t src = gbase + (dm ? (uint32_t)__ffs((int)dm) - 1 : (vm ? 8u + (uint32_t)__ffs((int)vm) - 1 : 0u));
+                const uint32_t src = gbase + (dm ? (uint32_t)__ffs((int)dm) - 1 : (vm ? ND_ + 1 + (uint32_t)__ffs((int)vm) - 1 : 0u));
                 const uint32_t s_pr = (uint32_t)__shfl((int)pr, (int)src, 64);
                 const int s_cv = __shfl(cv, (int)src, 64);
                 const uint4 s_rr = perm4(rr, src);
@@ -2449,7 +2461,7 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
                 if (need && goob) { gredo = true; walking = false; }
             }
             {
-                const int v = __shfl(hz, (int)(gbase + VC_TL - 1), 64);
+                const int v = __shfl(hz, (int)(gbase + TL - 1), 64);
                 if (need && !found && gj != 0 && gT == v) { pi_ = gi; pj_ = gj - 1; hv = v; nrec = grec; found = true; }
             }
             if (need && !gredo) {
@@ -2472,7 +2484,7 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     {   // statistics: summed over the wave first, then one of VC_STAT_SLOTS counter sets (a single set serialises in the L2)
         uint32_t s0 = (valid && gl == 0) ? gnout : 0u, s1 = (valid && gl == 0) ? nspec_ok : 0u, s2 = (valid && gl == 0) ? nrounds : 0u;
 #pragma unroll
-        for (int o = VC_TL; o < VC_TG * VC_TL; o <<= 1) { s0 += (uint32_t)__shfl_xor((int)s0, o, 64); s1 += (uint32_t)__shfl_xor((int)s1, o, 64); s2 += (uint32_t)__shfl_xor((int)s2, o, 64); }
+        for (int o = TL; o < TG * TL; o <<= 1) { s0 += (uint32_t)__shfl_xor((int)s0, o, 64); s1 += (uint32_t)__shfl_xor((int)s1, o, 64); s2 += (uint32_t)__shfl_xor((int)s2, o, 64); }
         if (lane == 0) {
             unsigned long long* st = vc_stat_slot(a.stat);
             atomicAdd(st + 4, (unsigned long long)s0); atomicAdd(st + 5, (unsigned long long)s1); atomicAdd(st + 6, (unsigned long long)s2);
@@ -2481,23 +2493,25 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     return valid && gredo;
 }
 
+template <int TL>
 __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t grp = (uint32_t)vc_lane() / VC_TL;
+    constexpr int TG = 64 / TL;
+    const uint32_t grp = (uint32_t)vc_lane() / TL;
     const uint32_t njobs = a.nslots * a.group;
     const bool redo = a.redo_list != nullptr;
-    uint32_t job = blockIdx.x * VC_TG + grp;
+    uint32_t job = blockIdx.x * TG + grp;
     bool valid = job < njobs;
     if (redo) {                                               // second pass: the jobs the first one gave up on
         const uint32_t nr = *a.redo_n;
-        if (blockIdx.x * VC_TG >= nr) return;
+        if (blockIdx.x * TG >= nr) return;
         valid = job < nr;
         job = valid ? a.redo_list[job] : 0u;
     }
     const uint32_t slot = valid ? job / a.group : 0, k = valid ? a.k0 + job % a.group : 0;
     const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
-    (void)vc_tracew_body<false>(a, smem, job, slot, k, pj, valid, redo);
+    (void)vc_tracew_body<false, TL>(a, smem, job, slot, k, pj, valid, redo);
 }
 
 // ------------------------------------------------------------------------------------------------
