@@ -51,7 +51,8 @@ constexpr int kRing = VC_RING;      // build phase: DP rows kept in LDS per alig
 constexpr int kKept = VC_KEPT;      // build phase: slots of the kept-row ring (0: plain ring of kRing rows); see vc_frec_kept
 constexpr int kRingPruned = VC_RING_PRUNED;   // re-alignment rounds and the final alignment: a pruned graph is nearly a chain, four rows hold
                                               // its non-adjacent predecessors, and the smaller ring lets a fifth / sixth wave onto each SIMD
-constexpr int kMaxStreams = 8;
+constexpr int kMaxStreams = 16;
+constexpr uint32_t kAutoStreamsMany = 8, kAutoStreamsFew = 4, kAutoStreamsFrom = 12288;   // windows from which a batch runs on the larger number of chunk streams
 constexpr uint32_t kTraceTabRows = 8188;           // rows covered by k_tracew's first-in-edge table (4 tables x 2 B x 8192 = 64 KB); later rows are walked without speculation
 constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may ask for (160 KB per CU minus room for static __shared__)
 constexpr uint32_t kMaxColumns = 2048;     // longest sequence the packed-int16 k_fwd takes (64 lanes x 32 columns); longer ones go to k_fwd_wide
@@ -110,6 +111,8 @@ struct vc_ctx {
     uint64_t chunk_bytes = 0;           // what they hold: counts as available when the next batch is planned
     char* arena = nullptr;              // vc_reserve: one allocation the workspaces are carved from (a change of shape then costs no hipFree / hipMalloc)
     size_t arena_bytes = 0, arena_used = 0;
+    bool auto_streams = false;          // vc_params.n_streams was 0: vc_submit picks the chunk streams per batch
+    uint32_t streams_made = 0;          // streams created (>= n_streams)
     bool have_ws = false;               // workspaces exist (out of the arena or allocated piece by piece)
 
     bool have_batch = false, ran = false;
@@ -885,7 +888,12 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     vc_ctx* c = new vc_ctx();
     c->prm = *p;
     c->device = p->device;
-    c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 4;      // measured: 2 -> 22.6 k, 3 -> 23.0 k, 4 -> 23.4 k windows/s on config C
+    // vc_params.n_streams = 0: the batch decides (vc_submit).  Round 4, after the backtrack got lighter: 8 chunk streams beat 4 by 4-8 %
+    // from 16 384 windows up (config C, 100 000 windows: 32.4 -> 34.4 k windows/s), are level at 8 192 and lose at 4 000, where a chunk
+    // of 500 windows no longer fills a launch
+    c->auto_streams = p->n_streams == 0;
+    c->n_streams = p->n_streams ? std::min<uint32_t>(p->n_streams, kMaxStreams) : 4;
+    c->streams_made = c->auto_streams ? kAutoStreamsMany : c->n_streams;
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     c->fold = getenv("VC_NO_FOLD") == nullptr;
@@ -908,7 +916,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     const int n_prio = prio_least - prio_greatest + 1;
-    for (uint32_t s = 0; s < c->n_streams; ++s) {
+    for (uint32_t s = 0; s < c->streams_made; ++s) {
         const int prio = n_prio > 1 && !getenv("VC_SAME_PRIORITY") ? prio_least - (int)(s % (uint32_t)n_prio) : 0;
         if (hipStreamCreateWithPriority(&c->streams[s], hipStreamNonBlocking, prio) != hipSuccess) {
             delete c;
@@ -1073,6 +1081,10 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     }
     }
     sync_ctx(c);                                          // only this context's streams: another context may be running
+    if (c->auto_streams) {
+        const uint32_t want = nw >= kAutoStreamsFrom ? kAutoStreamsMany : kAutoStreamsFew;
+        if (want != c->n_streams) { free_workspaces(c); c->n_streams = want; }
+    }
     c->have_batch = false; c->ran = false;
     VcBatchDev& b = c->b;
     b = VcBatchDev{};
