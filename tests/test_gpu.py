@@ -255,6 +255,43 @@ def test_reserved_workspace_serves_batches_of_any_shape(built):
     tiny.close()
 
 
+def test_launch_plans_of_round_four_agree(built, monkeypatch):
+    """Three choices the host makes for speed must not show in the bytes: layers whose sequences fall into more than two width
+    classes run as ONE forward launch built for the two widest (VC_NO_FOLD=1: one launch per class); the backtrack walks eight
+    alignments of eight lanes per wave (VC_TRACE_TL=16: four of sixteen); the chunk streams are picked per batch."""
+    batch = capi.synth_batch(capi.synth_cfg(71, 500, 20, frac_partial=0.5, n_haplotypes=2, snp_rate=0.02), 0, 48)
+    lens = np.diff(batch.seq_off)
+    classes = {next(c for c in (4, 6, 8, 10, 12, 16, 20, 24, 32) if 64 * c >= int(x)) for x in lens if x > 0}      # vc_cpl_for
+    assert len(classes) > 2                                                   # the batch really spans more than two width classes
+    out = []
+    for env in ({}, {"VC_NO_FOLD": "1"}, {"VC_TRACE_TL": "16"}, {"VC_NO_FOLD": "1", "VC_TRACE_TL": "16"}):
+        for k in ("VC_NO_FOLD", "VC_TRACE_TL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = HipContext(device=0, chunk_windows=16)
+        cons, status = c.consensus(batch)
+        st = c.stats()
+        out.append((cons, [int(x) for x in status], st["cells"], st["trace_steps"]))
+        assert st["n_streams"] == 4                                           # a small batch: four chunk streams
+        c.close()
+    assert all(o == out[0] for o in out[1:])
+    ref, _, _ = oa.oracle_run(batch, capi.default_params(), 0, 8)
+    assert out[0][0][:8] == list(ref)
+    # from 12 288 windows up a context with n_streams = 0 takes eight streams; an explicit count is kept
+    many = capi.synth_batch(capi.synth_cfg(72, 60, 3), 0, 12288)
+    c = HipContext(device=0)
+    c.submit(many); c.run(); c.sync()
+    assert c.stats()["n_streams"] == 8
+    c.submit(batch); c.run(); c.sync()
+    assert c.stats()["n_streams"] == 4 and c.collect()[0] == out[0][0]
+    c.close()
+    c = HipContext(device=0, n_streams=3)
+    c.submit(many); c.run(); c.sync()
+    assert c.stats()["n_streams"] == 3
+    c.close()
+
+
 def test_prune_parameters_and_rounds(built):
     batch = capi.synth_batch(capi.synth_cfg(41, 180, 14, n_haplotypes=2, snp_rate=0.03), 0, 6)
     for kw in (dict(num_prune=1), dict(num_prune=2), dict(num_prune=4, min_confidence=0.22, min_support=0.19),

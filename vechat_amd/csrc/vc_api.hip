@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <cstdarg>
@@ -147,7 +148,8 @@ struct vc_ctx {
     bool fold = true;             // launch_fwd: more than two width classes in one launch (development: VC_NO_FOLD=1 launches once per class)
     uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
     Work works[kMaxStreams];
-    hipStream_t streams[kMaxStreams]{};
+    hipStream_t streams[kMaxStreams]{};      // the process's chunk streams of this device (pooled_stream): not owned
+    hipStream_t own_stream = nullptr;        // this context's stream for copies, fills and small kernels
     // One host thread per chunk stream drives its chunks through the phases (vc_run starts them, vc_sync joins them): the one
     // host wait of the path -- the pruned graphs' height before a re-alignment round -- then stalls that stream only, and a
     // stream takes its next chunk as soon as it is done (no lockstep between streams, no barrier between groups of chunks).
@@ -193,6 +195,33 @@ int fail(vc_ctx* c, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                      \
         if (e_ != hipSuccess) return fail((c), VC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// Chunk streams are a property of the PROCESS, not of a context.  HIP maps streams onto a small pool of hardware queues by creation
+// order and priority (see vc_create); a second context that created eight streams of its own ran 18 % slower beside an idle first one
+// (26.9 against 32.8 k windows/s, tools/gpu_probe_ctx.py) because its streams landed on shared queues.  So every context of a device
+// takes stream s from the same per-device set, made once and kept: the mapping any context sees is the one a lone context sees.
+// Contexts that run at the same time then interleave their launches on the same streams, which orders them but changes no result.
+struct StreamSet {
+    hipStream_t chunk[kMaxStreams]{};          // the chunk streams, priorities cycling (never two neighbours on one hardware queue)
+    hipStream_t side[kMaxStreams]{};           // persistent pipeline only: the stream its backtrack kernel runs on beside chunk stream s
+};
+std::mutex g_streams_mu;
+std::map<int, StreamSet> g_streams;            // by device
+
+int stream_priority(uint32_t s, uint32_t shift) {
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const int n_prio = prio_least - prio_greatest + 1;
+    return n_prio > 1 && !getenv("VC_SAME_PRIORITY") ? prio_least - (int)((s + shift) % (uint32_t)n_prio) : 0;
+}
+// stream s of the device's set (made on first use); side = the pipeline's second stream.  nullptr: creation failed
+hipStream_t pooled_stream(int device, uint32_t s, bool side) {
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    StreamSet& set = g_streams[device];
+    hipStream_t& st = side ? set.side[s] : set.chunk[s];
+    if (!st && hipStreamCreateWithPriority(&st, hipStreamNonBlocking, stream_priority(s, side ? 1u : 0u)) != hipSuccess) st = nullptr;
+    return st;
+}
 
 template <typename T>
 int dalloc(vc_ctx* c, std::vector<void*>& list, T** out, size_t n) {
@@ -665,6 +694,10 @@ struct Plan {
         p.prof = c->d_pipe_prof;
         p.pub_time = getenv("VC_PIPE_PUBTIME") ? reinterpret_cast<unsigned long long*>(wk.d_scratch16 + (size_t)c->CW * (4 * PC + NC)) - c->CW : nullptr;   // development: tail of the note blocks
         p.spin_limit = c->pipe_patience_s * 100000000u;       // ticks of the 100 MHz clock: this long without an item is a protocol error
+        if (!wk.st_t) {                                       // the backtrack kernel's stream beside this chunk stream, on first use
+            wk.st_t = pooled_stream(c->device, (uint32_t)(&wk - c->works), true);
+            if (!wk.st_t) return fail(c, VC_ERR_HIP, "hipStreamCreate failed");
+        }
         hipLaunchKernelGGL(k_pipe_seed, dim3((ns + 255) / 256), dim3(256), 0, wk.stream, c->b, p, wk.w0, ns);
         HIPCHK(c, hipEventRecord(wk.ev_seed, wk.stream));
         HIPCHK(c, hipStreamWaitEvent(wk.st_t, wk.ev_seed, 0));
@@ -913,27 +946,20 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     // and serialise -- it depends on how many streams the process created before (measured: with RCCL
     // initialised first the 2-stream rate dropped from 19.9 k to 15.9 k windows/s).  Streams of different
     // priority never share a hardware queue, so the chunk streams cycle through the priority levels.
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    const int n_prio = prio_least - prio_greatest + 1;
+    // (the streams themselves belong to the process: pooled_stream)
     for (uint32_t s = 0; s < c->streams_made; ++s) {
-        const int prio = n_prio > 1 && !getenv("VC_SAME_PRIORITY") ? prio_least - (int)(s % (uint32_t)n_prio) : 0;
-        if (hipStreamCreateWithPriority(&c->streams[s], hipStreamNonBlocking, prio) != hipSuccess) {
-            delete c;
-            return fail(nullptr, VC_ERR_HIP, "hipStreamCreate failed");
-        }
+        c->streams[s] = pooled_stream(c->device, s, false);
+        if (!c->streams[s]) { delete c; return fail(nullptr, VC_ERR_HIP, "hipStreamCreate failed"); }
         c->works[s].stream = c->streams[s];
         if (hipHostMalloc((void**)&c->works[s].h_maxn, 64) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipHostMalloc failed"); }
-        // the backtrack and resolver kernels of the persistent pipeline must run BESIDE the forward kernel of their chunk: streams of
-        // their own, at other priorities than the chunk stream (never the same hardware queue, see above)
         Work& wk = c->works[s];
-        const int pt = n_prio > 1 ? prio_least - (int)((s + 1) % (uint32_t)n_prio) : 0;
-        if (hipStreamCreateWithPriority(&wk.st_t, hipStreamNonBlocking, pt) != hipSuccess ||
-            hipEventCreateWithFlags(&wk.ev_seed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&wk.ev_t, hipEventDisableTiming) != hipSuccess) {
-            delete c; return fail(nullptr, VC_ERR_HIP, "stream / event creation failed");
+        if (hipEventCreateWithFlags(&wk.ev_seed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&wk.ev_t, hipEventDisableTiming) != hipSuccess) {
+            delete c; return fail(nullptr, VC_ERR_HIP, "event creation failed");
         }
     }
-    c->stream = c->streams[0];
+    // the context's own stream for its copies, fills and small kernels: those must be able to run beside another context's chunks
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipStreamCreate failed"); }
+    c->stream = c->own_stream;
     // lookup tables from this host's libm, like the reference computes them (graph.cpp:169, window.cpp:235)
     uint32_t lw[256]; double ld[256];
     vc_weight_lut(lw);
@@ -963,10 +989,9 @@ void vc_destroy(vc_ctx* c) {
     for (int i = 0; i < 2; ++i) { if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); }
     for (uint32_t s = 0; s < kMaxStreams; ++s) {
         if (c->works[s].h_maxn) (void)hipHostFree(c->works[s].h_maxn);
-        if (c->works[s].st_t) (void)hipStreamDestroy(c->works[s].st_t);
         for (hipEvent_t e : {c->works[s].ev_seed, c->works[s].ev_t}) if (e) (void)hipEventDestroy(e);
-        if (c->streams[s]) (void)hipStreamDestroy(c->streams[s]);
     }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -1348,7 +1373,7 @@ int vc_sync(vc_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     join_workers(c);
     for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s]));
-    for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->works[s].st_t));
+    for (uint32_t s = 0; s < c->n_streams; ++s) if (c->works[s].st_t) HIPCHK(c, hipStreamSynchronize(c->works[s].st_t));
     if (c->prm.profile) flush_events(c);
     if (c->run_rc.load() != VC_OK) { c->ran = false; return c->run_rc.load(); }
     HIPCHK(c, hipGetLastError());
