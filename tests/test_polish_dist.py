@@ -20,8 +20,18 @@ from vechat_amd import capi
 class OracleContext:
     """Stand-in for vechat_amd.engine.HipContext in this test only."""
 
-    def __init__(self, device=0, **kw):
+    def __init__(self, device=0, reserve=None, **kw):
         self.params = capi.default_params(**kw)
+
+    @classmethod
+    def in_background(cls, **kw):                       # (polish starts its context while it parses: HipContext.in_background)
+        from concurrent.futures import Future
+        f = Future()
+        f.set_result(cls(**kw))
+        return f
+
+    def set_window_type(self, window_type):
+        self.params.window_type = int(window_type)
 
     def consensus(self, batch, retry_overflow=True):
         cons, pol, _ = oa.oracle_run(batch, self.params)
