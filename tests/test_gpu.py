@@ -380,6 +380,15 @@ def test_sequences_beyond_2048_columns_and_int32_scores(built):
     c = HipContext(device=0, match=5, mismatch=-4, gap=-8)          # -8 * (len + 8 + rows) passes -31744 around 3 000 rows
     _check(c, deep, "int32 score range")
     c.close()
+    # (round 4: the 3 kb windows above now fit the packed kernel -- width classes of 48 and 64 columns per lane, int16 judged on the
+    # tilted matrix, vc_int16_ok -- so k_fwd_wide is met here: layers beyond 4 096 columns, a gap score that leaves int16 on rows alone)
+    wider = capi.synth_batch(capi.synth_cfg(3004, 4400, 5, frac_partial=0.2), 0, 2)
+    c = HipContext(device=0)
+    _check(c, wider, "4.4 kb windows")
+    c.close()
+    c = HipContext(device=0, match=3, mismatch=-5, gap=-40)
+    _check(c, capi.synth_batch(capi.synth_cfg(3005, 600, 10), 0, 3), "gap -40")
+    c.close()
     c = HipContext(device=0, match=2, mismatch=-3, gap=-12, sw_match=4, sw_mismatch=1, sw_gap=-2)     # unusual signs and magnitudes
     _check(c, capi.synth_batch(capi.synth_cfg(3003, 300, 16, frac_partial=0.3), 0, 4), "odd scores")
     c.close()

@@ -56,7 +56,7 @@ constexpr int kMaxStreams = 16;
 constexpr uint32_t kAutoStreamsMany = 8, kAutoStreamsFew = 4, kAutoStreamsFrom = 12288;   // windows from which a batch runs on the larger number of chunk streams
 constexpr uint32_t kTraceTabRows = 8188;           // rows covered by k_tracew's first-in-edge table (4 tables x 2 B x 8192 = 64 KB); later rows are walked without speculation
 constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may ask for (160 KB per CU minus room for static __shared__)
-constexpr uint32_t kMaxColumns = 2048;     // longest sequence the packed-int16 k_fwd takes (64 lanes x 32 columns); longer ones go to k_fwd_wide
+constexpr uint32_t kMaxColumns = 4096;     // longest sequence the packed-int16 k_fwd takes (64 lanes x 64 columns); longer ones go to k_fwd_wide
 constexpr uint32_t kResolveGrid = 128;   // workgroups of k_resolve (each owns one DFS workspace in HBM)
 
 uint32_t topo_lds_bytes(uint32_t NC, uint32_t EC, uint32_t STK, uint32_t MA) {
@@ -112,6 +112,7 @@ struct vc_ctx {
     uint64_t chunk_bytes = 0;           // what they hold: counts as available when the next batch is planned
     char* arena = nullptr;              // vc_reserve: one allocation the workspaces are carved from (a change of shape then costs no hipFree / hipMalloc)
     size_t arena_bytes = 0, arena_used = 0;
+    bool ws_packed = false;             // the workspaces hold band space (the batch they were made for stores byte-packed rows)
     bool auto_streams = false;          // vc_params.n_streams was 0: vc_submit picks the chunk streams per batch
     uint32_t streams_made = 0;          // streams created (>= n_streams)
     bool have_ws = false;               // workspaces exist (out of the arena or allocated piece by piece)
@@ -314,7 +315,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, c->hmat_dwords / 4 + (VC_BAND_TILED ? c->hmat_dwords / 16 : 0) + (size_t)c->jobs_cap * VC_BAND_JOB_PAD_DWORDS + 64)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, (c->ws_packed ? c->hmat_dwords / 4 + (VC_BAND_TILED ? c->hmat_dwords / 16 : 0) + (size_t)c->jobs_cap * VC_BAND_JOB_PAD_DWORDS : 0) + 64)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_band_par, (size_t)c->jobs_cap * 2)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_list, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_n, 4)) ||
@@ -448,9 +449,9 @@ void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs, bool packed
 
 // lower class of a folded launch (launch_fwd), 0 when the batch's classes need no folding: what the backtrack reads the rows with
 uint32_t fold_lo(const vc_ctx* c) {
-    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
+    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
     int lo = -1, hi = -1;
-    for (int i = 0; i < 9; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
+    for (int i = 0; i < 11; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
     return (c->fold && lo >= 0 && hi - lo > 1) ? opts[hi - 1] : 0u;
 }
 
@@ -458,11 +459,11 @@ uint32_t fold_lo(const vc_ctx* c) {
 // read pieces of a window differ by a few percent in length); otherwise one launch per class.
 int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, const Work* wk = nullptr, bool nwonly = false) {
     if (c->dup & 16u) { const uint32_t d = c->dup; c->dup = 0; (void)launch_fwd(c, st, a0, jobs, wk, nwonly); c->dup = d; (void)hipMemsetAsync(a0.tie_n, 0, 4, st); }
-    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
+    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
     VcFwdArgs a = a0;
     a.do_init = 1;
     int lo = -1, hi = -1;
-    for (int i = 0; i < 9; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
+    for (int i = 0; i < 11; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
     if (lo < 0 || hi < 0) return fail(c, VC_ERR_ARG, "unsupported cells-per-lane %u..%u", c->cpl_min, c->cpl);
     auto wide = [&]() {                     // alignments the packed-int16 kernels declined (their job_type is still 255)
         if (c->wcols && wk) { Timer t(c, KC_FWD, st); hipLaunchKernelGGL(k_fwd_wide, dim3(jobs), dim3(64), 0, st, a, wk->d_wmat, (uint64_t)c->NC * c->wcols, c->wcols, wk->d_c0w); }
@@ -484,6 +485,8 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
             case 6: launch_fwd_t<16, 20>(st, a, jobs, c->packed, nwonly); break;
             case 7: launch_fwd_t<20, 24>(st, a, jobs, c->packed, nwonly); break;
             case 8: launch_fwd_t<24, 32>(st, a, jobs, c->packed, nwonly); break;
+            case 9: launch_fwd_t<32, 48>(st, a, jobs, c->packed, nwonly); break;
+            case 10: launch_fwd_t<48, 64>(st, a, jobs, c->packed, nwonly); break;
 #else
             default: return fail(c, VC_ERR_ARG, "development build: width classes 8 / 10 only");
 #endif
@@ -507,6 +510,8 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
             case 20: launch_fwd_t<20, 20>(st, a, jobs, c->packed, nwonly); break;
             case 24: launch_fwd_t<24, 24>(st, a, jobs, c->packed, nwonly); break;
             case 32: launch_fwd_t<32, 32>(st, a, jobs, c->packed, nwonly); break;
+            case 48: launch_fwd_t<48, 48>(st, a, jobs, c->packed, nwonly); break;
+            case 64: launch_fwd_t<64, 64>(st, a, jobs, c->packed, nwonly); break;
 #else
             default: return fail(c, VC_ERR_ARG, "development build: width classes 8 / 10 only");
 #endif
@@ -528,9 +533,9 @@ int launch_pipe_fwd_t(vc_ctx* c, hipStream_t st, const VcPipeFwdArgs& a, uint32_
 // The pipeline's forward kernel is built for the widest class of the batch and the one below it (everything narrower runs
 // in that lower class: partial-span layers are short).  -> (CA, CB), CA == CB when the batch has one class.
 bool pipe_classes(const vc_ctx* c, uint32_t* ca, uint32_t* cb) {
-    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
+    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
     int lo = -1, hi = -1;
-    for (int i = 0; i < 9; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
+    for (int i = 0; i < 11; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
     if (lo < 0 || hi < 0) return false;
     *cb = opts[hi]; *ca = lo < hi ? opts[hi - 1] : opts[hi];
 #ifdef VC_FAST_BUILD
@@ -553,7 +558,7 @@ int launch_pipe_fwd(vc_ctx* c, hipStream_t st, const VcPipeFwdArgs& a, uint32_t 
 }
 
 uint32_t pick_cpl(uint32_t max_len) {
-    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
+    const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
     for (uint32_t o : opts) if (64 * o >= max_len) return o;
     return 0;
 }
@@ -1201,20 +1206,17 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint64_t rowd = 64ull * (c->packed ? (uint64_t)vc_nds((int)cpl) : cpl / 2);      // dwords per stored row: byte-packed (NDS per lane) or raw int16 pairs
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6 + 16) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2) + EC * 2ull + 32) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
-    // Can any alignment of this batch leave the packed-int16 kernel's envelope (vc_fwd_body's check: the reference's int16
-    // rule, simd impl:699-706, on the worst case the capacities allow)?  Then k_fwd_wide and its int32 matrices are needed.
+    // Can any alignment of this batch leave the packed-int16 kernel's envelope (vc_fwd_body's check, vc_int16_ok, on the worst
+    // case the capacities allow)?  Then k_fwd_wide and its int32 matrices are needed.
     bool maybe_wide = ws_max_len > kMaxColumns || (have_ws && c->wcols);
-    for (int sw = 0; sw < 2; ++sw) {
-        const long long mm = sw ? c->prm.sw_match : c->prm.match, nn = sw ? c->prm.sw_mismatch : c->prm.mismatch, gg = sw ? c->prm.sw_gap : c->prm.gap;
-        const long long li = (long long)std::min(ws_max_len, kMaxColumns) + 8, lj = NC, mn = std::min(li, lj), d = li > lj ? li - lj : lj - li;
-        const long long wc = std::min(-(mm * mn + (d ? gg * d : 0)), gg * li + gg * lj);
-        if (wc < -31744 || (mm - gg) * (64ll * cpl + 1) >= 32767 || (sw && nn >= 0)) maybe_wide = true;
-    }
+    if (!vc_int16_ok(c->prm.match, c->prm.mismatch, c->prm.gap, NC, cpl, true) ||
+        !vc_int16_ok(c->prm.sw_match, c->prm.sw_mismatch, c->prm.sw_gap, NC, cpl, false)) maybe_wide = true;
     const uint32_t wcols = maybe_wide ? ((ws_max_len + 64 * VC_WIDE_CPL - 1) / (64 * VC_WIDE_CPL)) * (64 * VC_WIDE_CPL) : 0;
-    // (the int32 matrices of k_fwd_wide are 86 MB per alignment at 7 040 rows x 3 072 columns: there the chunk size IS the budget,
-    // and the 96-GiB cap above would halve it)
-    if (maybe_wide && !c->prm.scratch_bytes && !c->arena) budget = (uint64_t)(free_b * 0.6) / S;
-    const uint64_t per_job = NC * rowd * 5 + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
+    // whole rows, + a quarter for the band where rows are byte-packed (raw int16 rows -- wide classes, unusual scores -- have no band)
+    const uint64_t per_job = NC * rowd * (c->packed ? 5 : 4) + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
+    // big alignments (3 kb reads: 58 MB of raw rows each; the int32 matrices of k_fwd_wide: 86 MB more): there the chunk size IS the
+    // budget, and the 96-GiB cap would leave a few hundred alignments per stream -- take the 60 % whole
+    if (!c->prm.scratch_bytes && !c->arena && (per_slot_fixed + per_job) * 1024ull > budget) budget = std::max<uint64_t>(budget, (uint64_t)(free_b * 0.6) / S);
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);
     if (CW == 0) CW = 1;
@@ -1231,11 +1233,11 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint32_t group_max = 1 + (uint32_t)std::min<uint64_t>(spare / (per_job * CW), 7);
     if (group_max > max_nseq) group_max = max_nseq;
 
-    const bool same = have_ws && c->wcols == wcols && c->MA == MA && c->NC == NC && c->EC == EC && c->CW >= CW && c->ws_cpl == cpl && c->PC == PC &&
+    const bool same = have_ws && c->ws_packed == c->packed && c->wcols == wcols && c->MA == MA && c->NC == NC && c->EC == EC && c->CW >= CW && c->ws_cpl == cpl && c->PC == PC &&
                       c->big_ws_stride == big && c->max_nseq == max_nseq;
     if (!same) {
         free_workspaces(c);
-        c->wcols = wcols; c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->ws_cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
+        c->ws_packed = c->packed; c->wcols = wcols; c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->ws_cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
         c->ws_max_len = ws_max_len;
         c->big_ws_stride = big;
         // re-alignment rounds work on pruned graphs (a quarter of NC rows, typically), so more alignments per window fit the

@@ -65,9 +65,24 @@ __device__ __forceinline__ uint32_t vc_weight(const VcBatchDev& b, uint64_t off,
 
 // columns-per-lane class of a sequence: the smallest instantiated k_fwd width that holds it
 __host__ __device__ inline uint32_t vc_cpl_for(uint32_t len) {
-    const uint32_t opts[9] = {4, 6, 8, 10, 12, 16, 20, 24, 32};
-    for (int i = 0; i < 9; ++i) if (64 * opts[i] >= len) return opts[i];
+    const uint32_t opts[11] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
+    for (int i = 0; i < 11; ++i) if (64 * opts[i] >= len) return opts[i];
     return 0;
+}
+
+// Does a linear-gap alignment of `len` columns against `nrows` rows stay inside int16 in the form k_fwd computes it?  The reference
+// asks this of the plain matrix H, whose worst case is g * (len + nrows) (simd_alignment_engine_implementation.hpp:699-706), and
+// switches to 32-bit lanes beyond it; that decides its speed, not its result.  k_fwd works on the TILTED matrix T = H - j*g: a
+// horizontal step leaves T unchanged, so along any path a cell falls only by the rows it crosses -- T >= -rows * max(|g|, |n - g|)
+// for a global alignment (column 0 is H[i][0] >= g * i, the virtual row is 0), T >= 0 for a local one -- and rises by at most
+// m - g per column.  1 024 of headroom below, as before.  (Round 4: 3 kb reads against a 7 000-row graph fit; they used to go
+// to the int32 kernel on H's account.)
+__host__ __device__ inline bool vc_int16_ok(long long m, long long n, long long g, long long nrows, long long cpl, bool nw) {
+    if (g >= 0 || (!nw && n >= 0)) return false;
+    long long dec = -g;
+    if (-(n - g) > dec) dec = -(n - g);
+    const long long lo = nw ? -(nrows + 8) * dec : 0;
+    return lo >= -31744 && (m - g) * (64 * cpl + 1) < 32767;
 }
 
 // floor(x / d) == umulhi(x, vc_magic(d)) for x < 65536 and 2 <= d <= 64
@@ -1343,18 +1358,11 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     const int m = nw ? a.m : a.sm, n = nw ? a.n : a.sn, g = nw ? a.g : a.sg;
     const uint32_t nrows = a.dp.nrows[slot];
     const uint64_t nb = (uint64_t)slot * a.NC;
-    // envelope: the reference's int16 condition (simd impl:699-706) on the real length, plus headroom
-    // for H - j*g and for the cells this kernel computes beyond the sequence end.  The SW end-cell rule
-    // below also relies on negative mismatch / gap scores (cells past the sequence end can then never
-    // strictly exceed the best real cell).
+    // envelope: int16 on the tilted matrix (vc_int16_ok), the sequence inside this instantiation's columns.  The SW end-cell rule
+    // below also relies on negative mismatch / gap scores (cells past the sequence end can then never strictly exceed the best
+    // real cell).
     {
-        long long li = (long long)len + 8, lj = nrows;
-        long long d = li > lj ? li - lj : lj - li, mn = li < lj ? li : lj;
-        long long wc1 = -1 * ((long long)m * mn + (d == 0 ? 0 : (long long)g * d));
-        long long wc2 = (long long)g * li + (long long)g * lj;
-        long long wc = wc1 < wc2 ? wc1 : wc2;
-        bool ok = wc >= -31744 && ((long long)(m - g) * (64 * CPL + 1) < 32767) && len <= 64u * CPL && len > 0 &&
-                  nrows > 0 && !(a.dp.flags[slot] & 1u) && g < 0 && (nw || n < 0);
+        const bool ok = vc_int16_ok(m, n, g, nrows, CPL, nw) && len <= 64u * CPL && len > 0 && nrows > 0 && !(a.dp.flags[slot] & 1u);
         if (!ok) {
             // outside the packed-int16 envelope: not an error -- the job keeps type 255 and k_fwd_wide (int32 lanes, any
             // length, like the reference's fallback to 32-bit lanes, simd impl:699-706) takes it
