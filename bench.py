@@ -255,7 +255,7 @@ def main():
     ap.add_argument("--config", default=None, choices=["C", "D", "E", "W"],
                     help="BASELINE.json configuration: C = 100 000 windows of 500 bp x 64 reads on one GPU (default at --gpus 1..7); D = 1 M such windows "
                          "over 8 GPUs (125 000 per rank; default at --gpus 8); E = 50 000 ONT windows of 1 kb x 128 reads over the ranks; "
-                         "W = 3 kb x 12 reads, the int32 wide-column kernel (k_fwd_wide)")
+                         "W = 3 kb x 12 reads (-w 3000 windows: the widest classes of the packed kernel)")
     ap.add_argument("--windows", type=int, default=0, help="distinct windows per GPU per step (0: what --config says)")
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--length", type=int, default=0)
@@ -459,7 +459,7 @@ def main():
                        "identical_to_resident_run": all(cons_np[off[w]:off[w + 1]].tobytes() == cons_e2e[w] for w in range(0, n, 97))}
         line["configs"] = {"B": short_config(local, 1001, 500, 32, 10000, capi.PACBIO, check=256),
                            "E": short_config(local, 1005, 1000, 128, 4096, capi.ONT),
-                           "W": short_config(local, 1007, 3000, 12, 1024, capi.PACBIO),      # every alignment on k_fwd_wide (int32, column tiles)
+                           "W": short_config(local, 1007, 3000, 12, 1024, capi.PACBIO, check=64),      # 3 kb windows: width classes 48 / 64 of the packed kernel (k_fwd_wide until round 4)
                            # the hard cases of SURVEY 8(d): partial-span layers (Subgraph + local re-alignment), two haplotypes
                            # (graphs that stay branched after pruning), and the per-rank shards of configs D and E on this one GPU
                            # the other execution plan of the build loop, on the same workload (32 768 windows of config C)

@@ -386,6 +386,11 @@ def test_sequences_beyond_2048_columns_and_int32_scores(built):
     c = HipContext(device=0)
     _check(c, wider, "4.4 kb windows")
     c.close()
+    edge = capi.synth_batch(capi.synth_cfg(3006, 3400, 14), 0, 2)        # the graph passes 7 928 rows (-31 744 / gap) on its way up:
+    c = HipContext(device=0)                                              # early layers on the packed kernel, late ones on k_fwd_wide
+    _check(c, edge, "rows across the int16 bound")
+    assert c.stats()["max_nodes"] > 7928
+    c.close()
     c = HipContext(device=0, match=3, mismatch=-5, gap=-40)
     _check(c, capi.synth_batch(capi.synth_cfg(3005, 600, 10), 0, 3), "gap -40")
     c.close()
