@@ -1649,6 +1649,10 @@ int vc_get_stats(vc_ctx* c, vc_stats* s) {
         for (auto& sl : c->slots) held += sl.cap;
         c->stats.device_bytes = held;
     }
+#ifdef VC_ADD_PROF
+    { unsigned long long h[8] = {0}; (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(vc_add_prof), sizeof(h));
+      fprintf(stderr, "[add prof] waves %llu  ticks per wave: A %llu  B %llu  C %llu  D %llu  rows %llu\n", h[7], h[7] ? h[0] / h[7] : 0, h[7] ? h[1] / h[7] : 0, h[7] ? h[2] / h[7] : 0, h[7] ? h[3] / h[7] : 0, h[7] ? h[4] / h[7] : 0); }
+#endif
     c->stats.alignments = c->stats.launches[KC_FWD];
     c->stats.n_streams = c->n_streams;
     *s = c->stats;

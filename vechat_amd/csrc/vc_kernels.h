@@ -550,12 +550,15 @@ __device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_
     bool act[U];
     uint4 nr[U];
     uint32_t pp[U][VC_INLINE_PRED];
+    // The lanes walk the NODES (ids r0 ...), not the rows: a node's row is pos[node], which comes in the same round trip as the
+    // node's record and out-list head (all three indexed by the id: coalesced), where "row -> ord[row] -> the node's record" was a
+    // level more.  The records land where they belong (rec[pos[node]]); nothing below depends on the order the rows are made in.
 #pragma unroll
-    for (int u = 0; u < U; ++u) { r[u] = r0 + 64 * u + lane; act[u] = r[u] < o.N; v[u] = act[u] ? (uint32_t)o.ord[r[u]] : 0u; }
+    for (int u = 0; u < U; ++u) { v[u] = r0 + 64 * u + lane; act[u] = v[u] < o.N; }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        nr[u] = make_uint4(0, 0, 0, 0); of[u] = 0;
-        if (act[u]) { nr[u] = o.nrec[v[u]]; of[u] = o.out_first[v[u]]; }
+        nr[u] = make_uint4(0, 0, 0, 0); of[u] = 0; r[u] = 0;
+        if (act[u]) { r[u] = o.pos[v[u]]; nr[u] = o.nrec[v[u]]; of[u] = o.out_first[v[u]]; }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -2548,7 +2551,16 @@ struct VcAddArgs {
 // AddAlignment of sequence `layer` of window `slot` (+ the row records of the next layer when it is full-span).  `scr`: which of the
 // per-wave note blocks in VcAddArgs::scratch this wave uses (lock-step launches: the workgroup index; persistent pipeline: the
 // index of the resident wave).  smem: 2 * (PC + longest sequence) bytes, and vc_kept_lds_bytes(NC) for the row records.
+#ifdef VC_ADD_PROF          // development (tools/build_variant.sh addprof -DVC_ADD_PROF): shader-clock ticks of k_addaln's phases, summed over waves
+__device__ unsigned long long vc_add_prof[8];
+#define VC_ADD_STAMP(i) do { const long long n_ = clock64(); if (vc_lane() == 0) atomicAdd(&vc_add_prof[i], (unsigned long long)(n_ - t_prof)); t_prof = n_; } while (0)
+#else
+#define VC_ADD_STAMP(i) do { } while (0)
+#endif
 __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem, const uint32_t slot, const uint32_t layer, const uint32_t scr) {
+#ifdef VC_ADD_PROF
+    long long t_prof = clock64();
+#endif
     uint16_t* s_curr = (uint16_t*)smem;                 // [PC] node chosen for each pair (forward order)
     uint16_t* s_anchor = s_curr + a.PC;                 // [max_len] new node t goes in front of old position anchor[t]
     // bulky per-pair notes live in HBM scratch, not LDS: this kernel shares CUs with k_fwd of the other
@@ -2667,6 +2679,7 @@ __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem
 #endif
     if (err) { if (lane == 0) vc_fail(a.b, w, err, 6, nvalid != len || P == 0 ? 1 : 2); return; }
     __syncthreads();
+    VC_ADD_STAMP(0);
 
     // pass B: create nodes, extend aligned groups
     for (uint32_t f0 = 0; f0 < P; f0 += 64) {
@@ -2706,6 +2719,7 @@ __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem
     }
     if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 7, 0); return; }
     __syncthreads();      // pass B's stores are complete before pass C touches the same nodes
+    VC_ADD_STAMP(1);
 
     // every node on the path gains this sequence's label on an adjacent edge (Node::Coverage, graph.cpp:38-56)
     if (len >= 2) {
@@ -2834,6 +2848,7 @@ __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem
         }
     }
     if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 8, E0 + enew); return; }
+    VC_ADD_STAMP(2);
 
     // pass D: keep VcGraph::ord a valid DP order with aligned groups contiguous.
     //   a node created for a mismatch joins its group right behind the node it was aligned to;
@@ -2878,7 +2893,13 @@ __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem
     }
     if (lane == 0) { a.g.n_nodes[slot] = N0 + nnew; a.g.n_edges[slot] = E0 + enew; }
     __syncthreads();
+    VC_ADD_STAMP(3);
     if (a.make_rows) vc_rows_full(a.b, a.g, a.dp, slot, w, a.NC, a.EC, (int)layer + 1, a.ring, N0 + nnew, a.kept, smem);   // the next layer's rows (full-span layers)
+    VC_ADD_STAMP(4);
+    if (vc_lane() == 0) { (void)0; }
+#ifdef VC_ADD_PROF
+    if (vc_lane() == 0) atomicAdd(&vc_add_prof[7], 1ull);
+#endif
 }
 
 __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
