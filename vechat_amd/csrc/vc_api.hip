@@ -963,7 +963,11 @@ int vc_create(vc_ctx** out, const vc_params* p) {
         }
     }
     // the context's own stream for its copies, fills and small kernels: those must be able to run beside another context's chunks
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipStreamCreate failed"); }
+    {
+        int own_prio = 0;                                  // development: VC_OWN_PRIO = 0 / 1 / 2 picks the priority level of this stream
+        if (const char* d = getenv("VC_OWN_PRIO")) own_prio = stream_priority((uint32_t)std::atoi(d), 0u);
+        if (hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, own_prio) != hipSuccess) { delete c; return fail(nullptr, VC_ERR_HIP, "hipStreamCreate failed"); }
+    }
     c->stream = c->own_stream;
     // lookup tables from this host's libm, like the reference computes them (graph.cpp:169, window.cpp:235)
     uint32_t lw[256]; double ld[256];
