@@ -115,6 +115,8 @@ struct vc_ctx {
     bool ws_packed = false;             // the workspaces hold band space (the batch they were made for stores byte-packed rows)
     bool auto_streams = false;          // vc_params.n_streams was 0: vc_submit picks the chunk streams per batch
     uint32_t streams_made = 0;          // streams created (>= n_streams)
+    bool idle = true;                   // nothing of this context is queued on the (shared) chunk streams: vc_sync has returned since the last vc_run.
+                                        // A drained context must not wait on those streams again -- another context's chunks may be running on them
     bool have_ws = false;               // workspaces exist (out of the arena or allocated piece by piece)
 
     bool have_batch = false, ran = false;
@@ -1114,7 +1116,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
                 if ((int64_t)(hb->seq_off[q + 1] - hb->seq_off[q]) > std::max<int64_t>(allowed, 0)) pre[w] = VC_WIN_OVERFLOW;
     }
     }
-    sync_ctx(c);                                          // only this context's streams: another context may be running
+    if (c->idle) { join_workers(c); HIPCHK(c, hipStreamSynchronize(c->stream)); }      // (the chunk streams are the process's: another context may be running on them)
+    else sync_ctx(c);
     if (c->auto_streams) {
         const uint32_t want = nw >= kAutoStreamsFrom ? kAutoStreamsMany : kAutoStreamsFew;
         if (want != c->n_streams) { free_workspaces(c); c->n_streams = want; }
@@ -1283,6 +1286,7 @@ int vc_run(vc_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     join_workers(c);
     c->run_rc = VC_OK;
+    c->idle = false;
     const VcBatchDev& b = c->b;
     Plan pl{};
     pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
@@ -1380,6 +1384,7 @@ int vc_sync(vc_ctx* c) {
     join_workers(c);
     for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s]));
     for (uint32_t s = 0; s < c->n_streams; ++s) if (c->works[s].st_t) HIPCHK(c, hipStreamSynchronize(c->works[s].st_t));
+    c->idle = true;
     if (c->prm.profile) flush_events(c);
     if (c->run_rc.load() != VC_OK) { c->ran = false; return c->run_rc.load(); }
     HIPCHK(c, hipGetLastError());
@@ -1395,7 +1400,7 @@ static int fetch_lengths(vc_ctx* c) {
     join_workers(c);
     if (c->run_rc.load() != VC_OK) return c->run_rc.load();                  // the run failed: its own error text stands (vc_last_error)
     if (!c->ran) return fail(c, VC_ERR_STATE, "no finished run");
-    for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s]));
+    if (!c->idle) { for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s])); c->idle = true; }
     const uint32_t nw = c->b.n_windows;
     c->h_cons_len.resize(nw); c->h_status.resize(nw);
     HIPCHK(c, hipMemcpyAsync(c->h_cons_len.data(), c->b.cons_len, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
