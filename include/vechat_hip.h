@@ -5,9 +5,24 @@
  * reference file:line it stands in for is cited next to it (paths relative to the reference
  * tree).  No C++ or torch types cross this boundary: plain pointers and sizes only.
  *
- * Threading: a vc_ctx is bound to one HIP device and one stream and must be driven by one host
- * thread at a time (the reference gives each worker its own spoa engine, src/polisher.cpp:186-190;
- * its GPU shim gives each batch processor its own stream, src/cuda/cudabatch.cpp:54).
+ * Threading and streams.  A vc_ctx is bound to one HIP device and must be driven by ONE host thread at a
+ * time (the reference gives each worker its own spoa engine, src/polisher.cpp:186-190; its GPU shim gives
+ * each batch processor its own stream, src/cuda/cudabatch.cpp:54).  Different contexts may be driven from
+ * different threads at the same time.  What a context owns and what contexts share:
+ *   - its own stream (vc_stream): H2D of vc_submit, D2H of vc_collect, fills;
+ *   - the CHUNK STREAMS the kernels run on belong to the process: one set per device (up to 16, made on
+ *     first use, never destroyed), used by every context of that device.  Two contexts that run at the
+ *     same time interleave their chunks on those streams -- correct, results unchanged, but they share
+ *     the device; nothing is gained over one context with batches queued behind each other;
+ *   - host threads: one per chunk stream and context, started by the first vc_run, kept until vc_destroy
+ *     (blocked on a condition variable while the context has nothing queued).
+ * Pipelining inside one context.  A context holds TWO batches.  vc_run only queues the batch staged last
+ * and returns; a vc_submit that follows copies the next batch in while that one runs; vc_collect hands out
+ * the oldest run nobody has collected and waits for that run only.  So the loop of the reference's
+ * accelerated polisher (fill the next batch while one computes, src/cuda/cudapolisher.cpp:246-277) is
+ *     submit(b0) run   submit(b1) run   collect -> b0   submit(b2) run   collect -> b1   ...
+ * on one thread, with H2D, kernels and D2H overlapping and no gap on the device between batches.  The
+ * serial order (submit, run, [sync,] collect, submit ...) works as before and uses one batch slot.
  */
 #ifndef VECHAT_HIP_H_
 #define VECHAT_HIP_H_
@@ -57,7 +72,7 @@ typedef struct vc_params {
     uint32_t chunk_windows;                 /* windows resident per pass; 0 = derive from memory   */
     uint64_t scratch_bytes;                 /* device scratch budget; 0 = 60 % of free memory, at most 96 GiB */
     int32_t  profile;                       /* 1 = bracket every kernel launch with HIP events, 2 = only the forward kernel's */
-    uint32_t n_streams;                     /* chunks in flight on separate HIP streams; 0 = 4     */
+    uint32_t n_streams;                     /* chunks in flight on separate chunk streams (<= 16); 0 = chosen per batch: 8 from 12 288 windows up, else 4 */
 } vc_params;
 
 /* A batch of windows, the unit the reference's accelerated path fills with
@@ -111,10 +126,14 @@ void vc_destroy(vc_ctx* ctx);
 const char* vc_last_error(const vc_ctx* ctx);   /* ctx may be NULL: error of a failed vc_create */
 
 /* -- batch: addWindow()... / generateConsensus() / reset() (cudabatch.hpp:39-59) --------------- */
-int vc_submit(vc_ctx* ctx, const vc_batch* b);        /* validates, copies to HBM (H2D), retains nothing of b */
-int vc_run(vc_ctx* ctx);                              /* the whole hot path on the device; asynchronous       */
-int vc_sync(vc_ctx* ctx);                             /* waits for vc_run                                      */
-int vc_result_size(vc_ctx* ctx, uint64_t* cons_bytes);/* after vc_sync: total consensus bytes                  */
+int vc_submit(vc_ctx* ctx, const vc_batch* b);        /* validates, copies to HBM (H2D), retains nothing of b; does not wait for a batch
+                                                         that is running unless the workspaces must grow for this one                 */
+int vc_run(vc_ctx* ctx);                              /* queues the whole hot path for the batch staged last; returns at once          */
+int vc_sync(vc_ctx* ctx);                             /* waits for every queued run                                                    */
+/* The three calls below speak of the OLDEST run whose results have not been collected (none such: the latest run) and wait
+ * for that run only; vc_collect / vc_collect_device mark it collected. */
+int vc_result_windows(vc_ctx* ctx, uint32_t* n_windows);  /* windows of that batch                                 */
+int vc_result_size(vc_ctx* ctx, uint64_t* cons_bytes);/* total consensus bytes                                 */
 int vc_collect(vc_ctx* ctx, vc_result* r);            /* D2H of consensus + status                             */
 /* device-side hand-over for the multi-GPU gather (RCCL lives in the caller, e.g. torch.distributed):
  * compacts the consensus bytes into caller-owned DEVICE memory. */
@@ -128,7 +147,12 @@ int vc_debug_errinfo(vc_ctx* ctx, uint32_t* out /*[n_windows]*/);
  * where it stands, in the record format of the oracle's vco_window_stages.  Single-chunk batches. */
 int vc_debug_stop_after(vc_ctx* ctx, uint32_t kind, uint32_t index);
 int vc_debug_stage_digest(vc_ctx* ctx, uint32_t window, int with_pairs, uint64_t* out /*[8], [0..1] untouched*/);
-void* vc_stream(vc_ctx* ctx);                         /* the hipStream_t the context launches on               */
+/* development: the row records (16 B each) the next alignment of window w will use, after a stopped run (tools/gpu_rowstats.py);
+ * the persistent pipeline's counters / per-window words, and its waves' phase clocks (tools/gpu_pipe_dbg.py) */
+int vc_debug_rows(vc_ctx* ctx, uint32_t window, uint32_t* out, uint32_t cap_rows, uint32_t* nrows);
+int vc_debug_pipe_state(vc_ctx* ctx, uint32_t* out, uint32_t n);
+int vc_debug_pipe_prof(vc_ctx* ctx, unsigned long long* out);
+void* vc_stream(vc_ctx* ctx);                         /* the context's own hipStream_t (copies, fills); the kernels run on the process's chunk streams */
 int   vc_set_profile(vc_ctx* ctx, int profile);       /* change vc_params.profile of a live context (0, 1, 2)  */
 /* Execution plan of the build loop (src/window.cpp:239-298).  0 (default): lock-step -- one launch per kernel per layer for a
  * whole chunk.  1: persistent pipeline -- two resident kernels per chunk (forward + AddAlignment waves, backtrack waves) that

@@ -283,6 +283,7 @@ def test_launch_plans_of_round_four_agree(built, monkeypatch):
     c = HipContext(device=0)
     c.submit(many); c.run(); c.sync()
     assert c.stats()["n_streams"] == 8
+    assert len(c.collect()[0]) == 12288                                        # (results are handed out in the order of the runs)
     c.submit(batch); c.run(); c.sync()
     assert c.stats()["n_streams"] == 4 and c.collect()[0] == out[0][0]
     c.close()
@@ -290,6 +291,125 @@ def test_launch_plans_of_round_four_agree(built, monkeypatch):
     c.submit(many); c.run(); c.sync()
     assert c.stats()["n_streams"] == 3
     c.close()
+
+
+def _digest(cons):
+    return hashlib.sha256(b"".join(hashlib.sha256(x).digest() for x in cons)).hexdigest()
+
+
+def test_eight_stream_plan_on_config_c_shape(built):
+    """What only the bench used to cover: >= 12 288 windows of BASELINE config C's real shape (500 bp x 64 reads) through the
+    eight-stream plan.  Every window polished, the DP work of a sample equal to the oracle's cell count, the sample's bytes equal,
+    and the whole result independent of the number of chunk streams (8 picked by the batch, 4 asked for)."""
+    n = 12288
+    batch = capi.synth_batch(capi.synth_cfg(1002, 500, 64), 0, n)
+    c8 = HipContext(device=0)
+    cons8, st8 = c8.consensus(batch)
+    s8 = c8.stats()
+    assert s8["n_streams"] == 8 and (st8 == capi.VC_WIN_OK).all()
+    sample = batch.slice(4096, 4096 + 64)                                       # windows of the middle chunks
+    ref, pol, ost = oa.oracle_run(sample, c8.params)
+    assert all(pol) and cons8[4096:4096 + 64] == list(ref)
+    cs, _ = c8.consensus(sample)                                               # the same windows as a batch of their own: same bytes, and the cells can be compared
+    assert cs == list(ref) and c8.stats()["cells"] == ost.cells
+    c8.close()
+    c4 = HipContext(device=0, n_streams=4)
+    cons4, st4 = c4.consensus(batch)
+    assert c4.stats()["n_streams"] == 4 and c4.stats()["cells"] == s8["cells"]
+    c4.close()
+    assert _digest(cons4) == _digest(cons8) and (st4 == st8).all()
+
+
+def test_two_contexts_driven_concurrently(built):
+    """Two contexts on two host threads at the same time, no lock between them, batches of different shapes: the process-wide
+    chunk streams interleave their chunks; every result must equal the one the context produces alone."""
+    import threading
+    ba = capi.synth_batch(capi.synth_cfg(81, 500, 24), 0, 3000)
+    bb = capi.synth_batch(capi.synth_cfg(82, 300, 12, frac_partial=0.3, n_haplotypes=2, snp_rate=0.02), 0, 5000)
+    ca, cb = HipContext(device=0), HipContext(device=0, n_streams=3, chunk_windows=700)
+    alone = [_digest(ca.consensus(ba)[0]), _digest(cb.consensus(bb)[0])]
+    got, err = [[], []], []
+
+    def drive(k, c, b):
+        try:
+            for _ in range(3):
+                cons, status = c.consensus(b)
+                assert (status <= capi.VC_WIN_UNPOLISHED).all()
+                got[k].append(_digest(cons))
+        except Exception as e:                                                   # (an assertion on a thread must fail the test)
+            err.append(e)
+
+    th = [threading.Thread(target=drive, args=(0, ca, ba)), threading.Thread(target=drive, args=(1, cb, bb))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    ca.close(); cb.close()
+    assert not err, err
+    assert got[0] == [alone[0]] * 3 and got[1] == [alone[1]] * 3
+    ref, _, _ = oa.oracle_run(bb, capi.default_params(), 0, 6)
+    c = HipContext(device=0)
+    assert c.consensus(bb.slice(0, 6))[0] == list(ref)
+    c.close()
+
+
+def test_batches_queued_behind_each_other_in_one_context(built):
+    """The loop of include/vechat_hip.h ("Pipelining inside one context"): submit(b[i+1]) while b[i] runs, collect() hands out
+    b[i-1].  Batches of different sizes and shapes (the workspaces must grow under a running batch once), results in the order
+    of the runs, every one equal to the batch run alone; a run may be repeated and a batch may stay uncollected until both slots
+    are needed."""
+    cfgs = [capi.synth_cfg(91, 400, 16), capi.synth_cfg(92, 500, 20, frac_partial=0.25), capi.synth_cfg(93, 200, 8, fastq=0, backbone_fastq=0)]
+    parts = [capi.synth_batch(cfgs[i % 3], 100 * i, n) for i, n in enumerate((900, 1500, 40, 2000, 1, 700))]
+    solo = HipContext(device=0)
+    alone = [solo.consensus(p) for p in parts]
+    solo.close()
+    c = HipContext(device=0)
+    out = []
+    c.submit(parts[0]); c.run()
+    for i in range(1, len(parts)):
+        c.submit(parts[i]); c.run()
+        out.append(c.collect())
+    out.append(c.collect())
+    for i, ((cons, status), (rc, rs)) in enumerate(zip(out, alone)):
+        assert cons == rc and (status == rs).all(), i
+    # the same batch run twice without a submit in between, then a new batch while its results wait: nothing is lost
+    c.run(); c.sync()
+    c.submit(parts[1]); c.run()
+    again, _ = c.collect()
+    assert again == alone[-1][0]
+    assert c.collect()[0] == alone[1][0]
+    ref, _, _ = oa.oracle_run(parts[3], c.params, 0, 4)
+    assert alone[3][0][:4] == list(ref)
+    c.close()
+
+
+def test_config_d_rank_shard_properties(built):
+    """One rank's share of BASELINE config D (1 M windows of config C's shape over 8 GPUs = 125 000 windows; rank 3's windows
+    of the stream) at full size: every window polished, plausible lengths, deterministic, outliers and a random sample confirmed
+    by the oracle, and the shard's result independent of how it is cut into batches (one batch of 125 000 against batches of
+    20 000 queued behind each other)."""
+    n, first = 125000, 3 * 125000
+    batch = capi.synth_batch(capi.synth_cfg(1002, 500, 64), first, n)
+    c = HipContext(device=0)
+    cons, status = c.consensus(batch)
+    assert (status == capi.VC_WIN_OK).all()
+    lens = np.array([len(x) for x in cons])
+    assert 470 < np.median(lens) < 510 and lens.max() < 640
+    h1 = _digest(cons)
+    rng = np.random.default_rng(11)
+    for w in list(np.argsort(lens)[:3]) + list(np.argsort(lens)[-2:]) + list(rng.choice(n, size=8, replace=False)):
+        ref, pol, _ = oa.oracle_run(batch, capi.default_params(), int(w), int(w) + 1)
+        assert cons[int(w)] == ref[0] and pol[0], int(w)
+    del cons
+    parts = [batch.slice(lo, min(lo + 20000, n)) for lo in range(0, n, 20000)]
+    out = []
+    c.submit(parts[0]); c.run()
+    for i in range(1, len(parts)):
+        c.submit(parts[i]); c.run()
+        out.extend(c.collect()[0])
+    out.extend(c.collect()[0])
+    c.close()
+    assert _digest(out) == h1
 
 
 def test_prune_parameters_and_rounds(built):

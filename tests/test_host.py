@@ -18,6 +18,12 @@ def test_library_exports_every_declared_symbol(built):
     lib = C.CDLL(os.path.join(capi.LIB_DIR, "libvechat_hip.so"))
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing
+    # ... and the other way round: nothing is exported that a binder cannot find in the header
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(capi.LIB_DIR, "libvechat_hip.so")], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-2] in ("T", "t") and l.split()[-1].startswith("vc_")}
+    undeclared = sorted(n for n in exported if n not in names and not n.startswith("vc_debug_fwd_lab"))
+    assert not undeclared, undeclared
 
 
 def test_no_silent_cpu_fallback_without_gpu(built):

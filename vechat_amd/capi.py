@@ -280,6 +280,8 @@ def load_hip():
             getattr(lib, name).restype = C.c_int
         lib.vc_result_size.argtypes = [vp, C.POINTER(C.c_uint64)]
         lib.vc_result_size.restype = C.c_int
+        lib.vc_result_windows.argtypes = [vp, C.POINTER(C.c_uint32)]
+        lib.vc_result_windows.restype = C.c_int
         lib.vc_collect.argtypes = [vp, C.POINTER(VcResult)]
         lib.vc_collect.restype = C.c_int
         lib.vc_collect_device.argtypes = [vp, vp, C.c_uint64, vp, vp]

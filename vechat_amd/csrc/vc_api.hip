@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -97,17 +99,50 @@ struct Work {
 
 }  // namespace
 
+struct vc_ctx;
+
+namespace {
+struct Plan;
+struct DevSlot { void* p = nullptr; size_t cap = 0; };
+
+// Everything that belongs to ONE submitted batch.  A context holds two: while the chunks of one run on the chunk streams, the
+// next one is validated and copied in on the context's own stream (vc_submit) and the one before is copied out (vc_collect) --
+// the shape of the reference's accelerated polisher, which fills the next batch while one computes (src/cuda/cudapolisher.cpp:246-277).
+struct Batch {
+    bool have = false;                   // a batch is staged here (vc_submit succeeded)
+    VcBatchDev b{};
+    DevSlot slots[16];                   // its device buffers (inputs, per-window outputs, collect scratch): grow-only, kept between batches
+    std::vector<uint32_t> h_win_seq_off;
+    std::vector<uint8_t> h_layer_partial;   // [layer] does any window have a partial-span layer at this index?
+    std::vector<uint8_t> h_pre_status;   // per-window status decided at submit (outside the envelope), empty = none
+    uint32_t max_layers = 0, max_len = 0, max_backbone = 0;
+    uint32_t cpl = 0, cpl_min = 0;       // width classes of this batch's sequences (kernel selection)
+    uint32_t kept = 0;                   // slots of the build phase's kept-row ring for this batch (0: plain ring); needs 15-bit row distances
+    bool packed = false;                 // stored DP rows of this batch: byte-packed (both score sets within the byte bound at the widest class) or raw
+    bool band = false;                   // banded matrix store (vc_band_start): packed rows, row builders that mark the rows read back, cooperative backtrack
+    uint32_t cw_run = 0, n_streams = 1;  // chunk size and chunk streams of this batch
+    // ---- run state (guarded by vc_ctx::qmu while queued)
+    bool queued = false;                 // on the run queue: its chunks are being handed to the stream workers
+    bool ran = false, collected = false; // a run was started (and not invalidated) / its results were handed out
+    uint64_t run_seq = 0;                // order of the vc_run calls
+    uint32_t next_chunk = 0, n_chunks = 0, chunks_done = 0;
+    int run_rc = 0;
+    hipEvent_t done_ev[16]{};            // per chunk stream: recorded behind the last chunk of this batch on that stream
+    bool ev_rec[16]{};
+    Plan* pl = nullptr;                  // the plan of the run in flight (owned)
+    // ---- results
+    uint64_t total_cons = 0;
+    std::vector<uint32_t> h_cons_len;
+    std::vector<uint8_t> h_status;
+};
+}  // namespace
+
 struct vc_ctx {
     vc_params prm{};
     int device = 0;
-    hipStream_t stream = nullptr;       // stream 0: uploads, collects
+    hipStream_t stream = nullptr;       // the context's own stream: uploads, collects, fills
     std::string err;
     std::vector<void*> allocs;          // lifetime of the context
-    std::vector<void*> batch_allocs;    // per batch
-    // batch and collect buffers are kept between calls (grow-only): hipMalloc / hipFree synchronise the whole device and
-    // would serialise two contexts that a caller runs side by side to hide one batch's H2D behind the other's kernels
-    struct Slot { void* p = nullptr; size_t cap = 0; };
-    Slot slots[16];
     std::vector<void*> chunk_allocs;    // workspaces (re-created when capacities change)
     uint64_t chunk_bytes = 0;           // what they hold: counts as available when the next batch is planned
     char* arena = nullptr;              // vc_reserve: one allocation the workspaces are carved from (a change of shape then costs no hipFree / hipMalloc)
@@ -115,33 +150,22 @@ struct vc_ctx {
     bool ws_packed = false;             // the workspaces hold band space (the batch they were made for stores byte-packed rows)
     bool auto_streams = false;          // vc_params.n_streams was 0: vc_submit picks the chunk streams per batch
     uint32_t streams_made = 0;          // streams created (>= n_streams)
-    bool idle = true;                   // nothing of this context is queued on the (shared) chunk streams: vc_sync has returned since the last vc_run.
-                                        // A drained context must not wait on those streams again -- another context's chunks may be running on them
     bool have_ws = false;               // workspaces exist (out of the arena or allocated piece by piece)
 
-    bool have_batch = false, ran = false;
-    VcBatchDev b{};
-    std::vector<uint32_t> h_win_seq_off;
-    std::vector<uint8_t> h_layer_partial;   // [layer] does any window have a partial-span layer at this index?
-    uint32_t max_layers = 0, max_len = 0, max_nseq = 0;
-    uint64_t total_cons = 0;
-    std::vector<uint32_t> h_cons_len;
-    std::vector<uint8_t> h_status;
+    Batch bt[2];
+    Batch* cur = nullptr;               // the batch vc_submit staged last: what vc_run starts
+    uint64_t run_counter = 0;
+    uint32_t max_nseq = 0;              // deepest window the workspaces are laid out for (pair lists per window)
     uint32_t* d_lut_w = nullptr; double* d_lut_d = nullptr;
     unsigned long long* d_stat = nullptr;   // [VC_STAT_SLOTS][8] cells, rows, -, far-row reads, trace steps, speculated steps, rounds, -
 
-    bool band = false;                   // banded matrix store (vc_band_start): packed rows, row builders that mark the rows read back, cooperative backtrack
-    uint32_t kept = 0;                   // slots of the build phase's kept-row ring for this batch (0: plain ring); needs 15-bit row distances
-    bool packed = false;                 // stored DP rows of this batch: byte-packed (both score sets within the byte bound at the widest class) or raw
     uint32_t wcols = 0;                  // != 0: some alignment may need k_fwd_wide; columns of its int32 matrices (multiple of 512)
     uint32_t MA = 4;                     // entries per aligned list: max(4, distinct bytes in the batch - 1), even
-    uint32_t ws_cpl = 0, ws_max_len = 0, cw_run = 0;   // width class / longest sequence the workspaces are sized for; chunk size of the current batch
-    uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, cpl = 0, cpl_min = 0, jobs_cap = 0, group_max = 1, rgroup_max = 1, n_streams = 1;
+    uint32_t ws_cpl = 0, ws_max_len = 0;   // width class / longest sequence the workspaces are sized for
+    uint32_t NC = 0, EC = 0, CW = 0, STK = 2048, PC = 0, jobs_cap = 0, group_max = 1, rgroup_max = 1, n_streams = 1;
     uint64_t hmat_dwords = 0;
     uint32_t big_ws_stride = 0;          // bytes per window of the HBM workspace for oversized graph images (0: all fit the LDS)
     bool big_ws_topo = false;            // the workspace also backs k_topo's optimistic LDS image of the first pruned graphs
-    uint32_t max_backbone = 0;           // longest backbone of the batch
-    std::vector<uint8_t> h_pre_status;   // per-window status decided at submit (outside the envelope), empty = none
     bool trace_wave = true;
     int prune_hbm = 1;              // 1: the first prune of a chunk works from the HBM workspace instead of LDS; 2: every prune; 0: LDS
     bool topo_hbm = false;          // k_topo of the pruned graphs from the HBM workspace
@@ -153,9 +177,10 @@ struct vc_ctx {
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};      // the process's chunk streams of this device (pooled_stream): not owned
     hipStream_t own_stream = nullptr;        // this context's stream for copies, fills and small kernels
-    // One host thread per chunk stream drives its chunks through the phases (vc_run starts them, vc_sync joins them): the one
-    // host wait of the path -- the pruned graphs' height before a re-alignment round -- then stalls that stream only, and a
-    // stream takes its next chunk as soon as it is done (no lockstep between streams, no barrier between groups of chunks).
+    // One host thread per chunk stream (started with the first vc_run, kept until vc_destroy) takes chunks off the run queue and
+    // drives each through its phases on that stream: the one host wait of the path -- the pruned graphs' height before a
+    // re-alignment round -- then stalls that stream only, a stream takes its next chunk as soon as it has queued the last one,
+    // and when a batch has no chunk left it goes on with the next batch of the queue: no barrier between chunks, none between batches.
     bool host_threads = true;
     // persistent build pipeline: the build loop of a chunk as three resident kernels and device-side queues instead of six launches
     // per layer (vc_pipe.h); pipe_f / pipe_t / pipe_r: resident workgroups of the forward / backtrack / resolver kernels (0: default)
@@ -166,9 +191,11 @@ struct vc_ctx {
     uint32_t* d_pipe_abort = nullptr;    // != 0: a wave of the pipeline ran out of patience (site code): the run failed
     uint32_t n_cu = 256;
     std::thread workers[kMaxStreams];
-    bool workers_running = false;
-    std::atomic<uint32_t> next_chunk{0};
-    std::atomic<int> run_rc{0};
+    uint32_t workers_made = 0;
+    bool stop = false;                   // vc_destroy: the workers leave
+    std::mutex qmu;                      // run queue and the run state of the batches
+    std::condition_variable qcv;
+    std::deque<Batch*> runq;
     std::mutex mu;                       // err, event pool / records, launch counters
 
     void* h_stage[2] = {nullptr, nullptr};   // pinned staging for uploads from pageable caller memory
@@ -241,27 +268,45 @@ int dalloc(vc_ctx* c, std::vector<void*>& list, T** out, size_t n) {
     return VC_OK;
 }
 
-void join_workers(vc_ctx* c) {
-    if (!c->workers_running) return;
-    for (uint32_t k = 0; k < c->n_streams; ++k) if (c->workers[k].joinable()) c->workers[k].join();
-    c->workers_running = false;
+// Waits until every chunk of the batch's run has been queued on its stream by the workers and has finished there.  Only the
+// batch's own events are waited for: the chunk streams are the process's, another batch (or another context) may be running on them.
+int wait_batch(vc_ctx* c, Batch* bt) {
+    {
+        std::unique_lock<std::mutex> lk(c->qmu);
+        c->qcv.wait(lk, [&] { return !bt->queued; });
+    }
+    for (uint32_t s = 0; s < kMaxStreams; ++s) {
+        if (!bt->ev_rec[s]) continue;
+        hipError_t e = hipEventSynchronize(bt->done_ev[s]);
+        if (e != hipSuccess) return fail(c, VC_ERR_HIP, "waiting for chunk stream %u failed: %s", s, hipGetErrorString(e));
+        if (c->works[s].st_t) (void)hipStreamSynchronize(c->works[s].st_t);      // (persistent pipeline: the backtrack kernel's stream)
+    }
+    return VC_OK;
 }
 
-void sync_ctx(vc_ctx* c) {
-    join_workers(c);
+// nothing of this context is in flight any more (runs, copies)
+void drain(vc_ctx* c) {
+    for (Batch& bt : c->bt) (void)wait_batch(c, &bt);
     (void)hipStreamSynchronize(c->stream);
-    for (uint32_t k = 0; k < c->n_streams; ++k) {
+}
+
+// ... and nothing a stopped run (vc_debug_stop_after) left on the chunk streams either
+void sync_all(vc_ctx* c) {
+    drain(c);
+    for (uint32_t k = 0; k < kMaxStreams; ++k) {
         if (c->works[k].st_t) (void)hipStreamSynchronize(c->works[k].st_t);
         if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
     }
 }
 
 template <typename T>
-int salloc(vc_ctx* c, int slot, T** out, size_t n) {
-    vc_ctx::Slot& s = c->slots[slot];
+int salloc(vc_ctx* c, Batch* bt, int slot, T** out, size_t n) {
+    DevSlot& s = bt->slots[slot];
     const size_t bytes = std::max<size_t>(n * sizeof(T), 256);
     if (s.cap < bytes) {
-        sync_ctx(c);
+        // (the buffer belongs to a batch that is not in flight; hipFree / hipMalloc synchronise the device themselves -- a stall for a
+        // batch that is running, which is why the buffers are grow-only and kept)
+        (void)hipStreamSynchronize(c->stream);
         if (s.p) (void)hipFree(s.p);
         s.p = nullptr; s.cap = 0;
         const size_t want = bytes + bytes / 8;
@@ -270,6 +315,19 @@ int salloc(vc_ctx* c, int slot, T** out, size_t n) {
         s.cap = want;
     }
     *out = static_cast<T*>(s.p);
+    return VC_OK;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel in this process, not of a launch: two batches (or two
+// contexts) in flight must not lower each other's limit.  Grow-only.
+std::mutex g_lds_mu;
+std::map<const void*, int> g_lds_limit;
+int lds_limit(vc_ctx* c, const void* func, uint32_t bytes) {
+    std::lock_guard<std::mutex> lk(g_lds_mu);
+    int& cur = g_lds_limit[func];
+    if ((int)bytes <= cur) return VC_OK;
+    HIPCHK(c, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    cur = (int)bytes;
     return VC_OK;
 }
 
@@ -450,23 +508,23 @@ void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs, bool packed
 }
 
 // lower class of a folded launch (launch_fwd), 0 when the batch's classes need no folding: what the backtrack reads the rows with
-uint32_t fold_lo(const vc_ctx* c) {
+uint32_t fold_lo(const vc_ctx* c, const Batch* bt) {
     const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
     int lo = -1, hi = -1;
-    for (int i = 0; i < 11; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
+    for (int i = 0; i < 11; ++i) { if (opts[i] == bt->cpl_min) lo = i; if (opts[i] == bt->cpl) hi = i; }
     return (c->fold && lo >= 0 && hi - lo > 1) ? opts[hi - 1] : 0u;
 }
 
 // One launch when the batch's sequences fall into one width class or two adjacent ones (the usual case:
 // read pieces of a window differ by a few percent in length); otherwise one launch per class.
-int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, const Work* wk = nullptr, bool nwonly = false) {
-    if (c->dup & 16u) { const uint32_t d = c->dup; c->dup = 0; (void)launch_fwd(c, st, a0, jobs, wk, nwonly); c->dup = d; (void)hipMemsetAsync(a0.tie_n, 0, 4, st); }
+int launch_fwd(vc_ctx* c, const Batch* bt, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, const Work* wk = nullptr, bool nwonly = false) {
+    if (c->dup & 16u) { const uint32_t d = c->dup; c->dup = 0; (void)launch_fwd(c, bt, st, a0, jobs, wk, nwonly); c->dup = d; (void)hipMemsetAsync(a0.tie_n, 0, 4, st); }
     const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
     VcFwdArgs a = a0;
     a.do_init = 1;
     int lo = -1, hi = -1;
-    for (int i = 0; i < 11; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
-    if (lo < 0 || hi < 0) return fail(c, VC_ERR_ARG, "unsupported cells-per-lane %u..%u", c->cpl_min, c->cpl);
+    for (int i = 0; i < 11; ++i) { if (opts[i] == bt->cpl_min) lo = i; if (opts[i] == bt->cpl) hi = i; }
+    if (lo < 0 || hi < 0) return fail(c, VC_ERR_ARG, "unsupported cells-per-lane %u..%u", bt->cpl_min, bt->cpl);
     auto wide = [&]() {                     // alignments the packed-int16 kernels declined (their job_type is still 255)
         if (c->wcols && wk) { Timer t(c, KC_FWD, st); hipLaunchKernelGGL(k_fwd_wide, dim3(jobs), dim3(64), 0, st, a, wk->d_wmat, (uint64_t)c->NC * c->wcols, c->wcols, wk->d_c0w); }
     };
@@ -477,18 +535,18 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
         { Timer t(c, KC_FWD, st);
         switch (hi) {
 #ifndef VC_FAST_BUILD          // development builds (-DVC_FAST_BUILD) carry only the width classes of the benchmark
-            case 1: launch_fwd_t<4, 6>(st, a, jobs, c->packed, nwonly); break;
-            case 2: launch_fwd_t<6, 8>(st, a, jobs, c->packed, nwonly); break;
+            case 1: launch_fwd_t<4, 6>(st, a, jobs, bt->packed, nwonly); break;
+            case 2: launch_fwd_t<6, 8>(st, a, jobs, bt->packed, nwonly); break;
 #endif
-            case 3: launch_fwd_t<8, 10>(st, a, jobs, c->packed, nwonly); break;
+            case 3: launch_fwd_t<8, 10>(st, a, jobs, bt->packed, nwonly); break;
 #ifndef VC_FAST_BUILD
-            case 4: launch_fwd_t<10, 12>(st, a, jobs, c->packed, nwonly); break;
-            case 5: launch_fwd_t<12, 16>(st, a, jobs, c->packed, nwonly); break;
-            case 6: launch_fwd_t<16, 20>(st, a, jobs, c->packed, nwonly); break;
-            case 7: launch_fwd_t<20, 24>(st, a, jobs, c->packed, nwonly); break;
-            case 8: launch_fwd_t<24, 32>(st, a, jobs, c->packed, nwonly); break;
-            case 9: launch_fwd_t<32, 48>(st, a, jobs, c->packed, nwonly); break;
-            case 10: launch_fwd_t<48, 64>(st, a, jobs, c->packed, nwonly); break;
+            case 4: launch_fwd_t<10, 12>(st, a, jobs, bt->packed, nwonly); break;
+            case 5: launch_fwd_t<12, 16>(st, a, jobs, bt->packed, nwonly); break;
+            case 6: launch_fwd_t<16, 20>(st, a, jobs, bt->packed, nwonly); break;
+            case 7: launch_fwd_t<20, 24>(st, a, jobs, bt->packed, nwonly); break;
+            case 8: launch_fwd_t<24, 32>(st, a, jobs, bt->packed, nwonly); break;
+            case 9: launch_fwd_t<32, 48>(st, a, jobs, bt->packed, nwonly); break;
+            case 10: launch_fwd_t<48, 64>(st, a, jobs, bt->packed, nwonly); break;
 #else
             default: return fail(c, VC_ERR_ARG, "development build: width classes 8 / 10 only");
 #endif
@@ -501,19 +559,19 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
         Timer t(c, KC_FWD, st);
         switch (opts[i]) {
 #ifndef VC_FAST_BUILD
-            case 4:  launch_fwd_t<4, 4>(st, a, jobs, c->packed, nwonly); break;
-            case 6:  launch_fwd_t<6, 6>(st, a, jobs, c->packed, nwonly); break;
+            case 4:  launch_fwd_t<4, 4>(st, a, jobs, bt->packed, nwonly); break;
+            case 6:  launch_fwd_t<6, 6>(st, a, jobs, bt->packed, nwonly); break;
 #endif
-            case 8:  launch_fwd_t<8, 8>(st, a, jobs, c->packed, nwonly); break;
-            case 10: launch_fwd_t<10, 10>(st, a, jobs, c->packed, nwonly); break;
+            case 8:  launch_fwd_t<8, 8>(st, a, jobs, bt->packed, nwonly); break;
+            case 10: launch_fwd_t<10, 10>(st, a, jobs, bt->packed, nwonly); break;
 #ifndef VC_FAST_BUILD
-            case 12: launch_fwd_t<12, 12>(st, a, jobs, c->packed, nwonly); break;
-            case 16: launch_fwd_t<16, 16>(st, a, jobs, c->packed, nwonly); break;
-            case 20: launch_fwd_t<20, 20>(st, a, jobs, c->packed, nwonly); break;
-            case 24: launch_fwd_t<24, 24>(st, a, jobs, c->packed, nwonly); break;
-            case 32: launch_fwd_t<32, 32>(st, a, jobs, c->packed, nwonly); break;
-            case 48: launch_fwd_t<48, 48>(st, a, jobs, c->packed, nwonly); break;
-            case 64: launch_fwd_t<64, 64>(st, a, jobs, c->packed, nwonly); break;
+            case 12: launch_fwd_t<12, 12>(st, a, jobs, bt->packed, nwonly); break;
+            case 16: launch_fwd_t<16, 16>(st, a, jobs, bt->packed, nwonly); break;
+            case 20: launch_fwd_t<20, 20>(st, a, jobs, bt->packed, nwonly); break;
+            case 24: launch_fwd_t<24, 24>(st, a, jobs, bt->packed, nwonly); break;
+            case 32: launch_fwd_t<32, 32>(st, a, jobs, bt->packed, nwonly); break;
+            case 48: launch_fwd_t<48, 48>(st, a, jobs, bt->packed, nwonly); break;
+            case 64: launch_fwd_t<64, 64>(st, a, jobs, bt->packed, nwonly); break;
 #else
             default: return fail(c, VC_ERR_ARG, "development build: width classes 8 / 10 only");
 #endif
@@ -528,27 +586,27 @@ int launch_fwd(vc_ctx* c, hipStream_t st, const VcFwdArgs& a0, uint32_t jobs, co
 template <int CA, int CB>
 int launch_pipe_fwd_t(vc_ctx* c, hipStream_t st, const VcPipeFwdArgs& a, uint32_t grid, uint32_t lds) {
     auto k = k_pipe_fwd<CA, CB, (kKept ? kKept : 1), true>;
-    HIPCHK(c, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc_ = lds_limit(c, (const void*)k, lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, a);
     return VC_OK;
 }
 // The pipeline's forward kernel is built for the widest class of the batch and the one below it (everything narrower runs
 // in that lower class: partial-span layers are short).  -> (CA, CB), CA == CB when the batch has one class.
-bool pipe_classes(const vc_ctx* c, uint32_t* ca, uint32_t* cb) {
+bool pipe_classes(const Batch* bt, uint32_t* ca, uint32_t* cb) {
     const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
     int lo = -1, hi = -1;
-    for (int i = 0; i < 11; ++i) { if (opts[i] == c->cpl_min) lo = i; if (opts[i] == c->cpl) hi = i; }
+    for (int i = 0; i < 11; ++i) { if (opts[i] == bt->cpl_min) lo = i; if (opts[i] == bt->cpl) hi = i; }
     if (lo < 0 || hi < 0) return false;
     *cb = opts[hi]; *ca = lo < hi ? opts[hi - 1] : opts[hi];
 #ifdef VC_FAST_BUILD
     return *cb == 10 || *cb == 8;
 #else
-    return true;
+    return *cb <= 32;                  // (no pipeline kernel is built for the classes of 48 / 64 columns per lane: those batches take the lock-step plan)
 #endif
 }
-int launch_pipe_fwd(vc_ctx* c, hipStream_t st, const VcPipeFwdArgs& a, uint32_t grid, uint32_t lds) {
+int launch_pipe_fwd(vc_ctx* c, const Batch* bt, hipStream_t st, const VcPipeFwdArgs& a, uint32_t grid, uint32_t lds) {
     uint32_t lo = 0, hi = 0;
-    if (!pipe_classes(c, &lo, &hi)) return fail(c, VC_ERR_ARG, "persistent pipeline: unsupported cells-per-lane %u..%u", c->cpl_min, c->cpl);
+    if (!pipe_classes(bt, &lo, &hi)) return fail(c, VC_ERR_ARG, "persistent pipeline: unsupported cells-per-lane %u..%u", bt->cpl_min, bt->cpl);
 #define VC_PF(A, B) if (lo == A && hi == B) return launch_pipe_fwd_t<A, B>(c, st, a, grid, lds);
     VC_PF(8, 10) VC_PF(8, 8) VC_PF(10, 10) VC_PF(6, 8)
 #ifndef VC_FAST_BUILD
@@ -568,31 +626,32 @@ uint32_t pick_cpl(uint32_t max_len) {
 // ---------------------------------------------------------------- one chunk, phase by phase
 struct Plan {
     vc_ctx* c;
+    Batch* bt;
     uint32_t NC, EC, PC, cpl, topo_lds, prune_lds, add_lds, rows_lds, cons_lds;
     uint64_t rowd;          // dwords per H row
 
     VcFwdArgs fwd_args(const Work& wk) const {
         VcFwdArgs fa{};
-        fa.b = c->b; fa.dp = wk.dp; fa.w0 = wk.w0; fa.nslots = wk.ns; fa.NC = NC; fa.EC = EC;
+        fa.b = bt->b; fa.dp = wk.dp; fa.w0 = wk.w0; fa.nslots = wk.ns; fa.NC = NC; fa.EC = EC;
         fa.m = c->prm.match; fa.n = c->prm.mismatch; fa.g = c->prm.gap;
         fa.sm = c->prm.sw_match; fa.sn = c->prm.sw_mismatch; fa.sg = c->prm.sw_gap;
         fa.hmat = wk.d_hmat; fa.c0 = wk.d_c0;
         fa.job_end = wk.d_job_end; fa.job_type = wk.d_job_type; fa.tie_rows = wk.d_tie_rows; fa.tie_cnt = wk.d_tie_cnt; fa.tie_list = wk.d_tie_list; fa.tie_n = wk.d_tie_n;
-        fa.stat = c->d_stat; fa.wcols = c->wcols; fa.kept = c->kept;
-        fa.bmat = wk.d_bmat; fa.band_par = wk.d_band_par; fa.band = c->band ? 1 : 0; fa.redo_list = nullptr; fa.redo_n = nullptr;
+        fa.stat = c->d_stat; fa.wcols = c->wcols; fa.kept = bt->kept;
+        fa.bmat = wk.d_bmat; fa.band_par = wk.d_band_par; fa.band = bt->band ? 1 : 0; fa.redo_list = nullptr; fa.redo_n = nullptr;
         fa.fold = 0;                  // (launch_fwd decides)
         return fa;
     }
     VcTraceArgs trace_args(const Work& wk) const {
         VcTraceArgs ta{};
-        ta.b = c->b; ta.dp = wk.dp; ta.w0 = wk.w0; ta.nslots = wk.ns; ta.NC = NC; ta.EC = EC; ta.cpl = cpl;
+        ta.b = bt->b; ta.dp = wk.dp; ta.w0 = wk.w0; ta.nslots = wk.ns; ta.NC = NC; ta.EC = EC; ta.cpl = cpl;
         ta.m = c->prm.match; ta.n = c->prm.mismatch; ta.g = c->prm.gap;
         ta.sm = c->prm.sw_match; ta.sn = c->prm.sw_mismatch; ta.sg = c->prm.sw_gap;
         ta.wmat = wk.d_wmat; ta.wstride = (uint64_t)NC * c->wcols; ta.wcols = c->wcols; ta.c0w = wk.d_c0w; ta.only_wide = 0;
-        ta.stat = c->d_stat; ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC; ta.packed = c->packed ? 1 : 0; ta.kept = 0;
-        ta.bmat = wk.d_bmat; ta.band_par = wk.d_band_par; ta.band = c->band ? 1 : 0; ta.redo_list = nullptr; ta.redo_n = nullptr;
+        ta.stat = c->d_stat; ta.hmat = wk.d_hmat; ta.c0 = wk.d_c0; ta.job_end = wk.d_job_end; ta.job_type = wk.d_job_type; ta.PC = PC; ta.packed = bt->packed ? 1 : 0; ta.kept = 0;
+        ta.bmat = wk.d_bmat; ta.band_par = wk.d_band_par; ta.band = bt->band ? 1 : 0; ta.redo_list = nullptr; ta.redo_n = nullptr;
         ta.redo_out = wk.d_redo_list; ta.redo_out_n = wk.d_redo_n;
-        ta.cpl_lo = fold_lo(c);       // (the pipeline sets its own)
+        ta.cpl_lo = fold_lo(c, bt);       // (the pipeline sets its own)
         return ta;
     }
 
@@ -616,9 +675,9 @@ struct Plan {
     // banded store: the alignments whose backtrack needed a cell outside the band (a few per thousand) run once more with
     // whole rows, and are walked from there; both launches find their jobs on the list the first backtrack left
     int redo(Work& wk, VcFwdArgs fa, VcTraceArgs ta, uint32_t njobs, uint32_t max_rows, bool nwonly = false) {
-        if (!c->band || fa.mode == 2) return VC_OK;
+        if (!bt->band || fa.mode == 2) return VC_OK;
         fa.redo_list = wk.d_redo_list; fa.redo_n = wk.d_redo_n; fa.band = 0;
-        int rc = launch_fwd(c, wk.stream, fa, njobs, nullptr, nwonly);
+        int rc = launch_fwd(c, bt, wk.stream, fa, njobs, nullptr, nwonly);
         if (rc) return rc;
         ta.redo_list = wk.d_redo_list; ta.redo_n = wk.d_redo_n; ta.band = 0;
         launch_trace(wk, ta, njobs, 1, max_rows);         // listed jobs are of any window: no shared first-in-edge table
@@ -628,7 +687,7 @@ struct Plan {
     void begin(Work& wk, uint32_t w0, uint32_t ns) {
         wk.w0 = w0; wk.ns = ns; wk.cur = 0; wk.layers = 0; wk.nseq_max = 0; wk.active = true; wk.pruned_known = false;
         for (uint32_t w = w0; w < w0 + ns; ++w) {
-            const uint32_t n = c->h_win_seq_off[w + 1] - c->h_win_seq_off[w];
+            const uint32_t n = bt->h_win_seq_off[w + 1] - bt->h_win_seq_off[w];
             wk.nseq_max = std::max(wk.nseq_max, n);
             if (n >= 3) wk.layers = std::max(wk.layers, n - 1);
         }
@@ -637,8 +696,8 @@ struct Plan {
             (void)hipMemsetAsync(wk.gr[gi].n_nodes, 0, (size_t)ns * 4, wk.stream);   // images from the maximum over the chunk, skipped windows
             (void)hipMemsetAsync(wk.gr[gi].n_edges, 0, (size_t)ns * 4, wk.stream);   // (fewer than three sequences) included
         }
-        { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3(ns), dim3(64), 0, wk.stream, c->b, w0, ns); }
-        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), c->kept ? vc_kept_lds_bytes(NC) : 0, wk.stream, c->b, wk.gr[0], wk.dp, w0, ns, NC, EC, (uint32_t)kRing, c->kept); }
+        { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3(ns), dim3(64), 0, wk.stream, bt->b, w0, ns); }
+        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), bt->kept ? vc_kept_lds_bytes(NC) : 0, wk.stream, bt->b, wk.gr[0], wk.dp, w0, ns, NC, EC, (uint32_t)kRing, bt->kept); }
     }
 
     // one layer of the build loop (window.cpp:239-298) for every window of the chunk
@@ -646,10 +705,10 @@ struct Plan {
         const uint32_t ns = wk.ns;
         // the rows of a full-span layer were made at the tail of the kernel that last changed the graph (k_init / k_addaln);
         // a partial-span layer aligns to a Subgraph
-        if (c->h_layer_partial[j]) {
+        if (bt->h_layer_partial[j]) {
             Timer t(c, KC_ROWS, wk.stream);
-            const uint32_t sub_lds = std::max(8 * ((NC + 63) / 64) + 2 * NC + ((NC + 15) & ~15u) + 4 * (NC / 32 + 1) + 64, c->kept ? vc_kept_lds_bytes(NC) : 0u);
-            hipLaunchKernelGGL(k_rows_sub, dim3(ns), dim3(64), sub_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing, wk.d_submask, c->kept);
+            const uint32_t sub_lds = std::max(8 * ((NC + 63) / 64) + 2 * NC + ((NC + 15) & ~15u) + 4 * (NC / 32 + 1) + 64, bt->kept ? vc_kept_lds_bytes(NC) : 0u);
+            hipLaunchKernelGGL(k_rows_sub, dim3(ns), dim3(64), sub_lds, wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing, wk.d_submask, bt->kept);
         }
         VcFwdArgs fa = fwd_args(wk);
         fa.group = 1; fa.k0 = j; fa.mode = 0; fa.hstride = (uint64_t)NC * rowd;
@@ -658,23 +717,23 @@ struct Plan {
             HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
             HIPCHK(c, hipMemsetAsync(wk.d_redo_n, 0, 4, wk.stream));
         }
-        int rc = launch_fwd(c, wk.stream, fa, ns, &wk);
+        int rc = launch_fwd(c, bt, wk.stream, fa, ns, &wk);
         if (rc) return rc;
         { Timer t(c, KC_RESOLVE, wk.stream);
           const uint32_t rs_lds = 4 * ((NC + 31) / 32 + 1) + 2 * 256 + 16;
-          hipLaunchKernelGGL(k_resolve, dim3(kResolveGrid), dim3(64), rs_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
+          hipLaunchKernelGGL(k_resolve, dim3(kResolveGrid), dim3(64), rs_lds, wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
                              (const uint16_t*)wk.d_tie_rows, (const uint32_t*)wk.d_tie_cnt, (const uint32_t*)wk.d_pairs, PC, wk.d_job_end,
                              (const uint32_t*)wk.d_tie_list, (const uint32_t*)wk.d_tie_n, (const uint32_t*)wk.d_submask, (int)j,
                              wk.d_resolve_ws, (topo_lds + 15u) & ~15u, c->force_dfs ? 1 : 0); }
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
-        ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j; ta.kept = c->kept;
+        ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j; ta.kept = bt->kept;
         launch_trace(wk, ta, ns, 1, NC);
         if ((rc = redo(wk, fa, ta, ns, NC))) return rc;
         VcAddArgs aa{};
-        aa.b = c->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
+        aa.b = bt->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
         aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16; aa.ring = (uint32_t)kRing;
-        aa.make_rows = !(c->dbg_stop_kind == 1 && c->dbg_stop_index == j); aa.kept = c->kept;
+        aa.make_rows = !(c->dbg_stop_kind == 1 && c->dbg_stop_index == j); aa.kept = bt->kept;
         aa.tie_n = wk.d_tie_n; aa.redo_n = wk.d_redo_n;
         { Timer t(c, KC_ADDALN, wk.stream); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, wk.stream, aa); }
         return VC_OK;
@@ -684,7 +743,7 @@ struct Plan {
     // off device-side queues (vc_pipe.h) instead of build_layer() once per layer.
     bool pipe_ok() const {
         uint32_t ca_ = 0, cb_ = 0;
-        return c->pipe && c->kept && c->packed && c->band && c->wcols == 0 && c->dbg_stop_kind == 0 && c->trace_wave && pipe_classes(c, &ca_, &cb_);
+        return c->pipe && bt->kept && bt->packed && bt->band && c->wcols == 0 && c->dbg_stop_kind == 0 && c->trace_wave && pipe_classes(bt, &ca_, &cb_);
     }
     int build_pipe(Work& wk) {
         const uint32_t ns = wk.ns, cap = wk.pipe_cap;
@@ -705,7 +764,7 @@ struct Plan {
             wk.st_t = pooled_stream(c->device, (uint32_t)(&wk - c->works), true);
             if (!wk.st_t) return fail(c, VC_ERR_HIP, "hipStreamCreate failed");
         }
-        hipLaunchKernelGGL(k_pipe_seed, dim3((ns + 255) / 256), dim3(256), 0, wk.stream, c->b, p, wk.w0, ns);
+        hipLaunchKernelGGL(k_pipe_seed, dim3((ns + 255) / 256), dim3(256), 0, wk.stream, bt->b, p, wk.w0, ns);
         HIPCHK(c, hipEventRecord(wk.ev_seed, wk.stream));
         HIPCHK(c, hipStreamWaitEvent(wk.st_t, wk.ev_seed, 0));
 
@@ -717,9 +776,9 @@ struct Plan {
         VcPipeTraceArgs pt{};
         pt.ta = trace_args(wk);
         pt.ta.group = 1; pt.ta.k0 = 0; pt.ta.hstride = (uint64_t)NC * rowd;
-        pt.ta.pairs = wk.d_pairs; pt.ta.npairs = wk.d_npairs; pt.ta.pair_group = 1; pt.ta.pair_k0 = 0; pt.ta.kept = c->kept;
+        pt.ta.pairs = wk.d_pairs; pt.ta.npairs = wk.d_npairs; pt.ta.pair_group = 1; pt.ta.pair_k0 = 0; pt.ta.kept = bt->kept;
         pt.ta.shared_table = 0; pt.ta.tab_rows = std::min(NC, kTraceTabRows);
-        { uint32_t cb_ = 0; (void)pipe_classes(c, &pt.ta.cpl_lo, &cb_); }
+        { uint32_t cb_ = 0; (void)pipe_classes(bt, &pt.ta.cpl_lo, &cb_); }
         pt.p = p;
         pt.g = wk.gr[wk.cur]; pt.STK = c->STK;
         pt.tie_rows = wk.d_tie_rows; pt.tie_cnt = wk.d_tie_cnt; pt.tie_over = wk.d_pairs; pt.tie_over_stride = PC; pt.job_end = wk.d_job_end;
@@ -734,19 +793,19 @@ struct Plan {
         pf.fa = fwd_args(wk);
         pf.fa.group = 1; pf.fa.k0 = 0; pf.fa.mode = 0; pf.fa.hstride = (uint64_t)NC * rowd; pf.fa.do_init = 1;
         pf.fa.tie_over = wk.d_pairs; pf.fa.tie_over_stride = PC;
-        pf.aa.b = c->b; pf.aa.g = wk.gr[wk.cur]; pf.aa.dp = wk.dp; pf.aa.w0 = wk.w0; pf.aa.nslots = ns; pf.aa.NC = NC; pf.aa.EC = EC; pf.aa.layer = 0;
+        pf.aa.b = bt->b; pf.aa.g = wk.gr[wk.cur]; pf.aa.dp = wk.dp; pf.aa.w0 = wk.w0; pf.aa.nslots = ns; pf.aa.NC = NC; pf.aa.EC = EC; pf.aa.layer = 0;
         pf.aa.pairs = wk.d_pairs; pf.aa.npairs = wk.d_npairs; pf.aa.PC = PC; pf.aa.scratch = wk.d_scratch16; pf.aa.ring = (uint32_t)kRing;
-        pf.aa.make_rows = 1; pf.aa.kept = c->kept; pf.aa.tie_n = wk.d_tie_n; pf.aa.redo_n = wk.d_redo_n;
+        pf.aa.make_rows = 1; pf.aa.kept = bt->kept; pf.aa.tie_n = wk.d_tie_n; pf.aa.redo_n = wk.d_redo_n;
         pf.p = p; pf.submask = wk.d_submask; pf.force_fail_site = 0;
         bool any_partial = false;
-        for (uint8_t x : c->h_layer_partial) any_partial = any_partial || x;
-        uint32_t lds = std::max((uint32_t)(kKept ? kKept : 1) * (c->cpl / 2) * 64u * 4u, add_lds);
-        if (any_partial) lds = std::max(lds, vc_rows_sub_lds_bytes(NC, c->kept));
+        for (uint8_t x : bt->h_layer_partial) any_partial = any_partial || x;
+        uint32_t lds = std::max((uint32_t)(kKept ? kKept : 1) * (bt->cpl / 2) * 64u * 4u, add_lds);
+        if (any_partial) lds = std::max(lds, vc_rows_sub_lds_bytes(NC, bt->kept));
         lds = (lds + 255u) & ~255u;
         if (lds > kLdsCap) return fail(c, VC_ERR_ARG, "persistent pipeline: %u bytes of LDS per forward wave", lds);
         int rc;
         { Timer t(c, KC_PIPE, wk.stream);
-          if ((rc = launch_pipe_fwd(c, wk.stream, pf, std::min(GF, c->CW), lds))) return rc; }
+          if ((rc = launch_pipe_fwd(c, bt, wk.stream, pf, std::min(GF, c->CW), lds))) return rc; }
         HIPCHK(c, hipStreamWaitEvent(wk.stream, wk.ev_t, 0));
         return VC_OK;
     }
@@ -765,7 +824,7 @@ struct Plan {
             if (ECl == 0) ECl = 64;
         }
         VcPruneArgs pa{};
-        pa.b = c->b; pa.src = wk.gr[wk.cur]; pa.dst = wk.gr[wk.cur ^ 1]; pa.w0 = wk.w0; pa.nslots = ns; pa.NC = NC; pa.EC = EC;
+        pa.b = bt->b; pa.src = wk.gr[wk.cur]; pa.dst = wk.gr[wk.cur ^ 1]; pa.w0 = wk.w0; pa.nslots = ns; pa.NC = NC; pa.EC = EC;
         pa.NCl = NCl; pa.ECl = ECl;
         // the first prune works on the whole graph (60 KB image at 2 240 nodes): in LDS only two windows fit a CU, and beside a
         // full house of k_fwd waves not even one until eight of them retire; from the HBM workspace every window of the chunk
@@ -785,13 +844,13 @@ struct Plan {
             // workgroup its HBM workspace for the exception
             uint32_t NCt = NCl, ECt = ECl;
             if (!wk.pruned_known && c->big_ws_topo) {
-                NCt = std::min(NC, (uint32_t)((c->max_backbone * 5 / 4 + 127) & ~63u));
-                ECt = std::min(EC, (uint32_t)((c->max_backbone * 2 + 127) & ~63u));
+                NCt = std::min(NC, (uint32_t)((bt->max_backbone * 5 / 4 + 127) & ~63u));
+                ECt = std::min(EC, (uint32_t)((bt->max_backbone * 2 + 127) & ~63u));
             }
             bool tw = topo_lds_bytes(NCt, ECt, c->STK, c->MA) > kLdsCap;
             if (c->topo_hbm && c->big_ws_stride >= topo_lds_bytes(NCl, ECl, c->STK, c->MA)) { tw = true; NCt = NCl; ECt = ECl; }
             for (uint32_t rep = 0; rep < ((c->dup & 8u) ? 2u : 1u); ++rep) { Timer t(c, KC_TOPO, wk.stream);
-              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tw ? 0 : topo_lds_bytes(NCt, ECt, c->STK, c->MA), wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRingPruned, NCt, ECt,
+              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tw ? 0 : topo_lds_bytes(NCt, ECt, c->STK, c->MA), wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRingPruned, NCt, ECt,
                                  (tw || c->big_ws_topo) ? wk.d_big_ws : nullptr, c->big_ws_stride, tw ? 1 : 0); }
         }
         if (more) {
@@ -821,10 +880,10 @@ struct Plan {
         for (uint32_t k0 = 0; k0 < wk.nseq_max; k0 += group) {
             const uint32_t gsz = std::min(group, wk.nseq_max - k0);
             fa.group = gsz; fa.k0 = k0; fa.mode = 1; fa.hstride = stride;
-            if (c->band) HIPCHK(c, hipMemsetAsync(wk.d_redo_n, 0, 4, wk.stream));
+            if (bt->band) HIPCHK(c, hipMemsetAsync(wk.d_redo_n, 0, 4, wk.stream));
             bool nwonly = true;                                // no partial-span layer among these sequences in any window of the batch?
-            for (uint32_t k = std::max(k0, 1u); k < k0 + gsz; ++k) nwonly = nwonly && !(k < c->h_layer_partial.size() && c->h_layer_partial[k]);
-            int rc = launch_fwd(c, wk.stream, fa, ns * gsz, &wk, nwonly);
+            for (uint32_t k = std::max(k0, 1u); k < k0 + gsz; ++k) nwonly = nwonly && !(k < bt->h_layer_partial.size() && bt->h_layer_partial[k]);
+            int rc = launch_fwd(c, bt, wk.stream, fa, ns * gsz, &wk, nwonly);
             if (rc) return rc;
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
@@ -832,7 +891,7 @@ struct Plan {
             if ((rc = redo(wk, fa, ta, ns * gsz, maxn, nwonly))) return rc;
         }
         VcAddwArgs wa{};
-        wa.b = c->b; wa.g = wk.gr[wk.cur]; wa.dp = wk.dp; wa.w0 = wk.w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
+        wa.b = bt->b; wa.g = wk.gr[wk.cur]; wa.dp = wk.dp; wa.w0 = wk.w0; wa.nslots = ns; wa.NC = NC; wa.EC = EC;
         wa.pairs = wk.d_rpairs; wa.npairs = wk.d_rnpairs; wa.PC = PC; wa.pair_group = c->max_nseq;
         { Timer t(c, KC_ADDW, wk.stream); hipLaunchKernelGGL(k_addw, dim3(ns), dim3(64), 0, wk.stream, wa); }
         return VC_OK;
@@ -842,10 +901,10 @@ struct Plan {
     int linear_tail(Work& wk) {
         const uint32_t ns = wk.ns;
         { Timer t(c, KC_TOPO, wk.stream);
-          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds > kLdsCap ? 0 : topo_lds, wk.stream, c->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRingPruned, NC, EC,
+          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds > kLdsCap ? 0 : topo_lds, wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRingPruned, NC, EC,
                              topo_lds > kLdsCap ? wk.d_big_ws : nullptr, c->big_ws_stride, topo_lds > kLdsCap ? 1 : 0); }
         VcConsArgs ca{};
-        ca.b = c->b; ca.g = wk.gr[wk.cur]; ca.dp = wk.dp; ca.w0 = wk.w0; ca.nslots = ns; ca.NC = NC; ca.EC = EC;
+        ca.b = bt->b; ca.g = wk.gr[wk.cur]; ca.dp = wk.dp; ca.w0 = wk.w0; ca.nslots = ns; ca.NC = NC; ca.EC = EC;
         ca.trim = c->prm.trim; ca.window_type = c->prm.window_type;
         ca.ws = cons_lds > kLdsCap ? wk.d_big_ws : nullptr; ca.ws_stride = c->big_ws_stride;
         { Timer t(c, KC_CONS, wk.stream); hipLaunchKernelGGL(k_consensus, dim3(ns), dim3(64), cons_lds > kLdsCap ? 0 : cons_lds, wk.stream, ca); }
@@ -858,14 +917,14 @@ struct Plan {
         const uint32_t ns = wk.ns;
         VcFwdArgs fa = fwd_args(wk);
         fa.group = 1; fa.k0 = 0; fa.mode = 2; fa.hstride = (uint64_t)NC * rowd; fa.band = 0;
-        int rc = launch_fwd(c, wk.stream, fa, ns, &wk);
+        int rc = launch_fwd(c, bt, wk.stream, fa, ns, &wk);
         if (rc) return rc;
         VcTraceArgs ta = trace_args(wk);
         ta.group = 1; ta.k0 = 0; ta.hstride = fa.hstride; ta.band = 0;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = 0;
         launch_trace(wk, ta, ns, 1, NC);
         VcFinishArgs fn{};
-        fn.b = c->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;
+        fn.b = bt->b; fn.g = wk.gr[wk.cur]; fn.dp = wk.dp; fn.w0 = wk.w0; fn.nslots = ns; fn.NC = NC;
         fn.pairs = wk.d_pairs; fn.npairs = wk.d_npairs; fn.PC = PC;
         { Timer t(c, KC_FINISH, wk.stream); hipLaunchKernelGGL(k_finish, dim3(ns), dim3(64), 0, wk.stream, fn); }
         wk.active = false;
@@ -890,17 +949,52 @@ struct Plan {
     }
 };
 
-// host thread of chunk stream s: takes chunks off the batch until none is left
-void chunk_worker(vc_ctx* c, uint32_t s, Plan pl) {
-    if (hipSetDevice(c->device) != hipSuccess) { c->run_rc = fail(c, VC_ERR_HIP, "hipSetDevice failed in a chunk thread"); return; }
-    const uint32_t CW = c->cw_run, nw = c->b.n_windows;
+// Host thread of chunk stream s.  It takes the next chunk of the oldest queued batch that still has one -- when a batch has none
+// left it goes straight on to the batch queued behind it, so the device sees no gap between batches -- queues every phase of the
+// chunk on its stream, and records the batch's event of that stream behind it.
+void stream_worker(vc_ctx* c, uint32_t s) {
+    (void)hipSetDevice(c->device);
+    std::unique_lock<std::mutex> lk(c->qmu);
     for (;;) {
-        const uint32_t k = c->next_chunk.fetch_add(1);
-        if ((uint64_t)k * CW >= nw || c->run_rc.load() != VC_OK) break;
-        const uint32_t w0 = k * CW;
-        const int rc = pl.run_chunk(c->works[s], w0, std::min(CW, nw - w0));
-        if (rc) { c->run_rc = rc; break; }
+        Batch* bt = nullptr;
+        uint32_t k = 0;
+        for (Batch* q : c->runq)
+            if (s < q->n_streams && q->next_chunk < q->n_chunks) { bt = q; k = q->next_chunk++; break; }
+        if (!bt) {
+            if (c->stop) return;
+            c->qcv.wait(lk);
+            continue;
+        }
+        const bool skip = bt->run_rc != VC_OK;               // a chunk of this run failed: the rest is not started
+        lk.unlock();
+        int rc = VC_OK;
+        if (!skip) {
+            const uint32_t CW = bt->cw_run, nw = bt->b.n_windows, w0 = k * CW;
+            rc = bt->pl->run_chunk(c->works[s], w0, std::min(CW, nw - w0));
+            if (hipEventRecord(bt->done_ev[s], c->streams[s]) != hipSuccess && rc == VC_OK) rc = fail(c, VC_ERR_HIP, "hipEventRecord failed on chunk stream %u", s);
+        }
+        lk.lock();
+        if (!skip) bt->ev_rec[s] = true;
+        if (rc && bt->run_rc == VC_OK) bt->run_rc = rc;
+        if (++bt->chunks_done == bt->n_chunks) {
+            for (auto it = c->runq.begin(); it != c->runq.end(); ++it) if (*it == bt) { c->runq.erase(it); break; }
+            bt->queued = false;
+            c->qcv.notify_all();
+        }
     }
+}
+
+// the launch-time parameters of a run: everything derives from the workspace capacities and the batch's own classes
+Plan* make_plan(vc_ctx* c, Batch* bt) {
+    Plan* pl = new Plan();
+    pl->c = c; pl->bt = bt; pl->NC = c->NC; pl->EC = c->EC; pl->PC = c->PC; pl->cpl = bt->cpl;
+    pl->topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK, c->MA);
+    pl->prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
+    pl->add_lds = std::max(2 * c->PC + 2 * (c->PC - c->NC) + 64, bt->kept ? vc_kept_lds_bytes(c->NC) : 0u);
+    pl->rows_lds = 0;
+    pl->cons_lds = vc_cons_lds_bytes(c->NC, c->EC);
+    pl->rowd = 64ull * (bt->packed ? (uint64_t)vc_nds((int)c->ws_cpl) : c->ws_cpl / 2);
+    return pl;
 }
 
 }  // namespace
@@ -981,6 +1075,9 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     }
     (void)hipMemcpy(c->d_lut_w, lw, sizeof(lw), hipMemcpyHostToDevice);
     (void)hipMemcpy(c->d_lut_d, ld, sizeof(ld), hipMemcpyHostToDevice);
+    for (Batch& bt : c->bt)
+        for (uint32_t s = 0; s < kMaxStreams; ++s)
+            if (hipEventCreateWithFlags(&bt.done_ev[s], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { g_create_error = "event creation failed"; vc_destroy(c); return VC_ERR_HIP; }
     c->stats.n_classes = KC_N;
     for (int i = 0; i < KC_N; ++i) std::snprintf(c->stats.names[i], sizeof(c->stats.names[i]), "%s", kClassNames[i]);
     *out = c;
@@ -990,11 +1087,20 @@ int vc_create(vc_ctx** out, const vc_params* p) {
 void vc_destroy(vc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    sync_ctx(c);
+    drain(c);
+    {
+        std::lock_guard<std::mutex> lk(c->qmu);
+        c->stop = true;
+    }
+    c->qcv.notify_all();
+    for (uint32_t s = 0; s < c->workers_made; ++s) if (c->workers[s].joinable()) c->workers[s].join();
     free_workspaces(c);
     if (c->arena) (void)hipFree(c->arena);
-    free_list(c->batch_allocs);
-    for (auto& sl : c->slots) if (sl.p) (void)hipFree(sl.p);
+    for (Batch& bt : c->bt) {
+        for (auto& sl : bt.slots) if (sl.p) (void)hipFree(sl.p);
+        for (hipEvent_t e : bt.done_ev) if (e) (void)hipEventDestroy(e);
+        delete bt.pl;
+    }
     free_list(c->allocs);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) { if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); }
@@ -1010,14 +1116,14 @@ void* vc_stream(vc_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int vc_set_profile(vc_ctx* c, int profile) {
     if (!c || profile < 0 || profile > 2) return VC_ERR_ARG;
-    join_workers(c);                     // the chunk threads of a running batch read prm.profile and write the event records
+    drain(c);                            // the chunk threads of a running batch read prm.profile and write the event records
     c->prm.profile = profile;
     return VC_OK;
 }
 
 int vc_set_pipeline(vc_ctx* c, int on, uint32_t forward_waves, uint32_t backtrack_waves) {
     if (!c) return VC_ERR_ARG;
-    join_workers(c);
+    drain(c);
     c->pipe = on != 0; c->pipe_f = forward_waves; c->pipe_t = backtrack_waves;
     return VC_OK;
 }
@@ -1025,7 +1131,7 @@ int vc_set_pipeline(vc_ctx* c, int on, uint32_t forward_waves, uint32_t backtrac
 int vc_reserve(vc_ctx* c, uint64_t bytes) {
     if (!c) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    sync_ctx(c);
+    drain(c);
     free_workspaces(c);
     if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
     if (!bytes) {                                         // the default budget of vc_submit
@@ -1046,7 +1152,7 @@ int vc_reserve(vc_ctx* c, uint64_t bytes) {
 
 int vc_set_window_type(vc_ctx* c, int window_type) {
     if (!c || (window_type != 0 && window_type != 1)) return VC_ERR_ARG;
-    join_workers(c);
+    drain(c);
     c->prm.window_type = window_type;
     return VC_OK;
 }
@@ -1116,24 +1222,31 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
                 if ((int64_t)(hb->seq_off[q + 1] - hb->seq_off[q]) > std::max<int64_t>(allowed, 0)) pre[w] = VC_WIN_OVERFLOW;
     }
     }
-    if (c->idle) { join_workers(c); HIPCHK(c, hipStreamSynchronize(c->stream)); }      // (the chunk streams are the process's: another context may be running on them)
-    else sync_ctx(c);
-    if (c->auto_streams) {
-        const uint32_t want = nw >= kAutoStreamsFrom ? kAutoStreamsMany : kAutoStreamsFew;
-        if (want != c->n_streams) { free_workspaces(c); c->n_streams = want; }
+    // Which of the two batch slots this batch takes.  The last one again when it is neither running nor holding results nobody has
+    // collected (the serial caller: submit, run, collect, submit ...) -- else the other one, so that this batch is copied in while
+    // that one runs (a run still in flight in the slot taken is waited for; results not collected from it are dropped).
+    Batch* bt = c->cur ? c->cur : &c->bt[0];
+    {
+        bool busy;
+        { std::lock_guard<std::mutex> lk(c->qmu); busy = bt->queued; }
+        if (busy || (bt->ran && !bt->collected)) bt = bt == &c->bt[0] ? &c->bt[1] : &c->bt[0];
     }
-    c->have_batch = false; c->ran = false;
-    VcBatchDev& b = c->b;
+    int rc;
+    if ((rc = wait_batch(c, bt))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    bt->have = false; bt->ran = false; bt->collected = false;
+    uint32_t want_streams = c->n_streams;
+    if (c->auto_streams) want_streams = nw >= kAutoStreamsFrom ? kAutoStreamsMany : kAutoStreamsFew;
+    VcBatchDev& b = bt->b;
     b = VcBatchDev{};
     b.n_windows = nw;
     uint32_t* d_wso; uint64_t* d_so; uint32_t *d_sb, *d_se; uint8_t *d_hq, *d_ba, *d_qu, *d_wf;
-    int rc;
-    if ((rc = salloc(c, 0, &d_wso, nw + 1)) || (rc = salloc(c, 1, &d_so, nseq + 1)) ||
-        (rc = salloc(c, 2, &d_sb, nseq)) || (rc = salloc(c, 3, &d_se, nseq)) ||
-        (rc = salloc(c, 4, &d_hq, nseq)) || (rc = salloc(c, 5, &d_ba, nbytes + 16)) ||
-        (rc = salloc(c, 6, &d_qu, nbytes + 16)) || (rc = salloc(c, 7, &d_wf, nw)) ||
-        (rc = salloc(c, 8, &b.win_avg, nw)) || (rc = salloc(c, 9, &b.status, nw)) ||
-        (rc = salloc(c, 10, &b.cons_len, nw)) || (rc = salloc(c, 11, &b.errinfo, nw)))
+    if ((rc = salloc(c, bt, 0, &d_wso, nw + 1)) || (rc = salloc(c, bt, 1, &d_so, nseq + 1)) ||
+        (rc = salloc(c, bt, 2, &d_sb, nseq)) || (rc = salloc(c, bt, 3, &d_se, nseq)) ||
+        (rc = salloc(c, bt, 4, &d_hq, nseq)) || (rc = salloc(c, bt, 5, &d_ba, nbytes + 16)) ||
+        (rc = salloc(c, bt, 6, &d_qu, nbytes + 16)) || (rc = salloc(c, bt, 7, &d_wf, nw)) ||
+        (rc = salloc(c, bt, 8, &b.win_avg, nw)) || (rc = salloc(c, bt, 9, &b.status, nw)) ||
+        (rc = salloc(c, bt, 10, &b.cons_len, nw)) || (rc = salloc(c, bt, 11, &b.errinfo, nw)))
         return rc;
     HIPCHK(c, hipMemcpyAsync(d_wso, hb->win_seq_off, (nw + 1) * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_so, hb->seq_off, (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
@@ -1145,18 +1258,18 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     b.win_seq_off = d_wso; b.seq_off = d_so; b.seq_begin = d_sb; b.seq_end = d_se; b.seq_has_qual = d_hq;
     b.bases = d_ba; b.quals = d_qu; b.win_fasta = d_wf;
     b.lut_w = c->d_lut_w; b.lut_d = c->d_lut_d;
-    c->h_win_seq_off.assign(hb->win_seq_off, hb->win_seq_off + nw + 1);
-    c->h_layer_partial = layer_partial;
-    c->h_layer_partial.resize(std::max<size_t>(layer_partial.size(), max_nseq) + 2, 0);      // indexed by layer up to the deepest window of the batch
-    c->max_layers = max_layers; c->max_len = max_len;
-    c->h_pre_status = any_pre ? pre : std::vector<uint8_t>();
+    bt->h_win_seq_off.assign(hb->win_seq_off, hb->win_seq_off + nw + 1);
+    bt->h_layer_partial = layer_partial;
+    bt->h_layer_partial.resize(std::max<size_t>(layer_partial.size(), max_nseq) + 2, 0);      // indexed by layer up to the deepest window of the batch
+    bt->max_layers = max_layers; bt->max_len = max_len;
+    bt->h_pre_status = any_pre ? pre : std::vector<uint8_t>();
     if (max_len == 0) { max_len = 1; min_len = 1; }              // every window was outside the envelope
 
     // alphabet of the batch -> entries per aligned list (an aligned group holds distinct bytes, graph.cpp:258-277)
     uint32_t MA = 4;
     {
         uint32_t* d_mask = nullptr;
-        if ((rc = salloc(c, 15, &d_mask, 8))) return rc;
+        if ((rc = salloc(c, bt, 15, &d_mask, 8))) return rc;
         HIPCHK(c, hipMemsetAsync(d_mask, 0, 32, c->stream));
         hipLaunchKernelGGL(k_byte_presence, dim3(1024), dim3(256), 0, c->stream, (const uint8_t*)d_ba, nbytes, d_mask);
         uint32_t hm[8];
@@ -1175,7 +1288,12 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     // the capacities that exist (a few percent of difference would otherwise re-create ~100 GB of buffers, seconds per
     // batch).  Results do not depend on capacities; pinned capacities (max_nodes / max_edges) are taken literally.
     const bool have_ws = c->have_ws;
-    if (have_ws && !c->prm.max_nodes) NC = std::max(NC, c->NC);
+    if (have_ws && !c->prm.max_nodes) {
+        // (a batch that needs a little more than the workspaces hold gets a sixteenth on top: a stream of batches whose estimates
+        // creep upwards must not re-create the workspaces -- and wait for the batch in flight -- every time)
+        if (NC > c->NC) NC = std::min<uint32_t>(std::max(NC, (c->NC + c->NC / 16 + 63) & ~63u), 59968);
+        NC = std::max(NC, c->NC);
+    }
     if (have_ws) { MA = std::max(MA, c->MA); max_nseq = std::max(max_nseq, c->max_nseq); }
     const uint32_t ws_max_len = have_ws ? std::max(max_len, c->ws_max_len) : max_len;
     uint32_t EC = c->prm.max_edges ? c->prm.max_edges : (uint32_t)std::min<uint64_t>((uint64_t)(2.6 * NC), 32000);
@@ -1183,10 +1301,10 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     if (EC > 32000) EC = 32000;                     // k_prune_lcc keeps 2E adjacency offsets in 16 bits
     if (have_ws && !c->prm.max_edges) EC = std::max(EC, c->EC);
     if (NC > 59968) return fail(c, VC_ERR_ARG, "max_nodes %u exceeds the 16-bit id space (59968)", NC);
-    c->cpl = pick_cpl(std::min(max_len, kMaxColumns));                  // width classes of THIS batch (kernel selection)
-    c->packed = vc_row_packed(c->prm.match, c->prm.mismatch, c->prm.gap, (int)c->cpl) &&
-                vc_row_packed(c->prm.sw_match, c->prm.sw_mismatch, c->prm.sw_gap, (int)c->cpl);
-    c->cpl_min = pick_cpl(std::min(min_len, kMaxColumns));
+    bt->cpl = pick_cpl(std::min(max_len, kMaxColumns));                  // width classes of THIS batch (kernel selection)
+    bt->packed = vc_row_packed(c->prm.match, c->prm.mismatch, c->prm.gap, (int)bt->cpl) &&
+                 vc_row_packed(c->prm.sw_match, c->prm.sw_mismatch, c->prm.sw_gap, (int)bt->cpl);
+    bt->cpl_min = pick_cpl(std::min(min_len, kMaxColumns));
     const uint32_t cpl = pick_cpl(std::min(ws_max_len, kMaxColumns));   // width class the matrices are sized for
     const uint32_t lds_cap = kLdsCap;
     // graph images that do not fit the LDS are worked on in an HBM workspace (slower, not refused)
@@ -1196,7 +1314,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     if (c->prm.mode == 1 && vc_cons_lds_bytes(NC, EC) > lds_cap) big = std::max(big, vc_cons_lds_bytes(NC, EC));
     c->big_ws_topo = c->prm.mode == 0;                    // k_topo's LDS image of the first pruned graphs is sized optimistically: its fallback lives here
     if (c->big_ws_topo) big = std::max(big, std::max(topo_lds_bytes(NC, EC, c->STK, MA), vc_prune_lds_bytes(NC, EC)));   // (and the first prune's image, see Plan::prune)
-    c->max_backbone = max_backbone;
+    bt->max_backbone = max_backbone;
     big = (big + 255u) & ~255u;
     const uint32_t PC = NC + ws_max_len + 8;
 
@@ -1204,13 +1322,15 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     free_b += c->chunk_bytes;            // our own workspaces are reusable: the plan must not depend on whether they exist yet
-    const uint32_t S = c->n_streams;
+    // the workspaces of more streams than this batch wants are kept (it simply uses the first few): a small batch in a stream of
+    // large ones must not re-create them
+    const uint32_t S = c->have_ws ? std::max(want_streams, c->n_streams) : want_streams;
     // default budget: 60 % of what is free, but no more than 96 GiB -- config C runs at 97 % of its unrestricted rate with 64 GiB
     // (chunks of 4 096 windows) and at 86 % with 32 GiB (2 048), so holding more than that buys nothing (profiles/r3c_footprint.txt)
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : std::min<uint64_t>((uint64_t)(free_b * 0.6), 96ull << 30)) / S;
     const uint64_t budget_default = budget;
     if (c->arena) budget = (c->arena_bytes - std::min<size_t>(c->arena_bytes, 1u << 20)) / S;      // vc_reserve: the arena IS the budget (less the padding between its pieces)
-    const uint64_t rowd = 64ull * (c->packed ? (uint64_t)vc_nds((int)cpl) : cpl / 2);      // dwords per stored row: byte-packed (NDS per lane) or raw int16 pairs
+    const uint64_t rowd = 64ull * (bt->packed ? (uint64_t)vc_nds((int)cpl) : cpl / 2);      // dwords per stored row: byte-packed (NDS per lane) or raw int16 pairs
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6 + 16) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2) + EC * 2ull + 32) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
     // Can any alignment of this batch leave the packed-int16 kernel's envelope (vc_fwd_body's check, vc_int16_ok, on the worst
@@ -1220,7 +1340,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         !vc_int16_ok(c->prm.sw_match, c->prm.sw_mismatch, c->prm.sw_gap, NC, cpl, false)) maybe_wide = true;
     const uint32_t wcols = maybe_wide ? ((ws_max_len + 64 * VC_WIDE_CPL - 1) / (64 * VC_WIDE_CPL)) * (64 * VC_WIDE_CPL) : 0;
     // whole rows, + a quarter for the band where rows are byte-packed (raw int16 rows -- wide classes, unusual scores -- have no band)
-    const uint64_t per_job = NC * rowd * (c->packed ? 5 : 4) + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
+    const uint64_t per_job = NC * rowd * (bt->packed ? 5 : 4) + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
     // big alignments (3 kb reads: 58 MB of raw rows each; the int32 matrices of k_fwd_wide: 86 MB more): there the chunk size IS the
     // budget, and the 96-GiB cap would leave a few hundred alignments per stream -- take the 60 % whole
     if (!c->prm.scratch_bytes && !c->arena && (per_slot_fixed + per_job) * 1024ull > budget) budget = std::max<uint64_t>(budget, (uint64_t)(free_b * 0.6) / S);
@@ -1240,11 +1360,13 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     uint32_t group_max = 1 + (uint32_t)std::min<uint64_t>(spare / (per_job * CW), 7);
     if (group_max > max_nseq) group_max = max_nseq;
 
-    const bool same = have_ws && c->ws_packed == c->packed && c->wcols == wcols && c->MA == MA && c->NC == NC && c->EC == EC && c->CW >= CW && c->ws_cpl == cpl && c->PC == PC &&
+    const bool same = have_ws && S == c->n_streams && c->ws_packed == bt->packed && c->wcols == wcols && c->MA == MA && c->NC == NC && c->EC == EC && c->CW >= CW && c->ws_cpl == cpl && c->PC == PC &&
                       c->big_ws_stride == big && c->max_nseq == max_nseq;
     if (!same) {
+        drain(c);                           // the other batch may be running on the workspaces that go
         free_workspaces(c);
-        c->ws_packed = c->packed; c->wcols = wcols; c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->ws_cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
+        c->n_streams = S;
+        c->ws_packed = bt->packed; c->wcols = wcols; c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->ws_cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
         c->ws_max_len = ws_max_len;
         c->big_ws_stride = big;
         // re-alignment rounds work on pruned graphs (a quarter of NC rows, typically), so more alignments per window fit the
@@ -1261,78 +1383,86 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         c->have_ws = true;
     }
     b.cons_cap = NC;
-    c->kept = (kKept && NC < 32768 && !getenv("VC_PLAIN_RING")) ? (uint32_t)kKept : 0u;
-    c->band = c->packed && c->kept && c->trace_wave && !getenv("VC_NO_BAND");
-    if ((rc = salloc(c, 12, &b.cons, (size_t)nw * b.cons_cap))) return rc;
+    bt->kept = (kKept && NC < 32768 && !getenv("VC_PLAIN_RING")) ? (uint32_t)kKept : 0u;
+    bt->band = bt->packed && bt->kept && c->trace_wave && !getenv("VC_NO_BAND");
+    if ((rc = salloc(c, bt, 12, &b.cons, (size_t)nw * b.cons_cap))) return rc;
     HIPCHK(c, hipMemsetAsync(b.status, 0, nw, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, nw * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // chunks of this batch: as large as the workspace allows, and equal, so that the last round of chunks is not a lone one
     {
-        const uint64_t per_round = (uint64_t)S * c->CW;
+        const uint64_t SB = want_streams;
+        const uint64_t per_round = SB * c->CW;
         const uint64_t rounds = (nw + per_round - 1) / per_round;
-        uint64_t cw = (nw + S * rounds - 1) / (S * rounds);
+        uint64_t cw = (nw + SB * rounds - 1) / (SB * rounds);
         cw = std::min<uint64_t>((cw + 63) & ~63ull, c->CW);
-        c->cw_run = (uint32_t)std::max<uint64_t>(cw, 1);
+        bt->cw_run = (uint32_t)std::max<uint64_t>(cw, 1);
     }
-    c->stats.max_nodes = NC; c->stats.max_edges = EC; c->stats.chunk_windows = c->cw_run;
-    c->have_batch = true;
+    bt->n_streams = want_streams;
+    c->stats.max_nodes = NC; c->stats.max_edges = EC; c->stats.chunk_windows = bt->cw_run;
+    bt->have = true;
+    c->cur = bt;
     return VC_OK;
 }
 
 int vc_run(vc_ctx* c) {
     if (!c) return VC_ERR_ARG;
-    if (!c->have_batch) return fail(c, VC_ERR_STATE, "vc_run before vc_submit");
+    Batch* bt = c->cur;
+    if (!bt || !bt->have) return fail(c, VC_ERR_STATE, "vc_run before vc_submit");
     HIPCHK(c, hipSetDevice(c->device));
-    join_workers(c);
-    c->run_rc = VC_OK;
-    c->idle = false;
-    const VcBatchDev& b = c->b;
-    Plan pl{};
-    pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
-    pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK, c->MA);
-    pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
-    pl.add_lds = std::max(2 * c->PC + 2 * (c->PC - c->NC) + 64, c->kept ? vc_kept_lds_bytes(c->NC) : 0u);
-    pl.rows_lds = 0;
-    pl.cons_lds = vc_cons_lds_bytes(c->NC, c->EC);
-    pl.rowd = 64ull * (c->packed ? (uint64_t)vc_nds((int)c->ws_cpl) : c->ws_cpl / 2);
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.topo_lds, kLdsCap)));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_prune_lcc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.prune_lds, kLdsCap)));
+    int rc;
+    if ((rc = wait_batch(c, bt))) return rc;             // the same batch again: its last run must have left its buffers
+    const VcBatchDev& b = bt->b;
+    delete bt->pl;
+    Plan* const plp = bt->pl = make_plan(c, bt);
+    Plan& pl = *plp;
+    if ((rc = lds_limit(c, (const void*)k_topo, std::min(pl.topo_lds, kLdsCap))) || (rc = lds_limit(c, (const void*)k_prune_lcc, std::min(pl.prune_lds, kLdsCap)))) return rc;
     if (pl.add_lds > kLdsCap) return fail(c, VC_ERR_ARG, "a layer of %u bases on graphs of %u nodes needs %u bytes of LDS in k_addaln (limit %u)", c->ws_max_len, c->NC, pl.add_lds, kLdsCap);
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
-    if (c->kept) {
+    if ((rc = lds_limit(c, (const void*)k_addaln, pl.add_lds))) return rc;
+    if (bt->kept) {
         const uint32_t sub_lds = std::max(8 * ((c->NC + 63) / 64) + 2 * c->NC + ((c->NC + 15) & ~15u) + 4 * (c->NC / 32 + 1) + 64, vc_kept_lds_bytes(c->NC));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vc_kept_lds_bytes(c->NC)));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_rows_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sub_lds));
+        if ((rc = lds_limit(c, (const void*)k_init, vc_kept_lds_bytes(c->NC))) || (rc = lds_limit(c, (const void*)k_rows_sub, sub_lds))) return rc;
     }
-    if (c->prm.mode == 1)
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(pl.cons_lds, kLdsCap)));
-    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64 * VC_STAT_SLOTS, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_pipe_abort, 0, 64, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_pipe_prof, 0, VC_PP_TOTAL * 8, c->stream));
+    if (c->prm.mode == 1 && (rc = lds_limit(c, (const void*)k_consensus, std::min(pl.cons_lds, kLdsCap)))) return rc;
+    bool alone;                                          // no other run of this context is in flight: the counters are this run's
+    { std::lock_guard<std::mutex> lk(c->qmu); alone = c->runq.empty(); }
+    if (alone) {
+        HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64 * VC_STAT_SLOTS, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pipe_abort, 0, 64, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pipe_prof, 0, VC_PP_TOTAL * 8, c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
-    if (!c->h_pre_status.empty()) HIPCHK(c, hipMemcpyAsync(b.status, c->h_pre_status.data(), b.n_windows, hipMemcpyHostToDevice, c->stream));
+    if (!bt->h_pre_status.empty()) HIPCHK(c, hipMemcpyAsync(b.status, bt->h_pre_status.data(), b.n_windows, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(b.errinfo, 0, (size_t)b.n_windows * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, (size_t)b.n_windows * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < KC_N; ++i) { c->stats.ms[i] = 0; c->stats.busy_ms[i] = 0; c->stats.launches[i] = 0; }
+    if (alone) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (int i = 0; i < KC_N; ++i) { c->stats.ms[i] = 0; c->stats.busy_ms[i] = 0; c->stats.launches[i] = 0; }
+    }
+    c->stats.chunk_windows = bt->cw_run; c->stats.n_streams = bt->n_streams;
 
-    const uint32_t S = c->n_streams, CW = c->cw_run;
+    const uint32_t S = bt->n_streams, CW = bt->cw_run;
+    bt->collected = false; bt->run_rc = VC_OK; bt->run_seq = ++c->run_counter;
+    for (uint32_t s = 0; s < kMaxStreams; ++s) bt->ev_rec[s] = false;
     if (c->host_threads && c->dbg_stop_kind == 0) {
-        c->next_chunk = 0; c->run_rc = VC_OK;
-        for (uint32_t s = 0; s < S; ++s) c->works[s].active = false;
-        const uint32_t n_chunks = (b.n_windows + CW - 1) / CW;
-        c->workers_running = true;
         try {
-            for (uint32_t s = 0; s < S && s < n_chunks; ++s) c->workers[s] = std::thread(chunk_worker, c, s, pl);
-        } catch (const std::exception& e) {                  // (no exception may cross the C boundary) the threads that did start finish the batch
-            bool any = false;
-            for (uint32_t s = 0; s < S; ++s) any = any || c->workers[s].joinable();
-            if (!any) { c->workers_running = false; return fail(c, VC_ERR_STATE, "cannot start a chunk thread: %s", e.what()); }
+            while (c->workers_made < S) { c->workers[c->workers_made] = std::thread(stream_worker, c, c->workers_made); c->workers_made++; }
+        } catch (const std::exception& e) {                  // (no exception may cross the C boundary)
+            return fail(c, VC_ERR_STATE, "cannot start a chunk thread: %s", e.what());
         }
-        c->ran = true;                      // vc_sync joins the threads and reports what they met
+        {
+            std::lock_guard<std::mutex> lk(c->qmu);
+            bt->next_chunk = 0; bt->chunks_done = 0; bt->n_chunks = (b.n_windows + CW - 1) / CW;
+            bt->queued = true;
+            c->runq.push_back(bt);
+        }
+        c->qcv.notify_all();
+        bt->ran = true;                     // vc_sync / vc_collect wait for the workers and report what they met
         return VC_OK;
     }
+    // development / test hooks (vc_debug_stop_after, VC_HOST_THREADS=0): this thread walks the streams in lock-step, nothing else in flight
+    drain(c);
     for (uint32_t g0 = 0; g0 < b.n_windows; g0 += S * CW) {
         // S chunks advance in lockstep, each on its own stream
         uint32_t max_layers = 0;
@@ -1343,11 +1473,10 @@ int vc_run(vc_ctx* c) {
             pl.begin(c->works[s], w0, std::min(CW, b.n_windows - w0));
             max_layers = std::max(max_layers, c->works[s].layers);
         }
-        int rc;
         for (uint32_t j = 1; j <= max_layers; ++j) {
             for (uint32_t s = 0; s < S; ++s)
                 if (c->works[s].active && j <= c->works[s].layers && (rc = pl.build_layer(c->works[s], j))) return rc;
-            if (c->dbg_stop_kind == 1 && c->dbg_stop_index == j) { c->ran = false; return VC_OK; }
+            if (c->dbg_stop_kind == 1 && c->dbg_stop_index == j) { bt->ran = false; return VC_OK; }
         }
         if (c->prm.mode == 1) {
             for (uint32_t s = 0; s < S; ++s) {
@@ -1361,11 +1490,11 @@ int vc_run(vc_ctx* c) {
             const bool more = r + 1 < c->prm.num_prune;
             for (uint32_t s = 0; s < S; ++s)
                 if (c->works[s].active && c->works[s].layers && (rc = pl.prune(c->works[s], more))) return rc;
-            if (c->dbg_stop_kind == 2 && c->dbg_stop_index == r) { c->ran = false; return VC_OK; }
+            if (c->dbg_stop_kind == 2 && c->dbg_stop_index == r) { bt->ran = false; return VC_OK; }
             if (!more) break;
             for (uint32_t s = 0; s < S; ++s)
                 if (c->works[s].active && c->works[s].layers && (rc = pl.realign(c->works[s]))) return rc;
-            if (c->dbg_stop_kind == 3 && c->dbg_stop_index == r) { c->ran = false; return VC_OK; }
+            if (c->dbg_stop_kind == 3 && c->dbg_stop_index == r) { bt->ran = false; return VC_OK; }
         }
         for (uint32_t s = 0; s < S; ++s) {
             if (!c->works[s].active) continue;
@@ -1373,106 +1502,155 @@ int vc_run(vc_ctx* c) {
             else c->works[s].active = false;
         }
     }
+    for (uint32_t s = 0; s < S; ++s) { HIPCHK(c, hipEventRecord(bt->done_ev[s], c->streams[s])); bt->ev_rec[s] = true; }
     HIPCHK(c, hipGetLastError());
-    c->ran = true;
+    bt->ran = true;
     return VC_OK;
 }
+
+namespace {
+// the run of a batch is over: what it met
+int finish_run(vc_ctx* c, Batch* bt) {
+    int rc = wait_batch(c, bt);
+    if (rc) { bt->ran = false; return rc; }
+    if (bt->run_rc != VC_OK) { bt->ran = false; return bt->run_rc; }       // the run failed: its own error text stands (vc_last_error)
+    if (c->pipe && c->d_pipe_abort) {
+        uint32_t ab = 0;
+        HIPCHK(c, hipMemcpyAsync(&ab, c->d_pipe_abort, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (ab) { bt->ran = false; bt->run_rc = VC_ERR_HIP; return fail(c, VC_ERR_HIP, "persistent build pipeline gave up waiting (site %u): the run has no result", ab); }
+    }
+    return VC_OK;
+}
+// the batch vc_collect / vc_result_size speak of: the oldest run whose results nobody has taken; none such: the latest run
+Batch* collect_target(vc_ctx* c) {
+    Batch* best = nullptr;
+    for (Batch& bt : c->bt) if (bt.have && bt.ran && !bt.collected && (!best || bt.run_seq < best->run_seq)) best = &bt;
+    if (best) return best;
+    for (Batch& bt : c->bt) if (bt.have && bt.ran && (!best || bt.run_seq > best->run_seq)) best = &bt;
+    return best;
+}
+}  // namespace
 
 int vc_sync(vc_ctx* c) {
     if (!c) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    join_workers(c);
-    for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s]));
-    for (uint32_t s = 0; s < c->n_streams; ++s) if (c->works[s].st_t) HIPCHK(c, hipStreamSynchronize(c->works[s].st_t));
-    c->idle = true;
-    if (c->prm.profile) flush_events(c);
-    if (c->run_rc.load() != VC_OK) { c->ran = false; return c->run_rc.load(); }
+    int rc = VC_OK;
+    for (int pass = 0; pass < 2; ++pass)                     // in the order they were run
+        for (Batch& bt : c->bt) {
+            if (!bt.have || !bt.ran) continue;
+            const bool older = !c->cur || &bt != c->cur;
+            if ((pass == 0) != older) continue;
+            const int r = finish_run(c, &bt);
+            if (r && !rc) rc = r;
+        }
+    if (c->prm.profile) { std::lock_guard<std::mutex> lk(c->mu); flush_events(c); }
+    if (rc) return rc;
     HIPCHK(c, hipGetLastError());
-    if (c->pipe && c->d_pipe_abort) {
-        uint32_t ab = 0;
-        HIPCHK(c, hipMemcpy(&ab, c->d_pipe_abort, 4, hipMemcpyDeviceToHost));
-        if (ab) { c->ran = false; c->run_rc = VC_ERR_HIP; return fail(c, VC_ERR_HIP, "persistent build pipeline gave up waiting (site %u): the run has no result", ab); }
-    }
     return VC_OK;
 }
 
-static int fetch_lengths(vc_ctx* c) {
-    join_workers(c);
-    if (c->run_rc.load() != VC_OK) return c->run_rc.load();                  // the run failed: its own error text stands (vc_last_error)
-    if (!c->ran) return fail(c, VC_ERR_STATE, "no finished run");
-    if (!c->idle) { for (uint32_t s = 0; s < c->n_streams; ++s) HIPCHK(c, hipStreamSynchronize(c->streams[s])); c->idle = true; }
-    const uint32_t nw = c->b.n_windows;
-    c->h_cons_len.resize(nw); c->h_status.resize(nw);
-    HIPCHK(c, hipMemcpyAsync(c->h_cons_len.data(), c->b.cons_len, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_status.data(), c->b.status, nw, hipMemcpyDeviceToHost, c->stream));
+static int fetch_lengths(vc_ctx* c, Batch** out) {
+    Batch* bt = collect_target(c);
+    if (!bt) {
+        for (Batch& x : c->bt) if (x.have && x.run_rc != VC_OK) return x.run_rc;      // the run failed: its own error text stands
+        return fail(c, VC_ERR_STATE, "no finished run");
+    }
+    int rc = finish_run(c, bt);
+    if (rc) return rc;
+    const uint32_t nw = bt->b.n_windows;
+    bt->h_cons_len.resize(nw); bt->h_status.resize(nw);
+    HIPCHK(c, hipMemcpyAsync(bt->h_cons_len.data(), bt->b.cons_len, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bt->h_status.data(), bt->b.status, nw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint64_t tot = 0;
     for (uint32_t w = 0; w < nw; ++w) {
-        if (c->h_status[w] > VC_WIN_UNPOLISHED) c->h_cons_len[w] = 0;
-        tot += c->h_cons_len[w];
+        if (bt->h_status[w] > VC_WIN_UNPOLISHED) bt->h_cons_len[w] = 0;
+        tot += bt->h_cons_len[w];
     }
-    c->total_cons = tot;
+    bt->total_cons = tot;
+    *out = bt;
     return VC_OK;
 }
 
 int vc_result_size(vc_ctx* c, uint64_t* cons_bytes) {
     if (!c || !cons_bytes) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = fetch_lengths(c);
+    Batch* bt = nullptr;
+    int rc = fetch_lengths(c, &bt);
     if (rc) return rc;
-    *cons_bytes = c->total_cons;
+    *cons_bytes = bt->total_cons;
     return VC_OK;
 }
+
+int vc_result_windows(vc_ctx* c, uint32_t* n_windows) {
+    if (!c || !n_windows) return VC_ERR_ARG;
+    Batch* bt = collect_target(c);
+    if (!bt) return fail(c, VC_ERR_STATE, "no run to collect");
+    *n_windows = bt->b.n_windows;
+    return VC_OK;
+}
+
+namespace {
+int collect_device(vc_ctx* c, Batch* bt, void* d_cons, uint64_t cons_cap, void* d_cons_off, void* d_status) {
+    if (bt->total_cons > cons_cap) return fail(c, VC_ERR_CAPACITY, "consensus needs %llu bytes, buffer has %llu",
+                                               (unsigned long long)bt->total_cons, (unsigned long long)cons_cap);
+    const uint32_t nw = bt->b.n_windows;
+    std::vector<uint64_t> off(nw + 1, 0);
+    for (uint32_t w = 0; w < nw; ++w) off[w + 1] = off[w] + bt->h_cons_len[w];
+    HIPCHK(c, hipMemcpyAsync(d_cons_off, off.data(), (size_t)(nw + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    // statuses > UNPOLISHED publish no bytes: zero their lengths on the device view used by the gather
+    HIPCHK(c, hipMemcpyAsync(bt->b.cons_len, bt->h_cons_len.data(), (size_t)nw * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_gather_cons, dim3(nw), dim3(64), 0, c->stream, bt->b, (const uint64_t*)d_cons_off, (uint8_t*)d_cons, cons_cap);
+    if (d_status) HIPCHK(c, hipMemcpyAsync(d_status, bt->b.status, nw, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VC_OK;
+}
+}  // namespace
 
 int vc_collect_device(vc_ctx* c, void* d_cons, uint64_t cons_cap, void* d_cons_off, void* d_status) {
     if (!c || !d_cons || !d_cons_off) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = fetch_lengths(c);
+    Batch* bt = nullptr;
+    int rc = fetch_lengths(c, &bt);
     if (rc) return rc;
-    if (c->total_cons > cons_cap) return fail(c, VC_ERR_CAPACITY, "consensus needs %llu bytes, buffer has %llu",
-                                              (unsigned long long)c->total_cons, (unsigned long long)cons_cap);
-    const uint32_t nw = c->b.n_windows;
-    std::vector<uint64_t> off(nw + 1, 0);
-    for (uint32_t w = 0; w < nw; ++w) off[w + 1] = off[w] + c->h_cons_len[w];
-    HIPCHK(c, hipMemcpyAsync(d_cons_off, off.data(), (size_t)(nw + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    // statuses > UNPOLISHED publish no bytes: zero their lengths on the device view used by the gather
-    HIPCHK(c, hipMemcpyAsync(c->b.cons_len, c->h_cons_len.data(), (size_t)nw * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_gather_cons, dim3(nw), dim3(64), 0, c->stream, c->b, (const uint64_t*)d_cons_off, (uint8_t*)d_cons, cons_cap);
-    if (d_status) HIPCHK(c, hipMemcpyAsync(d_status, c->b.status, nw, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = collect_device(c, bt, d_cons, cons_cap, d_cons_off, d_status))) return rc;
+    bt->collected = true;
     return VC_OK;
 }
 
 int vc_collect(vc_ctx* c, vc_result* r) {
     if (!c || !r || !r->cons_off || !r->status) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = fetch_lengths(c);
+    Batch* bt = nullptr;
+    int rc = fetch_lengths(c, &bt);
     if (rc) return rc;
-    if (c->total_cons > r->cons_cap || (c->total_cons && !r->cons))
+    if (bt->total_cons > r->cons_cap || (bt->total_cons && !r->cons))
         return fail(c, VC_ERR_CAPACITY, "consensus needs %llu bytes, buffer has %llu",
-                    (unsigned long long)c->total_cons, (unsigned long long)r->cons_cap);
-    const uint32_t nw = c->b.n_windows;
+                    (unsigned long long)bt->total_cons, (unsigned long long)r->cons_cap);
+    const uint32_t nw = bt->b.n_windows;
     uint8_t* d_out = nullptr; uint64_t* d_off = nullptr;
-    if ((rc = salloc(c, 13, &d_out, c->total_cons + 16)) || (rc = salloc(c, 14, &d_off, (size_t)nw + 1))) return rc;
-    rc = vc_collect_device(c, d_out, c->total_cons + 16, d_off, nullptr);
-    if (rc == VC_OK) {
-        hipError_t e = hipMemcpy(r->cons, d_out, c->total_cons, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(c, VC_ERR_HIP, "D2H of consensus failed: %s", hipGetErrorString(e));
+    if ((rc = salloc(c, bt, 13, &d_out, bt->total_cons + 16)) || (rc = salloc(c, bt, 14, &d_off, (size_t)nw + 1))) return rc;
+    rc = collect_device(c, bt, d_out, bt->total_cons + 16, d_off, nullptr);
+    if (rc == VC_OK && bt->total_cons) {
+        HIPCHK(c, hipMemcpyAsync(r->cons, d_out, bt->total_cons, hipMemcpyDeviceToHost, c->stream));      // (on the context's own stream: the next batch's chunks keep running)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     if (rc) return rc;
     r->cons_off[0] = 0;
     for (uint32_t w = 0; w < nw; ++w) {
-        r->cons_off[w + 1] = r->cons_off[w] + c->h_cons_len[w];
-        r->status[w] = c->h_status[w];
+        r->cons_off[w + 1] = r->cons_off[w] + bt->h_cons_len[w];
+        r->status[w] = bt->h_status[w];
     }
+    bt->collected = true;
     return VC_OK;
 }
 
 int vc_debug_errinfo(vc_ctx* c, uint32_t* out) {
-    if (!c || !out || !c->have_batch) return VC_ERR_ARG;
+    if (!c || !out || !(c->cur && c->cur->have)) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    sync_ctx(c);
-    HIPCHK(c, hipMemcpy(out, c->b.errinfo, (size_t)c->b.n_windows * 4, hipMemcpyDeviceToHost));
+    sync_all(c);
+    HIPCHK(c, hipMemcpy(out, c->cur->b.errinfo, (size_t)c->cur->b.n_windows * 4, hipMemcpyDeviceToHost));
     return VC_OK;
 }
 
@@ -1489,10 +1667,10 @@ int vc_debug_stop_after(vc_ctx* c, uint32_t kind, uint32_t index) {
 // oracle/ref_harness.cpp:vcref_window_stages (nodes, edges, hash(nodes: byte, aligned ids), hash(edges: tail, head, weight),
 // pairs, hash(pairs: node id or -1, sequence position or -1)); out[0..1] are left to the caller.  Single-chunk batches only.
 int vc_debug_stage_digest(vc_ctx* c, uint32_t w, int with_pairs, uint64_t* out) {
-    if (!c || !out || !c->have_batch || w >= c->b.n_windows) return VC_ERR_ARG;
+    if (!c || !out || !(c->cur && c->cur->have) || w >= c->cur->b.n_windows) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->b.n_windows > c->cw_run) return fail(c, VC_ERR_ARG, "vc_debug_stage_digest: the batch spans several chunks");
-    sync_ctx(c);
+    if (c->cur->b.n_windows > c->cur->cw_run) return fail(c, VC_ERR_ARG, "vc_debug_stage_digest: the batch spans several chunks");
+    sync_all(c);
     const Work& wk = c->works[0];
     const VcGraph& g = wk.gr[wk.cur];
     const uint32_t slot = w, NC = c->NC, EC = c->EC, MA = c->MA;
@@ -1540,9 +1718,9 @@ int vc_debug_stage_digest(vc_ctx* c, uint32_t w, int with_pairs, uint64_t* out) 
 // development (tools/gpu_rowstats.py): the row records (backtrack view, 4 dwords per row) that the next alignment of window w will
 // use, after a run stopped with vc_debug_stop_after; returns the number of rows through *nrows.  Single-chunk batches only.
 int vc_debug_rows(vc_ctx* c, uint32_t w, uint32_t* out, uint32_t cap_rows, uint32_t* nrows) {
-    if (!c || !out || !nrows || !c->have_batch || w >= c->b.n_windows || c->b.n_windows > c->cw_run) return VC_ERR_ARG;
+    if (!c || !out || !nrows || !(c->cur && c->cur->have) || w >= c->cur->b.n_windows || c->cur->b.n_windows > c->cur->cw_run) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    sync_ctx(c);
+    sync_all(c);
     const Work& wk = c->works[0];
     uint32_t n = 0;
     HIPCHK(c, hipMemcpy(&n, wk.dp.nrows + w, 4, hipMemcpyDeviceToHost));
@@ -1556,23 +1734,20 @@ int vc_debug_rows(vc_ctx* c, uint32_t w, uint32_t* out, uint32_t cap_rows, uint3
 // development (tools/gpu_fwd_lab.py): build the first chunk up to `layer`, prepare that layer's rows, then time `reps`
 // launches of k_fwd alone with parts of its row loop switched off (VcFwdArgs::dbg).  Nothing downstream runs.
 int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, float* ms_out, unsigned long long* cells_out) {
-    if (!c || !c->have_batch) return VC_ERR_ARG;
+    if (!c || !(c->cur && c->cur->have)) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    Plan pl{};
-    pl.c = c; pl.NC = c->NC; pl.EC = c->EC; pl.PC = c->PC; pl.cpl = c->cpl;
-    pl.topo_lds = topo_lds_bytes(c->NC, c->EC, c->STK, c->MA);
-    pl.prune_lds = vc_prune_lds_bytes(c->NC, c->EC);
-    pl.add_lds = std::max(2 * c->PC + 2 * (c->PC - c->NC) + 64, c->kept ? vc_kept_lds_bytes(c->NC) : 0u);
-    pl.rows_lds = 0; pl.cons_lds = 0;
-    pl.rowd = 64ull * (c->packed ? (uint64_t)vc_nds((int)c->ws_cpl) : c->ws_cpl / 2);
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_addaln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.add_lds));
-    HIPCHK(c, hipMemsetAsync(c->b.status, 0, c->b.n_windows, c->stream));
+    Batch* const bt = c->cur;
+    delete bt->pl;
+    bt->pl = make_plan(c, bt);
+    Plan& pl = *bt->pl;
+    { int rc_ = lds_limit(c, (const void*)k_addaln, pl.add_lds); if (rc_) return rc_; }
+    HIPCHK(c, hipMemsetAsync(c->cur->b.status, 0, c->cur->b.n_windows, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     Work& wk = c->works[0];
     static uint32_t built_to = 0;
     int rc;
     if (built_to != layer) {
-        pl.begin(wk, 0, std::min(c->cw_run, c->b.n_windows));
+        pl.begin(wk, 0, std::min(c->cur->cw_run, c->cur->b.n_windows));
         for (uint32_t j = 1; j < layer; ++j) if ((rc = pl.build_layer(wk, j))) return rc;
         built_to = layer;
     }
@@ -1582,11 +1757,11 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
     HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
-    if ((rc = launch_fwd(c, wk.stream, fa, wk.ns))) return rc;            // warm-up
+    if ((rc = launch_fwd(c, bt, wk.stream, fa, wk.ns))) return rc;            // warm-up
     HIPCHK(c, hipEventRecord(e0, wk.stream));
     for (uint32_t r = 0; r < reps; ++r) {
         HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
-        if ((rc = launch_fwd(c, wk.stream, fa, wk.ns))) return rc;
+        if ((rc = launch_fwd(c, bt, wk.stream, fa, wk.ns))) return rc;
     }
     HIPCHK(c, hipEventRecord(e1, wk.stream));
     HIPCHK(c, hipEventSynchronize(e1));
@@ -1606,15 +1781,15 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
 // development: the persistent pipeline's counters and the per-window words its waves hand to each other, for the first `n` windows
 // of chunk stream 0: out[0..VC_PC_N) counters, then per window {layer, job_end, job_type, npairs}
 int vc_debug_pipe_state(vc_ctx* c, uint32_t* out, uint32_t n) {
-    if (!c || !out || !c->have_batch) return VC_ERR_ARG;
+    if (!c || !out || !(c->cur && c->cur->have)) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    sync_ctx(c);
+    sync_all(c);
     const Work& wk = c->works[0];
     std::vector<uint32_t> ctl((size_t)VC_PC_N * VC_PIPE_CTL_STRIDE);
     HIPCHK(c, hipMemcpy(ctl.data(), wk.d_pipe_ctl, ctl.size() * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < 10; ++i) out[i] = i < VC_PC_N ? ctl[(size_t)i * VC_PIPE_CTL_STRIDE] : 0u;
     HIPCHK(c, hipMemcpy(&out[9], c->d_pipe_abort, 4, hipMemcpyDeviceToHost));
-    n = std::min(n, c->cw_run);
+    n = std::min(n, c->cur->cw_run);
     std::vector<uint32_t> a(n), b(n), d(n); std::vector<uint8_t> t(n);
     HIPCHK(c, hipMemcpy(a.data(), wk.d_cur_layer, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(b.data(), wk.d_job_end, n * 4, hipMemcpyDeviceToHost));
@@ -1637,7 +1812,7 @@ int vc_debug_pipe_state(vc_ctx* c, uint32_t* out, uint32_t n) {
 int vc_debug_pipe_prof(vc_ctx* c, unsigned long long* out) {
     if (!c || !out) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    sync_ctx(c);
+    sync_all(c);
     HIPCHK(c, hipMemcpy(out, c->d_pipe_prof, VC_PP_TOTAL * 8, hipMemcpyDeviceToHost));
     return VC_OK;
 }
@@ -1645,7 +1820,7 @@ int vc_debug_pipe_prof(vc_ctx* c, unsigned long long* out) {
 int vc_get_stats(vc_ctx* c, vc_stats* s) {
     if (!c || !s) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    join_workers(c);                     // launch counters and event records belong to the chunk threads until they are done
+    drain(c);                            // launch counters and event records belong to the chunk threads until they are done
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, raw[8 * VC_STAT_SLOTS];
     HIPCHK(c, hipMemcpy(raw, c->d_stat, sizeof(raw), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8 * VC_STAT_SLOTS; ++i) st[i % 8] += raw[i];
@@ -1655,7 +1830,7 @@ int vc_get_stats(vc_ctx* c, vc_stats* s) {
     c->stats.band_redo = st[7];
     {
         uint64_t held = c->chunk_bytes + c->arena_bytes;
-        for (auto& sl : c->slots) held += sl.cap;
+        for (Batch& bt : c->bt) for (auto& sl : bt.slots) held += sl.cap;
         c->stats.device_bytes = held;
     }
 #ifdef VC_ADD_PROF
@@ -1663,7 +1838,6 @@ int vc_get_stats(vc_ctx* c, vc_stats* s) {
       fprintf(stderr, "[add prof] waves %llu  ticks per wave: A %llu  B %llu  C %llu  D %llu  rows %llu\n", h[7], h[7] ? h[0] / h[7] : 0, h[7] ? h[1] / h[7] : 0, h[7] ? h[2] / h[7] : 0, h[7] ? h[3] / h[7] : 0, h[7] ? h[4] / h[7] : 0); }
 #endif
     c->stats.alignments = c->stats.launches[KC_FWD];
-    c->stats.n_streams = c->n_streams;
     *s = c->stats;
     return VC_OK;
 }

@@ -162,6 +162,15 @@ __device__ __forceinline__ uint32_t vw_wait(const VcPipe& p, const VcQueue& q, u
     vq_stu64(s, 0u, 0u);                                                        // empty again
     return val;
 }
+// the value behind ticket t when it is there within a few polls, else VC_Q_NONE -- the ticket then stays the caller's to wait for later
+__device__ __forceinline__ uint32_t vw_peek(const VcQueue& q, uint32_t t) {
+    const uint32_t want = (t >> q.shift) + 1u;
+    unsigned long long* s = &q.slots[t & q.mask];
+    if (vq_poll_tag(s, want, 4u, 0u) != want) return VC_Q_NONE;
+    const uint32_t val = vq_ldu(reinterpret_cast<const uint32_t*>(s));
+    vq_stu64(s, 0u, 0u);
+    return val;
+}
 // a ticket only if an item stands behind it (reserved by its producer, written at once)
 __device__ __forceinline__ uint32_t vw_try(const VcPipe& p, const VcQueue& q, uint32_t site) {
     uint32_t got = VC_Q_NONE;
@@ -334,22 +343,75 @@ __global__ __launch_bounds__(64) VC_PIPE_TRACE_OCC void k_pipe_trace(VcPipeTrace
     if (vq_ldu(a.p.n_active) == 0 || vq_ldu(a.p.abort_code) != 0) return;
     unsigned long long t_wait = 0, t_walk = 0, t_hand = 0, t_tie = 0, n_rounds = 0, n_items = 0, n_ties = 0;
     const unsigned long long t_born = wall_clock64();
+    uint32_t owe[VC_TG - 1] = {VC_Q_NONE, VC_Q_NONE, VC_Q_NONE};       // tickets this wave drew whose items had not arrived when it looked
     for (;;) {
         const unsigned long long c0 = wall_clock64();
-        uint32_t v0 = vw_wait(a.p, a.p.tq, vq_inc(a.p.tq.head), 2), v1 = VC_Q_NONE, v2 = VC_Q_NONE, v3 = VC_Q_NONE;
-        if (v0 != VC_Q_NONE) {
-            // the other three groups: tickets only for items that stand in the queue.  With a backlog the tickets are simply
-            // drawn (a compare-and-swap on a counter that a thousand waves advance every half microsecond never succeeds:
-            // the first version took 1.4 windows per round while 12 000 were queued); near-empty, one at a time
-            const int avail = (int)(vq_ldc(a.p.tq.res) - vq_ldc(a.p.tq.head));
-            if (avail >= 64) {
-                const uint32_t t1 = vq_add(a.p.tq.head, VC_TG - 1);
-                v1 = vw_wait(a.p, a.p.tq, t1, 3); v2 = vw_wait(a.p, a.p.tq, t1 + 1, 3); v3 = vw_wait(a.p, a.p.tq, t1 + 2, 3);
-            } else if (avail > 0) {
-                v1 = vw_try(a.p, a.p.tq, 3);
-                if (v1 != VC_Q_NONE) { v2 = vw_try(a.p, a.p.tq, 3); if (v2 != VC_Q_NONE) v3 = vw_try(a.p, a.p.tq, 3); }
+        // The first item: a blocking wait -- the wave holds nothing, so waiting cannot keep a window from retiring.  Tickets drawn in
+        // an earlier round whose items had not arrived yet ("owed") come first.
+        uint32_t tk0;
+        if (owe[0] != VC_Q_NONE) { tk0 = owe[0]; owe[0] = owe[1]; owe[1] = owe[2]; owe[2] = VC_Q_NONE; }
+        else tk0 = vq_inc(a.p.tq.head);
+        uint32_t vv[VC_TG] = {vw_wait(a.p, a.p.tq, tk0, 2), VC_Q_NONE, VC_Q_NONE, VC_Q_NONE};
+        if (vv[0] != VC_Q_NONE) {
+            // The other groups: only what stands in the queue NOW.  A wave that holds an item never blocks on a further ticket
+            // (many waves that see a backlog at once can together draw more tickets than there are items; at the end of a chunk
+            // nothing would fill the surplus, the windows held would never retire, and every wave would wait out its patience):
+            // a ticket whose item is not there yet stays owed and is waited for when the wave's hands are empty.
+            uint32_t n = 1, no = 0;
+            uint32_t keep[VC_TG - 1] = {VC_Q_NONE, VC_Q_NONE, VC_Q_NONE};
+#pragma unroll
+            for (int i = 0; i < VC_TG - 1; ++i) {
+                if (owe[i] == VC_Q_NONE) continue;
+                const uint32_t x = vw_peek(a.p.tq, owe[i]);
+                if (x != VC_Q_NONE) {
+#pragma unroll
+                    for (int j = 1; j < VC_TG; ++j) if (n == (uint32_t)j) vv[j] = x;
+                    n++;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VC_TG - 1; ++j) if (no == (uint32_t)j) keep[j] = owe[i];
+                    no++;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VC_TG - 1; ++i) owe[i] = keep[i];
+            const uint32_t room = (uint32_t)VC_TG - n - no;      // held + owed never exceed the groups of the wave
+            if (room) {
+                // With a backlog the tickets are simply drawn (a compare-and-swap on a counter that a thousand waves advance every
+                // half microsecond never succeeds: the first version took 1.4 windows per round while 12 000 were queued);
+                // near-empty, one at a time and only behind an item that stands there
+                const int avail = (int)(vq_ldc(a.p.tq.res) - vq_ldc(a.p.tq.head));
+                if (avail >= 64) {
+                    const uint32_t t1 = vq_add(a.p.tq.head, room);
+#pragma unroll
+                    for (uint32_t r = 0; r < (uint32_t)VC_TG - 1; ++r) {
+                        if (r >= room) continue;
+                        const uint32_t x = vw_peek(a.p.tq, t1 + r);
+                        if (x != VC_Q_NONE) {
+#pragma unroll
+                            for (int j = 1; j < VC_TG; ++j) if (n == (uint32_t)j) vv[j] = x;
+                            n++;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < VC_TG - 1; ++j) if (no == (uint32_t)j) owe[j] = t1 + r;
+                            no++;
+                        }
+                    }
+                } else if (avail > 0) {
+                    bool more = true;
+#pragma unroll
+                    for (uint32_t r = 0; r < (uint32_t)VC_TG - 1; ++r) {
+                        if (r >= room || !more) continue;
+                        const uint32_t x = vw_try(a.p, a.p.tq, 3);
+                        if (x == VC_Q_NONE) { more = false; continue; }
+#pragma unroll
+                        for (int j = 1; j < VC_TG; ++j) if (n == (uint32_t)j) vv[j] = x;
+                        n++;
+                    }
+                }
             }
         }
+        const uint32_t v0 = vv[0], v1 = vv[1], v2 = vv[2], v3 = vv[3];
         if (v0 == VC_Q_NONE) break;
         vp_acquire();
         const unsigned long long c1 = wall_clock64();

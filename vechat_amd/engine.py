@@ -21,7 +21,8 @@ MAX_EDGES = 32000
 
 
 class HipContext:
-    """Owns a vc_ctx (one device, one stream)."""
+    """Owns a vc_ctx: one device, two batch slots -- `submit(b1)` while b0 runs, `collect()` hands out the oldest run
+    (include/vechat_hip.h, "Pipelining inside one context")."""
 
     def __init__(self, params=None, pipeline=None, reserve=None, **kw):
         """pipeline: None = the library's default (lock-step, or what VC_PIPE says); True / False = the persistent build
@@ -83,8 +84,10 @@ class HipContext:
         self._chk(self.lib.vc_sync(self.h), "vc_sync")
 
     def collect(self):
-        """-> (list of consensus bytes per window, status array)"""
-        n = self._batch.n_windows
+        """-> (list of consensus bytes per window, status array) of the oldest run not yet collected"""
+        nw = C.c_uint32(0)
+        self._chk(self.lib.vc_result_windows(self.h, C.byref(nw)), "vc_result_windows")
+        n = int(nw.value)
         size = C.c_uint64(0)
         self._chk(self.lib.vc_result_size(self.h, C.byref(size)), "vc_result_size")
         cons = np.zeros(max(int(size.value), 1), np.uint8)
