@@ -64,22 +64,59 @@ def kernel_hash():
 
 
 def valu_peak_now(device):
-    """The VALU issue rate the roofline is priced against, measured on this device in this run: vechat_amd/lib/valu_peak.bin
-    (built by __graft_entry__.build() from tools/valu_peak.hip) in its quick mode -- independent v_pk_max_i16 / v_pk_add_i16
-    chains at 4 and 8 waves per SIMD, ~0.2 s.  -> (wave instructions per microsecond per SIMD or None, provenance)."""
+    """The VALU issue rates the roofline is priced against, measured on this device in this run: vechat_amd/lib/valu_peak.bin
+    (built by __graft_entry__.build() from tools/valu_peak.hip) in its quick mode, ~1 s -- independent v_pk_max_i16 / v_pk_add_i16
+    chains at 4 and 8 waves per SIMD (the rate rounds 2-4 priced against), then every opcode class of k_fwd's row loop on its own at
+    5 and 8 waves per SIMD, each with the shader clock it ran at (s_memtime over s_memrealtime) and the SIMD cycles per instruction.
+    -> dict(pk16=rate or None, classes={name: best test record}, source=...)"""
     import subprocess
     exe = os.path.join(ROOT, "vechat_amd", "lib", "valu_peak.bin")
+    res = {"pk16": None, "classes": {}, "source": None}
     try:
         env = dict(os.environ)
         vis = [x for x in env.get("HIP_VISIBLE_DEVICES", "").split(",") if x]
         env["HIP_VISIBLE_DEVICES"] = vis[device] if device < len(vis) else str(device)      # the calibration binary uses device 0 of what it sees
-        out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=120, env=env).stdout
-        rates = [json.loads(l)["inst_per_us_per_simd"] for l in out.splitlines() if l.startswith('{"test"')]
-        if rates:
-            return max(rates), "this run (vechat_amd/lib/valu_peak.bin quick, after the timed region on the same device: best of three passes of independent v_pk_max_i16 / v_pk_add_i16 chains at 4 and 8 waves per SIMD)"
+        out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=180, env=env).stdout
+        tests = [json.loads(l) for l in out.splitlines() if l.startswith('{"test"')]
+        pk = [t for t in tests if t["test"] == "pk_i16_independent"]
+        if pk:
+            best = max(pk, key=lambda t: t["inst_per_us_per_simd"])
+            res["pk16"] = best["inst_per_us_per_simd"]
+            res["pk16_sclk_mhz"] = best.get("sclk_mhz"); res["pk16_simd_cycles_per_inst"] = best.get("simd_cycles_per_inst")
+        for t in tests:
+            if t["test"].startswith("class_"):
+                k = t["test"][6:]
+                if k not in res["classes"] or t["inst_per_us_per_simd"] > res["classes"][k]["inst_per_us_per_simd"]:
+                    res["classes"][k] = {x: t[x] for x in ("inst_per_us_per_simd", "waves_per_simd", "sclk_mhz", "simd_cycles_per_inst") if x in t}
+        res["source"] = ("this run (vechat_amd/lib/valu_peak.bin quick, after the timed region on the same device: independent chains of each opcode class, "
+                         "best of 5 / 8 waves per SIMD; pk16: v_pk_max_i16 / v_pk_add_i16 interleaved, best of three passes at 4 / 8 waves)")
+        if not tests:
+            res["source"] = "calibration printed nothing"
     except Exception as e:
-        return None, f"calibration failed: {e!r}"
-    return None, "calibration printed nothing"
+        res["source"] = f"calibration failed: {e!r}"
+    return res
+
+
+def mix_peak(classes, khash):
+    """The issue rate of k_fwd's own instruction mix: sum(n_i) / sum(n_i / rate_i) over the opcode classes of its row loop
+    (profiles/r5_valu_mix.json: histogram of the commonest row from the device ISA, tools/valu_mix.py), every class's rate measured
+    in this run.  -> (rate or None, detail)"""
+    try:
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r5_valu_mix.json")))
+    except Exception as e:
+        return None, {"note": repr(e)}
+    if mix.get("kernel_hash") != khash:
+        return None, {"note": f"profiles/r5_valu_mix.json was made for kernels {mix.get('kernel_hash')}, these are {khash}: not used"}
+    n = mix["representative_row"]
+    missing = [k for k in n if k not in classes]
+    if missing:
+        return None, {"note": f"no calibration for classes {missing}"}
+    tot = sum(n.values())
+    t = sum(v / classes[k]["inst_per_us_per_simd"] for k, v in n.items())
+    return tot / t, {"instructions_per_row_by_class": n, "rate_by_class": {k: classes[k]["inst_per_us_per_simd"] for k in n},
+                     "simd_cycles_per_inst_by_class": {k: classes[k].get("simd_cycles_per_inst") for k in n},
+                     "sclk_mhz_by_class": {k: classes[k].get("sclk_mhz") for k in n},
+                     "histogram_source": mix["source"] + "; the cheapest way round the row loop = the row whose only predecessor is the row above"}
 
 
 def cpu_baseline(batch, params, budget_s):
@@ -360,15 +397,26 @@ def main():
         khash = kernel_hash()
         simds = torch.cuda.get_device_properties(local).multi_processor_count * 4
         wall_s = dt / a.steps
-        peak_now, peak_src = valu_peak_now(local)
+        cal = valu_peak_now(local)
+        peak_pk16, peak_src = cal["pk16"], cal["source"]
+        peak_mix, mix_detail = mix_peak(cal["classes"], khash)
+        peak_now = peak_mix or peak_pk16
         # The forward DP keeps its predecessor rows in registers / LDS and stores a byte-packed band: it moves ~0.5 B per cell, an
         # eighth of SURVEY 8(d)'s 4 B/cell model, so the bound that holds is the instruction stream ("then the VALU
         # issue bound is the honest limiter and must be stated").  achieved = VALU wave-instructions of ALL kernels of a step
         # (rocprofv3 PMC SQ_INSTS_VALU per window of this workload, measured on these kernel sources) / step wall time / SIMDs;
-        # peak = issue rate of independent v_pk_max_i16 / v_pk_add_i16 chains measured on THIS device in THIS run.
+        # peak = the issue rate of k_fwd's OWN instruction mix (peak_mix: packed int16 max / add, v_perm / v_alignbit, DPP forms, lane
+        # moves, 32-bit odds and ends weighted by the histogram of its row loop), every class measured on THIS device in THIS run;
+        # peak_pk16 = the packed-int16 class alone (what rounds 2-4 priced against), frac_vs_pk16 beside it.
         roof = {"bound": "valu_issue", "kernel": "all kernels of a step (k_fwd alone: roofline.k_fwd)", "achieved": None, "peak": peak_now,
+                "peak_mix": peak_mix, "peak_pk16": peak_pk16, "peak_mix_detail": mix_detail,
                 "unit": "VALU wave-instructions / us / SIMD", "frac": None, "traffic": None, "peak_source": peak_src, "simds": simds,
-                "kernel_hash": khash}
+                "kernel_hash": khash,
+                # the shader clock: s_memtime ticks (one per shader cycle) over s_memrealtime ticks (100 MHz), wave by wave -- under the job
+                # (summed over k_fwd's row loops inside the timed region) and under the calibration loops.  The chip clocks to its power
+                # budget (MI355X_MICROARCH.md, DVFS): a dense vector stream runs well below the 2.4 GHz the device reports.
+                "sclk_mhz": {"timed_region_k_fwd": s.get("fwd_sclk_mhz"), "calibration_pk16": cal.get("pk16_sclk_mhz"), "device_reports": torch.cuda.get_device_properties(local).clock_rate / 1e3 if hasattr(torch.cuda.get_device_properties(local), "clock_rate") else None},
+                "pk16_simd_cycles_per_inst": cal.get("pk16_simd_cycles_per_inst")}
         hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_cell": BYTES_PER_CELL, "cells_per_step": cells / a.steps,
                "algorithmic_gbs_over_wall": BYTES_PER_CELL * cells / a.steps / wall_s / 1e9}
         hbm["algorithmic_model_exceeds_peak"] = hbm["algorithmic_gbs_over_wall"] > HBM_PEAK_GBS
@@ -378,11 +426,11 @@ def main():
               "timing": "HIP events around every k_fwd launch on its own stream, inside the timed region (vc_params.profile = 2); the chunk streams "
                         "overlap, so launches run beside each other: busy_ms = time during which at least one k_fwd launch was running"}
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r4_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r5_hbm_traffic.json")))
             if tj.get("kernel_hash") != khash:
-                roof["counts_note"] = f"profiles/r4_hbm_traffic.json was measured for kernels {tj.get('kernel_hash')}, these are {khash}: not used"
+                roof["counts_note"] = f"profiles/r5_hbm_traffic.json was measured for kernels {tj.get('kernel_hash')}, these are {khash}: not used"
             else:
-                roof["counts_source"] = ("rocprofv3 --pmc passes over the same kernel sources (profiles/r4_hbm_traffic.json from profiles/r4*_pmc_counters.txt: "
+                roof["counts_source"] = ("rocprofv3 --pmc passes over the same kernel sources (profiles/r5_hbm_traffic.json from profiles/r5*_pmc_counters.txt: "
                                          "SQ_INSTS_VALU, FETCH_SIZE, WRITE_SIZE, one counter group per pass) scaled by this run's windows / DP rows / cells")
                 wps = a.windows * world                                             # windows per step
                 job_valu = tj["valu_insts_per_window_all_kernels"] * wps
@@ -390,6 +438,9 @@ def main():
                 if peak_now:
                     roof["achieved"] = job_valu / (wall_s * 1e6 * simds)
                     roof["frac"] = roof["achieved"] / peak_now
+                    if peak_pk16:
+                        roof["frac_vs_pk16"] = roof["achieved"] / peak_pk16
+                roof["_valu_per_window_by_config"] = tj.get("valu_insts_per_window_by_config", {})
                 ipr = tj["instructions_per_dp_row"]["VALU"]
                 kf.update({"valu_insts_per_dp_row": ipr, "valu_wave_insts_per_step": ipr * rows / a.steps})
                 if peak_now:
@@ -458,6 +509,18 @@ def main():
                            "C_hap2": short_config(local, 1012, 500, 64, 16384, capi.PACBIO, n_haplotypes=2, snp_rate=0.01, check=256),
                            "D_shard": short_config(local, 1002, 500, 64, 125000, capi.PACBIO, first=3 * 125000, check=256),
                            "E_shard": short_config(local, 1005, 1000, 128, 6250, capi.ONT, first=5 * 6250, check=256)}
+        # the same roofline for the other shapes: VALU wave-instructions per window of configs E and W by their own PMC passes
+        # (profiles/r5_hbm_traffic.json), priced against the same peak (the mix is config C's: the wider classes spend a larger share
+        # of a row in the packed-int16 class, whose rate is the highest -- the fraction is, if anything, flattered by a few percent)
+        pc = {}
+        for name, v in (line["roofline"].get("_valu_per_window_by_config") or {}).items():
+            cfg_line = line["configs"].get(name)
+            if cfg_line and line["roofline"].get("peak"):
+                ach = v * cfg_line["windows_per_s"] / 1e6 / line["roofline"]["simds"]
+                pc[name] = {"valu_wave_insts_per_window": v, "windows_per_s": cfg_line["windows_per_s"], "achieved": ach, "frac": ach / line["roofline"]["peak"]}
+        line["roofline"]["per_config"] = pc
+    if rank == 0:
+        line["roofline"].pop("_valu_per_window_by_config", None)
     if rank == 0 and world == 1 and not a.no_extras and not a.ab and cfg_name == "C":
         line["files_to_fasta"] = files_to_fasta(ctx_params)
     if rank == 0 and world == 1 and not a.no_cpu:

@@ -118,6 +118,8 @@ typedef struct vc_stats {
                              /* so a class's launches overlap each other and `ms` counts such time once per launch)             */
     uint64_t band_redo;      /* alignments whose backtrack left the stored band and were run again with whole rows              */
     uint64_t device_bytes;   /* device memory this context holds (workspaces + batch buffers)                                   */
+    uint64_t fwd_shader_cycles, fwd_wall_ticks;   /* summed over the forward waves' row loops: shader cycles and 100 MHz ticks -- their ratio  */
+                             /* x 100 is the shader clock in MHz the chip sustained under the job                                    */
 } vc_stats;
 
 /* -- lifecycle: stands in for createCUDABatch / ~CUDABatchProcessor (cudabatch.hpp:26,33) ------ */
@@ -280,6 +282,12 @@ const char* vc_ovlset_error(const vc_ovlset* o);
 uint64_t    vc_ovlset_size(const vc_ovlset* o);
 int         vc_ovlset_get(const vc_ovlset* o, uint64_t i, vc_overlap_rec* out);
 int         vc_ovlset_set_cigar(vc_ovlset* o, uint64_t i, const char* cigar);
+/* Planning for one rank of a multi-GPU run, on names, lengths and overlap records only (targets / reads may be names-only sets):
+ * cost[k] = length of target k + the target bases its overlaps cover; and the '\n'-separated names (malloc'ed, vc_io_free) a rank
+ * that owns targets [t_lo, t_hi) must load -- those targets and the queries of the overlaps on them. */
+int         vc_io_target_cost(const vc_ovlset* o, const vc_seqset* targets, double* cost /*[targets]*/);
+char*       vc_io_rank_names(const vc_ovlset* o, const vc_seqset* targets, const vc_seqset* reads, uint64_t t_lo, uint64_t t_hi, uint64_t* n_names);
+void        vc_io_free(void* p);
 /* Polisher::initialize, fragment-correction mode: every target, every read (a read that is also a target shares its record),
  * every overlap that survives the filters, into the window builder.  Returns the number of overlaps kept, -1 on error. */
 int64_t     vc_io_load(vc_wb* builder, const vc_seqset* targets, const vc_seqset* reads, vc_ovlset* overlaps, double error_threshold,

@@ -2,7 +2,7 @@
 # One GPU-box call per measurement round: gpu tests, PMC passes (own runs, kernel-trace only) + VALU calibration -> traffic / count
 # files, THEN the bench line (its roofline reads those counts), then rocprofv3 kernel stats of the same command.
 # Everything lands in gpurun_out/$TAG/.   usage: tools/gpu_round.sh TAG [skip-tests]
-TAG=${1:-r4}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
+TAG=${1:-r5}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 if [ "$2" != "skip-tests" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
@@ -16,11 +16,15 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_
   fc=$(find /tmp/pmc/p$i -name "*counter_collection.csv" | head -1)
   echo "== pass $i: $grp" >> $O/pmc_counters.txt; python $R/tools/pmc_summary.py $fc | cut -c1-700 >> $O/pmc_counters.txt
 done
+# the other workload shapes, VALU instruction counts only (roofline.per_config): config E (1 kb x 128, ONT) and W (3 kb x 12)
+rm -rf /tmp/pmcE /tmp/pmcW
+VC_PROFILE=ont VC_SEED=1005 VC_STATS_JSON=$O/pmc_stats_E.json timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pmcE -- python $R/tools/gpu_scale.py 1024 128 1000 > $O/pmcE.log 2>&1
+VC_SEED=1007 VC_STATS_JSON=$O/pmc_stats_W.json timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pmcW -- python $R/tools/gpu_scale.py 512 12 3000 > $O/pmcW.log 2>&1
 $R/vechat_amd/lib/valu_peak.bin > $O/valu_peak.txt
-python $R/tools/make_traffic_json.py /tmp/pmc $O/pmc_stats.json $O/valu_peak.txt $O
-cp $O/r4_hbm_traffic.json $R/profiles/r4_hbm_traffic.json      # (on this box: the bench below prices its step against these counts)
+python $R/tools/make_traffic_json.py /tmp/pmc $O/pmc_stats.json $O/valu_peak.txt $O E=/tmp/pmcE:$O/pmc_stats_E.json W=/tmp/pmcW:$O/pmc_stats_W.json
+cp $O/r5_hbm_traffic.json $R/profiles/r5_hbm_traffic.json      # (on this box: the bench below prices its step against these counts)
 cd $R
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; tail -c 1500 $O/bench.json
+timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; tail -c 1500 $O/bench.json
 cd /tmp
 rm -rf /tmp/prof_stats
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --no-cpu --no-extras > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err

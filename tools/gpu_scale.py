@@ -11,7 +11,7 @@ chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 streams = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 fp = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
 t0 = time.time()
-b = capi.synth_batch(capi.synth_cfg(1002, L, D, frac_partial=fp), 0, n)
+b = capi.synth_batch(capi.synth_cfg(int(os.environ.get("VC_SEED", "1002")), L, D, frac_partial=fp, profile=capi.ONT if os.environ.get("VC_PROFILE") == "ont" else capi.PACBIO), 0, n)
 print(f"generated {n} windows in {time.time()-t0:.1f}s, {b.bases.size/1e6:.1f} MB bases", flush=True)
 ctx = HipContext(device=0, profile=1, chunk_windows=chunk, n_streams=streams, num_prune=int(os.environ.get('VC_NUM_PRUNE', '3')),
                  scratch_bytes=int(float(os.environ.get('VC_SCRATCH_GB', '0')) * (1 << 30)))

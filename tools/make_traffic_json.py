@@ -1,6 +1,9 @@
-"""Build profiles/r4_hbm_traffic.json and profiles/r4_valu_peak_final.json from the PMC passes of tools/pmc_run.sh and tools/valu_peak.bin.
+"""Build profiles/r5_hbm_traffic.json and profiles/r5_valu_peak_final.json from the PMC passes of tools/gpu_round.sh and tools/valu_peak.bin.
 
-  python tools/make_traffic_json.py <dir with pmc1..4 counter csv> <gpu_scale stats json> <valu_peak output> <out dir>
+  python tools/make_traffic_json.py <dir with pmc1..4 counter csv> <gpu_scale stats json> <valu_peak output> <out dir> [NAME=<pmc dir>:<stats json> ...]
+
+NAME=...: one SQ_INSTS_VALU pass over another workload shape (configs E, W): its VALU wave-instructions per window go into
+valu_insts_per_window_by_config (bench.py: roofline.per_config).
 
 FETCH_SIZE is doubled (gfx950: 128-B requests counted as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported.
 Both are in KB.  The kernel hash ties the file to the sources it was measured on (bench.py refuses any other)."""
@@ -8,6 +11,7 @@ import csv, collections, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pmc_dir, stats_json, valu_out, out_dir = sys.argv[1:5]
+extra = sys.argv[5:]
 
 
 from bench import kernel_hash  # noqa: E402  (the same identity bench.py checks)
@@ -52,8 +56,25 @@ if f:
 t = out["kernels"].get("k_tracew", {})
 if t and moves:
     out["k_tracew_bytes_fetched_per_move"] = t.get("hbm_read_bytes", 0) / moves
+by_cfg = {}
+for spec in extra:
+    name, rest = spec.split("=", 1)
+    d2, sj = rest.split(":", 1)
+    try:
+        tot2 = 0.0
+        for f in glob.glob(os.path.join(d2, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == "SQ_INSTS_VALU":
+                    tot2 += float(r["Counter_Value"])
+        st2 = json.load(open(sj))
+        if tot2 and st2.get("windows"):
+            by_cfg[name] = tot2 / st2["windows"]
+            out.setdefault("by_config_commands", {})[name] = st2["command"]
+    except Exception as e:
+        print("config", name, "skipped:", repr(e))
+out["valu_insts_per_window_by_config"] = by_cfg
 os.makedirs(out_dir, exist_ok=True)
-json.dump(out, open(os.path.join(out_dir, "r4_hbm_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(out_dir, "r5_hbm_traffic.json"), "w"), indent=1)
 print("bytes/cell", out.get("bytes_per_cell"), "insts/row", out.get("instructions_per_dp_row"), "tracew B/move", out.get("k_tracew_bytes_fetched_per_move"))
 
 tests = [json.loads(l) for l in open(valu_out) if l.startswith("{")]
@@ -63,5 +84,5 @@ best = max(ind, key=lambda x: x["inst_per_us_per_simd"])
 json.dump({"source": "tools/valu_peak.bin on the bench box", "device": dev, "tests": tests[1:],
            "peak_wave_insts_per_us_per_simd": best["inst_per_us_per_simd"],
            "note": f"best issue rate of independent v_pk_max_i16 / v_pk_add_i16 chains ({best['waves_per_simd']} waves per SIMD)"},
-          open(os.path.join(out_dir, "r4_valu_peak_final.json"), "w"), indent=1)
+          open(os.path.join(out_dir, "r5_valu_peak_final.json"), "w"), indent=1)
 print("valu peak", best["inst_per_us_per_simd"], "wave insts / us / SIMD")

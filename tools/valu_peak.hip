@@ -20,13 +20,17 @@
 // MODE 7: 4 independent chains of v_pk_add_f32 (64-bit register pairs)
 // MODE 8: 8 independent v_fma_f32
 // MODE 9: 8 independent v_pk_fma_f16
+// round 5 -- the opcode classes of k_fwd's row loop, each on its own (roofline.peak_mix weights them by the loop's histogram):
+// MODE 10: v_pk_max_i16 only     MODE 11: v_pk_add_u16 only     MODE 12: v_alignbit_b32     MODE 13: v_max_i32_dpp row_shr (8 independent registers)
+// MODE 14: v_readlane_b32 / v_writelane_b32 pairs     MODE 15: v_cndmask_b32 / v_mov_b32 / v_and / v_lshl_or (the 32-bit odds and ends)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, unsigned long long* cyc) {
+__global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, unsigned long long* cyc, unsigned long long* wall) {
     uint32_t r0 = threadIdx.x, r1 = r0 * 3 + 1, r2 = r0 * 5 + 2, r3 = r0 * 7 + 3, r4 = r0 ^ 0x55, r5 = r0 + 77, r6 = r0 * 11, r7 = r0 + 9;
     const uint32_t c = 0x00010001u * (blockIdx.x & 3) + 0x00020001u;
     unsigned long long q0 = r0 | ((unsigned long long)r1 << 32), q1 = r2 | ((unsigned long long)r3 << 32), q2 = r4 | ((unsigned long long)r5 << 32), q3 = r6 | ((unsigned long long)r7 << 32);
     const unsigned long long qc = c | ((unsigned long long)c << 32);
-    const unsigned long long t0 = clock64();
+    const unsigned long long w0 = wall_clock64();          // s_memrealtime: constant 100 MHz
+    const unsigned long long t0 = clock64();               // s_memtime: one tick per shader cycle (MI355X_MICROARCH.md)
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) {
             asm volatile(
@@ -92,6 +96,52 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, unsigned
                 "v_pk_fma_f16 %0, %0, %8, %8\n v_pk_fma_f16 %1, %1, %8, %8\n v_pk_fma_f16 %2, %2, %8, %8\n v_pk_fma_f16 %3, %3, %8, %8\n"
                 "v_pk_fma_f16 %4, %4, %8, %8\n v_pk_fma_f16 %5, %5, %8, %8\n v_pk_fma_f16 %6, %6, %8, %8\n v_pk_fma_f16 %7, %7, %8, %8\n"
                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c));
+        } else if (MODE == 10) {
+            asm volatile(
+                "v_pk_max_i16 %0, %0, %8\n v_pk_max_i16 %1, %1, %8\n v_pk_max_i16 %2, %2, %8\n v_pk_max_i16 %3, %3, %8\n"
+                "v_pk_max_i16 %4, %4, %8\n v_pk_max_i16 %5, %5, %8\n v_pk_max_i16 %6, %6, %8\n v_pk_max_i16 %7, %7, %8\n"
+                "v_pk_max_i16 %0, %0, %8\n v_pk_max_i16 %1, %1, %8\n v_pk_max_i16 %2, %2, %8\n v_pk_max_i16 %3, %3, %8\n"
+                "v_pk_max_i16 %4, %4, %8\n v_pk_max_i16 %5, %5, %8\n v_pk_max_i16 %6, %6, %8\n v_pk_max_i16 %7, %7, %8\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c));
+        } else if (MODE == 11) {
+            asm volatile(
+                "v_pk_add_u16 %0, %0, %8\n v_pk_add_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n v_pk_add_u16 %3, %3, %8\n"
+                "v_pk_add_u16 %4, %4, %8\n v_pk_add_u16 %5, %5, %8\n v_pk_add_u16 %6, %6, %8\n v_pk_add_u16 %7, %7, %8\n"
+                "v_pk_add_u16 %0, %0, %8\n v_pk_add_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n v_pk_add_u16 %3, %3, %8\n"
+                "v_pk_add_u16 %4, %4, %8\n v_pk_add_u16 %5, %5, %8\n v_pk_add_u16 %6, %6, %8\n v_pk_add_u16 %7, %7, %8\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c));
+        } else if (MODE == 12) {
+            asm volatile(
+                "v_alignbit_b32 %0, %0, %8, 16\n v_alignbit_b32 %1, %1, %8, 16\n v_alignbit_b32 %2, %2, %8, 16\n v_alignbit_b32 %3, %3, %8, 16\n"
+                "v_alignbit_b32 %4, %4, %8, 16\n v_alignbit_b32 %5, %5, %8, 16\n v_alignbit_b32 %6, %6, %8, 16\n v_alignbit_b32 %7, %7, %8, 16\n"
+                "v_alignbit_b32 %0, %0, %8, 16\n v_alignbit_b32 %1, %1, %8, 16\n v_alignbit_b32 %2, %2, %8, 16\n v_alignbit_b32 %3, %3, %8, 16\n"
+                "v_alignbit_b32 %4, %4, %8, 16\n v_alignbit_b32 %5, %5, %8, 16\n v_alignbit_b32 %6, %6, %8, 16\n v_alignbit_b32 %7, %7, %8, 16\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c));
+        } else if (MODE == 13) {
+            asm volatile(
+                "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+                "v_max_i32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n v_max_i32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+                "v_max_i32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_max_i32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+                "v_max_i32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_max_i32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+                "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+                "v_max_i32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n v_max_i32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+                "v_max_i32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_max_i32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+                "v_max_i32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_max_i32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
+        } else if (MODE == 14) {
+            asm volatile(
+                "v_readlane_b32 s20, %0, 3\n v_writelane_b32 %1, s21, 5\n v_readlane_b32 s22, %2, 7\n v_writelane_b32 %3, s23, 9\n"
+                "v_readlane_b32 s24, %4, 11\n v_writelane_b32 %5, s25, 13\n v_readlane_b32 s26, %6, 15\n v_writelane_b32 %7, s27, 17\n"
+                "v_readlane_b32 s21, %0, 19\n v_writelane_b32 %1, s20, 21\n v_readlane_b32 s23, %2, 23\n v_writelane_b32 %3, s22, 25\n"
+                "v_readlane_b32 s25, %4, 27\n v_writelane_b32 %5, s24, 29\n v_readlane_b32 s27, %6, 31\n v_writelane_b32 %7, s26, 33\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) :: "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        } else if (MODE == 15) {
+            asm volatile(
+                "v_cndmask_b32 %0, %0, %8, vcc\n v_mov_b32 %1, %8\n v_and_b32 %2, %2, %8\n v_lshl_or_b32 %3, %3, 16, %8\n"
+                "v_cndmask_b32 %4, %4, %8, vcc\n v_or_b32 %5, %5, %8\n v_sub_u32 %6, %6, %8\n v_min_u32 %7, %7, %8\n"
+                "v_cndmask_b32 %0, %0, %8, vcc\n v_mov_b32 %1, %8\n v_and_b32 %2, %2, %8\n v_lshl_or_b32 %3, %3, 16, %8\n"
+                "v_cndmask_b32 %4, %4, %8, vcc\n v_or_b32 %5, %5, %8\n v_sub_u32 %6, %6, %8\n v_min_u32 %7, %7, %8\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(c) : "vcc");
         } else {
             asm volatile(
                 "v_max_i32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_max_i32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
@@ -102,35 +152,45 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, unsigned
         }
     }
     const unsigned long long t1 = clock64();
+    const unsigned long long w1 = wall_clock64();
     out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + (uint32_t)(q0 + q1 + q2 + q3) + (uint32_t)((q0 + q1 + q2 + q3) >> 32);
-    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0; wall[blockIdx.x * 4 + threadIdx.x / 64] = w1 - w0; }
 }
 
 template <int MODE>
 int run(const char* name, int waves_per_simd, int n_cu, int per_iter) {
     const int iters = 200000;
     const int blocks = n_cu * waves_per_simd;          // 256-thread blocks: one wave per SIMD each
-    uint32_t* d_out; unsigned long long* d_cyc;
-    CHK(hipMalloc(&d_out, (size_t)blocks * 256 * 4)); CHK(hipMalloc(&d_cyc, (size_t)blocks * 4 * 8));
+    uint32_t* d_out; unsigned long long *d_cyc, *d_wall;
+    CHK(hipMalloc(&d_out, (size_t)blocks * 256 * 4)); CHK(hipMalloc(&d_cyc, (size_t)blocks * 4 * 8)); CHK(hipMalloc(&d_wall, (size_t)blocks * 4 * 8));
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
-    hipLaunchKernelGGL(k_valu<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, 1000, d_cyc);
+    hipLaunchKernelGGL(k_valu<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, 1000, d_cyc, d_wall);
     CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(a, 0));
-    hipLaunchKernelGGL(k_valu<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, iters, d_cyc);
+    hipLaunchKernelGGL(k_valu<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, iters, d_cyc, d_wall);
     CHK(hipEventRecord(b, 0));
     CHK(hipEventSynchronize(b));
     float ms = 0; CHK(hipEventElapsedTime(&ms, a, b));
-    std::vector<unsigned long long> cyc((size_t)blocks * 4);
+    std::vector<unsigned long long> cyc((size_t)blocks * 4), wal((size_t)blocks * 4);
     CHK(hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(wal.data(), d_wall, wal.size() * 8, hipMemcpyDeviceToHost));
+    // shader clock over the loop, wave by wave: shader cycles per 100 MHz tick; the median wave
+    std::vector<double> mhz(cyc.size());
+    for (size_t i = 0; i < cyc.size(); ++i) mhz[i] = wal[i] ? 100.0 * (double)cyc[i] / (double)wal[i] : 0.0;
+    std::sort(mhz.begin(), mhz.end());
+    const double sclk_mhz = mhz[mhz.size() / 2];
     std::sort(cyc.begin(), cyc.end());
     const double med = (double)cyc[cyc.size() / 2];
     const double insts = (double)iters * per_iter;
     // clock64() ticks at a constant 100 MHz on gfx9; the engine clock follows from the instruction count when the issue
     // rate per cycle is known -- report both views: instructions per microsecond per SIMD and ticks
     const double inst_per_us_per_simd = insts * waves_per_simd / (ms * 1e3);
-    printf("{\"test\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"wave_insts\": %.0f, \"inst_per_us_per_simd\": %.1f, \"ns_per_wave_inst\": %.3f, \"clock64_ticks_median\": %.0f}\n",
-           name, waves_per_simd, ms, insts, inst_per_us_per_simd, ms * 1e6 / insts, med);
-    (void)hipFree(d_out); (void)hipFree(d_cyc);
+    // cycles of the SIMD per wave-instruction issued: a wave's loop lasted `med` shader cycles and waves_per_simd waves shared the SIMD
+    const double cyc_per_inst = med / (insts * waves_per_simd);
+    printf("{\"test\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"wave_insts\": %.0f, \"inst_per_us_per_simd\": %.1f, \"ns_per_wave_inst\": %.3f, \"clock64_ticks_median\": %.0f, "
+           "\"sclk_mhz\": %.0f, \"simd_cycles_per_inst\": %.2f}\n",
+           name, waves_per_simd, ms, insts, inst_per_us_per_simd, ms * 1e6 / insts, med, sclk_mhz, cyc_per_inst);
+    (void)hipFree(d_out); (void)hipFree(d_cyc); (void)hipFree(d_wall);
     return 0;
 }
 
@@ -141,6 +201,12 @@ int main(int argc, char** argv) {
     if (argc > 1 && std::string(argv[1]) == "quick") {      // bench.py: only the rate the forward DP is priced against (~0.2 s)
         for (int rep = 0; rep < 3; ++rep)                    // (the clock needs a moment after the bench's last kernel: best of three)
             for (int w : {4, 8}) if (run<0>("pk_i16_independent", w, n_cu, 16)) return 1;
+        // the opcode classes of the forward DP's row loop, each at the occupancy it runs at (5 waves per SIMD) and at 8
+        for (int w : {5, 8}) {
+            if (run<10>("class_pk16_max", w, n_cu, 16) || run<11>("class_pk16_add", w, n_cu, 16) || run<4>("class_i32_max_add", w, n_cu, 16) ||
+                run<15>("class_i32_misc", w, n_cu, 16) || run<3>("class_perm", w, n_cu, 16) || run<12>("class_alignbit", w, n_cu, 16) ||
+                run<13>("class_dpp", w, n_cu, 16) || run<14>("class_lane", w, n_cu, 16)) return 1;
+        }
         return 0;
     }
     for (int w : {1, 2, 4, 8}) if (run<0>("pk_i16_independent", w, n_cu, 16)) return 1;
@@ -153,5 +219,10 @@ int main(int argc, char** argv) {
     for (int w : {1, 4, 8}) if (run<9>("pk_fma_f16_independent", w, n_cu, 16)) return 1;
     for (int w : {1, 2, 4}) if (run<1>("pk_i16_dependent", w, n_cu, 16)) return 1;
     for (int w : {1, 4}) if (run<2>("dpp_max_dependent", w, n_cu, 8)) return 1;
+    for (int w : {1, 2, 4, 5, 8}) {
+        if (run<10>("class_pk16_max", w, n_cu, 16) || run<11>("class_pk16_add", w, n_cu, 16) || run<4>("class_i32_max_add", w, n_cu, 16) ||
+            run<15>("class_i32_misc", w, n_cu, 16) || run<3>("class_perm", w, n_cu, 16) || run<12>("class_alignbit", w, n_cu, 16) ||
+            run<13>("class_dpp", w, n_cu, 16) || run<14>("class_lane", w, n_cu, 16)) return 1;
+    }
     return 0;
 }

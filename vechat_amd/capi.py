@@ -64,6 +64,7 @@ class VcStats(C.Structure):
         ("max_nodes", C.c_uint32), ("max_edges", C.c_uint32), ("chunk_windows", C.c_uint32), ("n_streams", C.c_uint32),
         ("busy_ms", C.c_double * 16),
         ("band_redo", C.c_uint64), ("device_bytes", C.c_uint64),
+        ("fwd_shader_cycles", C.c_uint64), ("fwd_wall_ticks", C.c_uint64),
     ]
 
 
@@ -231,6 +232,9 @@ def _declare_host(lib):
     lib.vc_ovlset_get.argtypes = [vp, C.c_uint64, C.POINTER(VcOverlapRec)]; lib.vc_ovlset_get.restype = C.c_int
     lib.vc_ovlset_set_cigar.argtypes = [vp, C.c_uint64, C.c_char_p]; lib.vc_ovlset_set_cigar.restype = C.c_int
     lib.vc_io_load.argtypes = [vp, vp, vp, vp, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_uint64]; lib.vc_io_load.restype = C.c_int64
+    lib.vc_io_target_cost.argtypes = [vp, vp, C.POINTER(C.c_double)]; lib.vc_io_target_cost.restype = C.c_int
+    lib.vc_io_rank_names.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, u64p]; lib.vc_io_rank_names.restype = C.c_void_p
+    lib.vc_io_free.argtypes = [vp]; lib.vc_io_free.restype = None
     lib.vc_synth_generate.argtypes = [C.POINTER(VcSynthCfg), C.c_uint64, C.c_uint32, C.c_uint32]
     lib.vc_synth_generate.restype = C.c_void_p
     lib.vc_synth_batch.argtypes = [C.c_void_p, C.POINTER(VcBatch)]

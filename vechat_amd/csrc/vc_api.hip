@@ -129,6 +129,7 @@ struct Batch {
     int run_rc = 0;
     hipEvent_t done_ev[16]{};            // per chunk stream: recorded behind the last chunk of this batch on that stream
     bool ev_rec[16]{};
+    uint32_t first_stream = 0;           // chunk stream that ran chunk 0 of the last run (the debug digests look at that workspace)
     Plan* pl = nullptr;                  // the plan of the run in flight (owned)
     // ---- results
     uint64_t total_cons = 0;
@@ -697,21 +698,32 @@ struct Plan {
             (void)hipMemsetAsync(wk.gr[gi].n_edges, 0, (size_t)ns * 4, wk.stream);   // (fewer than three sequences) included
         }
         { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3(ns), dim3(64), 0, wk.stream, bt->b, w0, ns); }
-        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), bt->kept ? vc_kept_lds_bytes(NC) : 0, wk.stream, bt->b, wk.gr[0], wk.dp, w0, ns, NC, EC, (uint32_t)kRing, bt->kept); }
+        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), bt->kept ? vc_kept_lds_bytes(NC) : 0, wk.stream, bt->b, wk.gr[0], wk.dp, w0, ns, NC, EC, (uint32_t)kRing, bt->kept, wk.d_cur_layer); }
     }
 
-    // one layer of the build loop (window.cpp:239-298) for every window of the chunk
-    int build_layer(Work& wk, uint32_t j) {
+    // One round of the build loop (window.cpp:239-298) for every window of the chunk.  Every window is at a layer of its own
+    // (Work::d_cur_layer; the reference runs a window as one sequential function, window.cpp:239-298, and the windows of a chunk need
+    // not march together): the kernels take the layer from the cursor, k_addaln moves a window on when its alignment is in.
+    //   inline_redo = false: a window whose backtrack left the stored band (0.14 % of the alignments) simply does not move on; the
+    //     next round's forward launch aligns the same layer again with whole rows and the walk is done from there.  The redo
+    //     launch pair that every chunk-layer used to pay (half of the build phase's k_fwd launches, each as long as one alignment)
+    //     is gone; the chunk ends with a few catch-up rounds for the windows that fell behind (Plan::run_chunk).
+    //   inline_redo = true: the redo pair inside the round, as before -- every window moves on in every round (catch-up rounds,
+    //     and the lock-step walk of vc_debug_stop_after, whose digests want every window at layer j after round j).
+    int build_layer(Work& wk, uint32_t j, bool inline_redo) {
         const uint32_t ns = wk.ns;
         // the rows of a full-span layer were made at the tail of the kernel that last changed the graph (k_init / k_addaln);
-        // a partial-span layer aligns to a Subgraph
-        if (bt->h_layer_partial[j]) {
+        // a partial-span layer aligns to a Subgraph (a window that lags may be at any earlier layer)
+        bool any_partial = false;
+        for (uint32_t q = 1; q <= j && q < bt->h_layer_partial.size(); ++q) any_partial = any_partial || bt->h_layer_partial[q];
+        if (any_partial) {
             Timer t(c, KC_ROWS, wk.stream);
             const uint32_t sub_lds = std::max(8 * ((NC + 63) / 64) + 2 * NC + ((NC + 15) & ~15u) + 4 * (NC / 32 + 1) + 64, bt->kept ? vc_kept_lds_bytes(NC) : 0u);
-            hipLaunchKernelGGL(k_rows_sub, dim3(ns), dim3(64), sub_lds, wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing, wk.d_submask, bt->kept);
+            hipLaunchKernelGGL(k_rows_sub, dim3(ns), dim3(64), sub_lds, wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing, wk.d_submask, bt->kept,
+                               (const uint32_t*)wk.d_cur_layer);
         }
         VcFwdArgs fa = fwd_args(wk);
-        fa.group = 1; fa.k0 = j; fa.mode = 0; fa.hstride = (uint64_t)NC * rowd;
+        fa.group = 1; fa.k0 = j; fa.mode = 0; fa.hstride = (uint64_t)NC * rowd; fa.cursor = wk.d_cur_layer;
         fa.tie_over = wk.d_pairs; fa.tie_over_stride = PC;      // the pair list of the job is written only after k_resolve
         if (j == 1 || c->dbg_stop_kind) {                      // later layers: k_addaln of the layer before cleared the counters
             HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
@@ -724,18 +736,35 @@ struct Plan {
           hipLaunchKernelGGL(k_resolve, dim3(kResolveGrid), dim3(64), rs_lds, wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK,
                              (const uint16_t*)wk.d_tie_rows, (const uint32_t*)wk.d_tie_cnt, (const uint32_t*)wk.d_pairs, PC, wk.d_job_end,
                              (const uint32_t*)wk.d_tie_list, (const uint32_t*)wk.d_tie_n, (const uint32_t*)wk.d_submask, (int)j,
-                             wk.d_resolve_ws, (topo_lds + 15u) & ~15u, c->force_dfs ? 1 : 0); }
+                             wk.d_resolve_ws, (topo_lds + 15u) & ~15u, c->force_dfs ? 1 : 0, (const uint32_t*)wk.d_cur_layer); }
         VcTraceArgs ta = trace_args(wk);
-        ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride;
+        ta.group = 1; ta.k0 = j; ta.hstride = fa.hstride; ta.cursor = wk.d_cur_layer;
         ta.pairs = wk.d_pairs; ta.npairs = wk.d_npairs; ta.pair_group = 1; ta.pair_k0 = j; ta.kept = bt->kept;
         launch_trace(wk, ta, ns, 1, NC);
-        if ((rc = redo(wk, fa, ta, ns, NC))) return rc;
+        if (inline_redo && (rc = redo(wk, fa, ta, ns, NC))) return rc;
         VcAddArgs aa{};
         aa.b = bt->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
         aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16; aa.ring = (uint32_t)kRing;
         aa.make_rows = !(c->dbg_stop_kind == 1 && c->dbg_stop_index == j); aa.kept = bt->kept;
-        aa.tie_n = wk.d_tie_n; aa.redo_n = wk.d_redo_n;
+        aa.tie_n = wk.d_tie_n; aa.redo_n = wk.d_redo_n; aa.cursor = wk.d_cur_layer;
         { Timer t(c, KC_ADDALN, wk.stream); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, wk.stream, aa); }
+        return VC_OK;
+    }
+
+    // every layer of every window of the chunk: `layers` rounds, then as many catch-up rounds as the slowest window is behind
+    int build_loop(Work& wk) {
+        int rc;
+        const bool defer = bt->band && !getenv("VC_INLINE_REDO");        // (development: VC_INLINE_REDO=1 keeps the redo pair in every round)
+        for (uint32_t j = 1; j <= wk.layers; ++j) if ((rc = build_layer(wk, j, !defer))) return rc;
+        if (!defer) return VC_OK;
+        // (the one host wait of the build phase; the re-alignment rounds have theirs: Plan::realign)
+        HIPCHK(c, hipMemsetAsync(wk.d_maxn, 0, 8, wk.stream));
+        hipLaunchKernelGGL(k_lag, dim3((wk.ns + 255) / 256), dim3(256), 0, wk.stream, bt->b, (const uint32_t*)wk.d_cur_layer, wk.w0, wk.ns, wk.d_maxn);
+        HIPCHK(c, hipMemcpyAsync(wk.h_maxn + 4, wk.d_maxn, 4, hipMemcpyDeviceToHost, wk.stream));
+        HIPCHK(c, hipStreamSynchronize(wk.stream));
+        const uint32_t lag = std::min(wk.h_maxn[4], wk.layers);
+        // with the redo pair inside the round every window moves on in every round: `lag` rounds bring the slowest one home
+        for (uint32_t r = 0; r < lag; ++r) if ((rc = build_layer(wk, wk.layers, true))) return rc;
         return VC_OK;
     }
 
@@ -936,7 +965,7 @@ struct Plan {
         int rc;
         begin(wk, w0, ns);
         if (wk.layers && pipe_ok()) { if ((rc = build_pipe(wk))) return rc; }
-        else for (uint32_t j = 1; j <= wk.layers; ++j) if ((rc = build_layer(wk, j))) return rc;
+        else if ((rc = build_loop(wk))) return rc;
         if (!wk.layers) { wk.active = false; return VC_OK; }
         if (c->prm.mode == 1) return linear_tail(wk);
         for (uint32_t r = 0; r < c->prm.num_prune; ++r) {
@@ -966,6 +995,7 @@ void stream_worker(vc_ctx* c, uint32_t s) {
             continue;
         }
         const bool skip = bt->run_rc != VC_OK;               // a chunk of this run failed: the rest is not started
+        if (k == 0) bt->first_stream = s;
         lk.unlock();
         int rc = VC_OK;
         if (!skip) {
@@ -1069,7 +1099,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     uint32_t lw[256]; double ld[256];
     vc_weight_lut(lw);
     for (int ch = 0; ch < 256; ++ch) ld[ch] = 1 - pow(10, (33 - (int)(signed char)ch) / 10.0);
-    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, 8 * VC_STAT_SLOTS) ||
+    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, VC_STAT_WORDS) ||
         dalloc(c, c->allocs, &c->d_pipe_abort, 64) || dalloc(c, c->allocs, &c->d_pipe_prof, VC_PP_TOTAL)) {
         g_create_error = c->err; vc_destroy(c); return VC_ERR_HIP;
     }
@@ -1427,7 +1457,7 @@ int vc_run(vc_ctx* c) {
     bool alone;                                          // no other run of this context is in flight: the counters are this run's
     { std::lock_guard<std::mutex> lk(c->qmu); alone = c->runq.empty(); }
     if (alone) {
-        HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64 * VC_STAT_SLOTS, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 8 * VC_STAT_WORDS, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_pipe_abort, 0, 64, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_pipe_prof, 0, VC_PP_TOTAL * 8, c->stream));
     }
@@ -1463,6 +1493,7 @@ int vc_run(vc_ctx* c) {
     }
     // development / test hooks (vc_debug_stop_after, VC_HOST_THREADS=0): this thread walks the streams in lock-step, nothing else in flight
     drain(c);
+    bt->first_stream = 0;
     for (uint32_t g0 = 0; g0 < b.n_windows; g0 += S * CW) {
         // S chunks advance in lockstep, each on its own stream
         uint32_t max_layers = 0;
@@ -1475,7 +1506,7 @@ int vc_run(vc_ctx* c) {
         }
         for (uint32_t j = 1; j <= max_layers; ++j) {
             for (uint32_t s = 0; s < S; ++s)
-                if (c->works[s].active && j <= c->works[s].layers && (rc = pl.build_layer(c->works[s], j))) return rc;
+                if (c->works[s].active && j <= c->works[s].layers && (rc = pl.build_layer(c->works[s], j, true))) return rc;
             if (c->dbg_stop_kind == 1 && c->dbg_stop_index == j) { bt->ran = false; return VC_OK; }
         }
         if (c->prm.mode == 1) {
@@ -1671,7 +1702,7 @@ int vc_debug_stage_digest(vc_ctx* c, uint32_t w, int with_pairs, uint64_t* out) 
     HIPCHK(c, hipSetDevice(c->device));
     if (c->cur->b.n_windows > c->cur->cw_run) return fail(c, VC_ERR_ARG, "vc_debug_stage_digest: the batch spans several chunks");
     sync_all(c);
-    const Work& wk = c->works[0];
+    const Work& wk = c->works[c->cur->first_stream];
     const VcGraph& g = wk.gr[wk.cur];
     const uint32_t slot = w, NC = c->NC, EC = c->EC, MA = c->MA;
     uint32_t N = 0, E = 0, P = 0;
@@ -1721,7 +1752,7 @@ int vc_debug_rows(vc_ctx* c, uint32_t w, uint32_t* out, uint32_t cap_rows, uint3
     if (!c || !out || !nrows || !(c->cur && c->cur->have) || w >= c->cur->b.n_windows || c->cur->b.n_windows > c->cur->cw_run) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     sync_all(c);
-    const Work& wk = c->works[0];
+    const Work& wk = c->works[c->cur->first_stream];
     uint32_t n = 0;
     HIPCHK(c, hipMemcpy(&n, wk.dp.nrows + w, 4, hipMemcpyDeviceToHost));
     if (n > c->NC || n > cap_rows) return fail(c, VC_ERR_CAPACITY, "vc_debug_rows: %u rows", n);
@@ -1748,12 +1779,12 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
     int rc;
     if (built_to != layer) {
         pl.begin(wk, 0, std::min(c->cur->cw_run, c->cur->b.n_windows));
-        for (uint32_t j = 1; j < layer; ++j) if ((rc = pl.build_layer(wk, j))) return rc;
+        for (uint32_t j = 1; j < layer; ++j) if ((rc = pl.build_layer(wk, j, true))) return rc;
         built_to = layer;
     }
     VcFwdArgs fa = pl.fwd_args(wk);
     fa.group = 1; fa.k0 = layer; fa.mode = 0; fa.hstride = (uint64_t)pl.NC * pl.rowd; fa.dbg = flags;
-    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 64 * VC_STAT_SLOTS, wk.stream));
+    HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 8 * VC_STAT_WORDS, wk.stream));
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
     HIPCHK(c, hipMemsetAsync(wk.d_tie_n, 0, 4, wk.stream));
@@ -1768,7 +1799,7 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / reps;
-    unsigned long long raw[8 * VC_STAT_SLOTS], cells = 0, rows = 0;
+    unsigned long long raw[VC_STAT_WORDS], cells = 0, rows = 0;
     HIPCHK(c, hipMemcpy(raw, c->d_stat, sizeof(raw), hipMemcpyDeviceToHost));
     for (int i = 0; i < VC_STAT_SLOTS; ++i) { cells += raw[i * 8]; rows += raw[i * 8 + 1]; }
     cells_out[0] = cells / (reps + 1); cells_out[1] = rows / (reps + 1);
@@ -1784,7 +1815,7 @@ int vc_debug_pipe_state(vc_ctx* c, uint32_t* out, uint32_t n) {
     if (!c || !out || !(c->cur && c->cur->have)) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     sync_all(c);
-    const Work& wk = c->works[0];
+    const Work& wk = c->works[c->cur->first_stream];
     std::vector<uint32_t> ctl((size_t)VC_PC_N * VC_PIPE_CTL_STRIDE);
     HIPCHK(c, hipMemcpy(ctl.data(), wk.d_pipe_ctl, ctl.size() * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < 10; ++i) out[i] = i < VC_PC_N ? ctl[(size_t)i * VC_PIPE_CTL_STRIDE] : 0u;
@@ -1821,13 +1852,15 @@ int vc_get_stats(vc_ctx* c, vc_stats* s) {
     if (!c || !s) return VC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     drain(c);                            // launch counters and event records belong to the chunk threads until they are done
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, raw[8 * VC_STAT_SLOTS];
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, raw[VC_STAT_WORDS];
     HIPCHK(c, hipMemcpy(raw, c->d_stat, sizeof(raw), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8 * VC_STAT_SLOTS; ++i) st[i % 8] += raw[i];
     c->stats.cells = st[0]; c->stats.dp_rows = st[1];
     c->stats.far_row_reads = st[3];
     c->stats.trace_steps = st[4]; c->stats.trace_spec = st[5]; c->stats.trace_rounds = st[6];
     c->stats.band_redo = st[7];
+    c->stats.fwd_shader_cycles = 0; c->stats.fwd_wall_ticks = 0;
+    for (int i = 0; i < VC_STAT_SLOTS; ++i) { c->stats.fwd_shader_cycles += raw[8 * VC_STAT_SLOTS + 2 * i]; c->stats.fwd_wall_ticks += raw[8 * VC_STAT_SLOTS + 2 * i + 1]; }
     {
         uint64_t held = c->chunk_bytes + c->arena_bytes;
         for (Batch& bt : c->bt) for (auto& sl : bt.slots) held += sl.cap;

@@ -600,6 +600,62 @@ int vc_ovlset_set_cigar(vc_ovlset* o, uint64_t i, const char* cigar) {
 
 // Polisher::initialize (src/polisher.cpp:207-352) in fragment-correction mode: sequences and overlaps into the window builder.
 // Returns the number of overlaps kept, or -1 (message through err).  window_type: 0 NGS (mean read length <= 1000), 1 TGS.
+// ---- planning for one rank of a multi-GPU run (vechat_amd/polish.py): nothing but names, lengths and the overlap records are in
+// memory yet.  Stands in for the part of Polisher::initialize that sizes the work (src/polisher.cpp:207-352) before anything large
+// is loaded; the reference has no ranks -- it fans windows out over its devices inside one process (src/cuda/cudapolisher.cpp:229-241).
+// cost[k] = length of target k + the target bases every overlap lays on it (windows x depth x length).
+// Overlaps that name their sequences by file position (MHAP) are resolved through `reads` / `targets` (both may be names-only sets).
+int vc_io_target_cost(const vc_ovlset* o, const vc_seqset* targets, double* cost) {
+    if (!o || !targets || !cost) return VC_ERR_ARG;
+    std::unordered_map<std::string, uint32_t> t_id;
+    t_id.reserve(targets->size() * 2);
+    for (size_t i = 0; i < targets->size(); ++i) { t_id[targets->name(i)] = (uint32_t)i; cost[i] = (double)targets->length[i]; }
+    for (size_t k = 0; k < o->size(); ++k) {
+        uint32_t t;
+        if (o->by_index[k]) { if (o->t_index[k] >= targets->size()) continue; t = t_id[targets->name(o->t_index[k])]; }
+        else {
+            auto ti = t_id.find(std::string(o->text.data() + o->tn_off[k], o->tn_len[k]));
+            if (ti == t_id.end()) continue;
+            t = ti->second;
+        }
+        cost[t] += (double)(o->t_end[k] - o->t_begin[k]);
+    }
+    return VC_OK;
+}
+
+// '\n'-separated names a rank that owns targets [t_lo, t_hi) has to load: those targets and the query of every overlap on one of
+// them (each once).  The buffer is malloc'ed: vc_io_free() it.  NULL on error.
+char* vc_io_rank_names(const vc_ovlset* o, const vc_seqset* targets, const vc_seqset* reads, uint64_t t_lo, uint64_t t_hi, uint64_t* n_names) {
+    if (!o || !targets || t_lo > t_hi || t_hi > targets->size()) return nullptr;
+    std::unordered_map<std::string, uint8_t> mine;
+    mine.reserve((t_hi - t_lo) * 2);
+    std::string out;
+    uint64_t n = 0;
+    for (uint64_t i = t_lo; i < t_hi; ++i) {
+        const std::string nm = targets->name(i);
+        if (mine.emplace(nm, 1).second) { out += nm; out += '\n'; n++; }
+    }
+    std::unordered_map<std::string, uint8_t> seen;
+    for (size_t k = 0; k < o->size(); ++k) {
+        std::string tn, qn;
+        if (o->by_index[k]) {
+            if (!reads || o->t_index[k] >= targets->size() || o->q_index[k] >= reads->size()) continue;
+            tn = targets->name(o->t_index[k]); qn = reads->name(o->q_index[k]);
+        } else {
+            tn.assign(o->text.data() + o->tn_off[k], o->tn_len[k]); qn.assign(o->text.data() + o->qn_off[k], o->qn_len[k]);
+        }
+        if (!mine.count(tn) || mine.count(qn)) continue;
+        if (seen.emplace(qn, 1).second) { out += qn; out += '\n'; n++; }
+    }
+    char* buf = (char*)malloc(out.size() + 1);
+    if (!buf) return nullptr;
+    memcpy(buf, out.data(), out.size());
+    buf[out.size()] = 0;
+    if (n_names) *n_names = n;
+    return buf;
+}
+void vc_io_free(void* p) { free(p); }
+
 int64_t vc_io_load(vc_wb* wb, const vc_seqset* targets, const vc_seqset* reads, vc_ovlset* ovl, double error_threshold, int allow_empty,
                    int* window_type, char* err, uint64_t err_cap) {
     auto fail = [&](const std::string& m) -> int64_t { if (err && err_cap) { snprintf(err, (size_t)err_cap, "%s", m.c_str()); } return -1; };

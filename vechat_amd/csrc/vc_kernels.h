@@ -180,10 +180,11 @@ __device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph&
 // k_init: backbone chain graph (AddAlignment with an empty alignment, graph.cpp:207-212)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                             uint32_t NC, uint32_t EC, uint32_t ring, uint32_t kept) {
+                                             uint32_t NC, uint32_t EC, uint32_t ring, uint32_t kept, uint32_t* cursor) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];          // kept != 0: vc_kept_lds_bytes(NC)
     uint32_t slot = blockIdx.x;
     if (slot >= nslots) return;
+    if (cursor && threadIdx.x == 0) cursor[slot] = 1u;                       // the build loop starts at layer 1
     uint32_t w = w0 + slot;
     const int lane = vc_lane();
     uint32_t s0 = b.win_seq_off[w], ns = b.win_seq_off[w + 1] - s0;
@@ -963,9 +964,16 @@ __device__ __forceinline__ void vc_rows_sub_body(const VcBatchDev& b, const VcGr
 }
 
 __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
-                                                 uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask, uint32_t kept) {
+                                                 uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask, uint32_t kept,
+                                                 const uint32_t* cursor) {
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (cursor) {                                             // every window at its own layer; one that repeats its layer has its rows already
+        if (blockIdx.x >= nslots) return;
+        const uint32_t cv = cursor[blockIdx.x];
+        if (cv >> 31) return;
+        next_layer = (int)(cv & 0xFFFFu);
+    }
     vc_rows_sub_body(b, g, dp, w0, nslots, NC, EC, next_layer, ring, submask, kept, smem, blockIdx.x);
 }
 
@@ -1134,14 +1142,16 @@ __global__ __launch_bounds__(64) VC_RESOLVE_OCC void k_resolve(VcBatchDev b, VcG
                                                 uint32_t NC, uint32_t EC, uint32_t STK,
                                                 const uint16_t* tie_rows, const uint32_t* tie_cnt, const uint32_t* tie_over, uint32_t tie_over_stride, uint32_t* job_end,
                                                 const uint32_t* tie_list, const uint32_t* tie_n,
-                                                const uint32_t* submask, int layer, uint8_t* workspace, uint32_t ws_bytes, int force_dfs) {
+                                                const uint32_t* submask, int layer, uint8_t* workspace, uint32_t ws_bytes, int force_dfs,
+                                                const uint32_t* cursor) {
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];     // visit bitmap [NC/32 + 1] words + stack [256] u16
     const uint32_t n = *tie_n;
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
         __syncthreads();
-        vc_resolve_one(smem, workspace + (size_t)blockIdx.x * ws_bytes, tie_list[idx], b, g, dp, w0, nslots, NC, EC, STK, tie_rows, tie_cnt, tie_over, tie_over_stride,
-                       job_end, submask, layer, force_dfs);
+        const uint32_t slot = tie_list[idx];
+        vc_resolve_one(smem, workspace + (size_t)blockIdx.x * ws_bytes, slot, b, g, dp, w0, nslots, NC, EC, STK, tie_rows, tie_cnt, tie_over, tie_over_stride,
+                       job_end, submask, (cursor && slot < nslots) ? (int)(cursor[slot] & 0xFFFFu) : layer, force_dfs);
     }
 }
 
@@ -1224,6 +1234,8 @@ struct VcFwdArgs {
     const uint32_t* redo_list;     // != nullptr: this launch re-runs the listed jobs with whole rows (the backtrack left the band)
     const uint32_t* redo_n;
     uint32_t fold;                 // 1: the launch is built for the two widest classes of the batch and takes every narrower sequence in the lower one
+    const uint32_t* cursor;        // build phase, != nullptr: [nslots] the layer every window is at (bits 0..15) and, in bit 31, "its last backtrack
+                                   //   left the band: this layer again, with whole rows" (see Plan::build_layer); k0 is then unused
 #ifdef VC_LAB
     uint32_t dbg;                  // development (tools/gpu_fwd_lab.py): parts of the row loop switched off, timing only
 #endif
@@ -1273,6 +1285,10 @@ __host__ __device__ constexpr int vc_nds(int cpl) { return (cpl + 2 + 3) / 4; }
 // work counters: VC_STAT_SLOTS sets of 8, picked by block, summed by vc_get_stats
 #define VC_STAT_SLOTS 64
 __device__ __forceinline__ unsigned long long* vc_stat_slot(unsigned long long* stat) { return stat + (blockIdx.x % VC_STAT_SLOTS) * 8; }
+// behind the counter sets: [VC_STAT_SLOTS][2] shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) the forward waves spent in their
+// row loops -- their ratio is the shader clock the chip sustained under the job (bench.py: roofline.sclk_mhz)
+#define VC_STAT_WORDS (8 * VC_STAT_SLOTS + 2 * VC_STAT_SLOTS)
+__device__ __forceinline__ unsigned long long* vc_clk_slot(unsigned long long* stat) { return stat + 8 * VC_STAT_SLOTS + (blockIdx.x % VC_STAT_SLOTS) * 2; }
 
 __host__ __device__ inline bool vc_row_packed(int m, int n, int g, int cpl) {
     return g < 0 && (cpl - 1) * ((m > n ? m : n) - 2 * g) <= 255;
@@ -1408,13 +1424,14 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     // banded store: global alignments only (a local alignment may end and start anywhere), byte-packed rows only
     const bool band = NWT && PACKED && a.band && !redo;
     const char* const brow0 = reinterpret_cast<const char*>(a.bmat + (uint64_t)job * vc_band_job_dwords(a.hstride));
-    const uint32_t band_ql = vc_band_slope(len, nrows, CPL);
+    const uint32_t band_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_slope(len, nrows, CPL));   // a scalar: the band of a row is worked out on the scalar side
     if (band && lane == 0) a.band_par[job] = band_ql;
     constexpr uint32_t TR = vc_band_tile_rows(NDS);
     constexpr uint32_t TBB = vc_band_block_bytes(NDS), TLB = vc_band_tile_bytes(NDS);
     uint32_t t_rin = TR, t_off = 0u - TBB;                     // row inside the current block, byte offset of the block (scalars)
     unsigned long long t_mask = 0;                             // lanes of the block's band
-    uint32_t t_lane = 0;                                       // my byte offset inside a block: (lane - first band lane) * 128
+    uint32_t t_lane = 0;                                       // my byte offset inside a block: (lane - first band lane) * TLB
+    const uint32_t lane_tlb = (uint32_t)lane * TLB;
     int16_t* const c0p_out = a.c0 + (uint64_t)job * a.NC;
     const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
 
@@ -1578,9 +1595,19 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
             if (band) {
                 if (t_rin == TR) {                        // next row block: its band, once per TR rows, on the scalar side
                     t_rin = 0; t_off += TBB;
-                    const uint32_t bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_start(i + TR / 2u, band_ql));
+                    // vc_band_start(i + TR / 2, band_ql) in scalar arithmetic (row and slope are uniform; the product stays below 2^23, so
+                    // the plain multiply equals the 24-bit one the backtrack uses).  As vector code -- v_mul_u32_u24, a clamped subtract,
+                    // a minimum, v_readfirstlane and a full-rate-quarter v_mul_lo_u32 for the lane offset -- this was 5 of a row's ~59
+                    // vector instructions
+                    const uint32_t bt_ = ((i + TR / 2u) * band_ql) >> 16;
+                    // (in assembly: left to itself the compiler clamps with v_med3_u32 / a saturating v_sub -- only the vector ALU has those --
+                    // and multiplies the lane offset with a quarter-rate v_mad_u64_u32)
+                    constexpr uint32_t BLO = VC_BAND_LANES / 2 - 1, BHI = BLO + 64u - VC_BAND_LANES;
+                    uint32_t bs, bso;
+                    asm("s_max_u32 %0, %2, %3\n\ts_min_u32 %0, %0, %4\n\ts_sub_u32 %0, %0, %3\n\ts_mul_i32 %1, %0, %5"
+                        : "=&s"(bs), "=s"(bso) : "s"(bt_), "n"(BLO), "n"(BHI), "n"(TLB) : "scc");
                     t_mask = (unsigned long long)((1u << VC_BAND_LANES) - 1u) << bs;
-                    t_lane = ((uint32_t)lane - bs) * TLB;
+                    t_lane = lane_tlb - bso;
                 }
                 // the band lanes store under their own exec mask (all 64 lanes are active here: one wave, uniform control flow);
                 // the store is not visible to the compiler's vmcnt bookkeeping, which only makes its waits longer, never shorter
@@ -1617,6 +1644,7 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
         __builtin_amdgcn_wave_barrier();
     };
 
+    const unsigned long long clk_w0 = wall_clock64(), clk_c0 = clock64();
     for (uint32_t i0 = 1; i0 <= nrows; i0 += 64) {              // blocks of 64 rows: one record fetch, one column-0 flush
       myrec = nextrec;
       {
@@ -1730,6 +1758,10 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
       __threadfence_block();
     }
     if (lane == 0 && far_reads && !redo) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
+    if (!PIPE) {
+        const unsigned long long dc = clock64() - clk_c0, dw = wall_clock64() - clk_w0;
+        if (lane == 0) { unsigned long long* ck = vc_clk_slot(a.stat); atomicAdd(ck, dc); atomicAdd(ck + 1, dw); }
+    }
 
     if (redo) return VC_FWD_DONE;                           // the end cell, ties and counters stand from the first pass
     // publish the end cell
@@ -1784,6 +1816,11 @@ __device__ __forceinline__ bool vc_fwd_pick(const VcFwdArgs& a, VcJob& jb) {
     jb.slot = jb.job / a.group;
     if (jb.slot >= a.nslots) return false;
     jb.k = a.k0 + jb.job % a.group;
+    if (a.cursor) {                                         // every window at its own layer
+        const uint32_t cv = a.cursor[jb.slot];
+        jb.k = cv & 0xFFFFu;
+        jb.redo = jb.redo || (cv >> 31) != 0;
+    }
     return true;
 }
 
@@ -1851,7 +1888,7 @@ __global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_
     const uint32_t job = blockIdx.x;
     const uint32_t slot = job / a.group;
     if (slot >= a.nslots) return;
-    const uint32_t k = a.k0 + job % a.group;
+    const uint32_t k = a.cursor ? (a.cursor[slot] & 0xFFFFu) : a.k0 + job % a.group;
     const uint32_t w = a.w0 + slot;
     if (a.job_type[job] != 255) return;                      // k_fwd took it
     if (a.b.status[w] != VC_WIN_OK) return;
@@ -2083,6 +2120,8 @@ struct VcTraceArgs {
     int shared_table;           // k_tracew: the VC_TG alignments of a wave share a window (group % VC_TG == 0)
     uint32_t tab_rows;          // k_tracew: rows the LDS table is sized for (>= every graph's height in this launch)
     uint32_t cpl_lo;            // narrowest width class the forward pass of this launch used (0: every sequence in its own class)
+    uint32_t* cursor;           // build phase, != nullptr: [nslots] layer of every window | "left the band" << 31 (VcFwdArgs::cursor); the walk
+                                //   sets / clears the flag, the pair list of a window is pairs + slot * PC
 };
 
 // One alignment per THREAD: the walk is a chain of dependent lookups, so the instruction cost is shared
@@ -2095,9 +2134,9 @@ __global__ void k_trace(VcTraceArgs a) {
     if (threadIdx.x >= VC_TRACE_LANES) return;
     const uint32_t job = blockIdx.x * VC_TRACE_LANES + threadIdx.x;
     if (job >= a.nslots * a.group) return;
-    const uint32_t slot = job / a.group, k = a.k0 + job % a.group;
+    const uint32_t slot = job / a.group, k = a.cursor ? (a.cursor[slot] & 0xFFFFu) : a.k0 + job % a.group;
     const uint32_t w = a.w0 + slot;
-    const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
+    const uint64_t pj = a.cursor ? (uint64_t)slot : (uint64_t)slot * a.pair_group + (k - a.pair_k0);
     const uint8_t type = a.job_type[job];
     if (type == 255) return;
     const bool wide = type >= 2;
@@ -2491,6 +2530,9 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
         else if (gbroken) { vc_fail(a.b, w, VC_WIN_INVALID, 17, gi); gnout = 0; }
         else if (govf) { vc_fail(a.b, w, VC_WIN_OVERFLOW, 5, gnout); gnout = 0; }
         a.npairs[pj] = gnout;
+        // the window stays at this layer when the walk left the band (k_addaln passes it over, the next forward pass stores its rows
+        // whole); a walk over whole rows cannot leave anything: the flag goes
+        if (!PIPE && a.cursor) a.cursor[slot] = k | (gredo ? 0x80000000u : 0u);
     }
     {   // statistics: summed over the wave first, then one of VC_STAT_SLOTS counter sets (a single set serialises in the L2)
         uint32_t s0 = (valid && gl == 0) ? gnout : 0u, s1 = (valid && gl == 0) ? nspec_ok : 0u, s2 = (valid && gl == 0) ? nrounds : 0u;
@@ -2520,9 +2562,16 @@ __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
         valid = job < nr;
         job = valid ? a.redo_list[job] : 0u;
     }
-    const uint32_t slot = valid ? job / a.group : 0, k = valid ? a.k0 + job % a.group : 0;
-    const uint64_t pj = (uint64_t)slot * a.pair_group + (k - a.pair_k0);
-    (void)vc_tracew_body<false, TL>(a, smem, job, slot, k, pj, valid, redo);
+    const uint32_t slot = valid ? job / a.group : 0;
+    uint32_t k = valid ? a.k0 + job % a.group : 0;
+    bool whole = redo;                                        // this alignment's matrix was stored whole
+    if (a.cursor && valid) {
+        const uint32_t cv = a.cursor[slot];
+        k = cv & 0xFFFFu;
+        whole = redo || (cv >> 31) != 0;
+    }
+    const uint64_t pj = a.cursor ? (uint64_t)slot : (uint64_t)slot * a.pair_group + (k - a.pair_k0);
+    (void)vc_tracew_body<false, TL>(a, smem, job, slot, k, pj, valid, whole);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2546,6 +2595,8 @@ struct VcAddArgs {
     int make_rows;                // 0: leave the row records of THIS layer in place (vc_debug_stop_after looks at them)
     uint32_t kept;                // != 0: slots of k_fwd's kept-row ring (the dynamic LDS then also covers vc_kept_lds_bytes(NC))
     uint32_t* tie_n; uint32_t* redo_n;   // the layer's tie-list and redo-list counters: this is the layer's last kernel, it clears them for the next layer
+    uint32_t* cursor;             // != nullptr: [nslots] the layer every window is at (VcFwdArgs::cursor); `layer` is then unused.  A window whose
+                                  //   backtrack left the band is passed over; one whose alignment was added moves on to its next layer
 };
 
 // AddAlignment of sequence `layer` of window `slot` (+ the row records of the next layer when it is full-span).  `scr`: which of the
@@ -2557,7 +2608,8 @@ __device__ unsigned long long vc_add_prof[8];
 #else
 #define VC_ADD_STAMP(i) do { } while (0)
 #endif
-__device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem, const uint32_t slot, const uint32_t layer, const uint32_t scr) {
+// -> the alignment was added (false: nothing to do for this window, or it failed and carries its status)
+__device__ __forceinline__ bool vc_addaln_body(const VcAddArgs& a, uint8_t* smem, const uint32_t slot, const uint32_t layer, const uint32_t scr) {
 #ifdef VC_ADD_PROF
     long long t_prof = clock64();
 #endif
@@ -2570,12 +2622,12 @@ __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem
     uint16_t* s_be = s_bs + a.PC;                       //      aligned group of the pair's node
     uint16_t* s_pn = s_be + a.PC;                       // [PC] position of the pair's node itself
     uint16_t* s_ord = s_pn + a.PC;                      // [NC] old order
-    if (slot >= a.nslots) return;
+    if (slot >= a.nslots) return false;
     const uint32_t w = a.w0 + slot;
-    if (a.b.status[w] != VC_WIN_OK) return;
+    if (a.b.status[w] != VC_WIN_OK) return false;
     const int lane = vc_lane();
     const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
-    if (layer >= ns) return;
+    if (layer >= ns) return false;
     const uint64_t so = a.b.seq_off[s0 + layer];
     const uint32_t len = (uint32_t)(a.b.seq_off[s0 + layer + 1] - so);
     const bool hq = a.b.seq_has_qual[s0 + layer] != 0;
@@ -2675,9 +2727,9 @@ __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem
     if (nvalid != len || P == 0) err = VC_WIN_INVALID;
     if (N0 + nnew > a.NC || N0 + nnew >= 0xFFFF) err = VC_WIN_OVERFLOW;
 #ifdef VC_DBG_ADD
-    if (err) { if (lane == 0) vc_fail(a.b, w, err, 6, (nvalid & 0x3FF) | ((P & 0x3F) << 10)); return; }
+    if (err) { if (lane == 0) vc_fail(a.b, w, err, 6, (nvalid & 0x3FF) | ((P & 0x3F) << 10)); return false; }
 #endif
-    if (err) { if (lane == 0) vc_fail(a.b, w, err, 6, nvalid != len || P == 0 ? 1 : 2); return; }
+    if (err) { if (lane == 0) vc_fail(a.b, w, err, 6, nvalid != len || P == 0 ? 1 : 2); return false; }
     __syncthreads();
     VC_ADD_STAMP(0);
 
@@ -2717,7 +2769,7 @@ __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem
         a.g.visits[nb + curr] = 0;
         a.g.nrec[nb + curr] = make_uint4((uint32_t)a.b.bases[so + col - 1], 0u, 0u, 0u);
     }
-    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 7, 0); return; }
+    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 7, 0); return false; }
     __syncthreads();      // pass B's stores are complete before pass C touches the same nodes
     VC_ADD_STAMP(1);
 
@@ -2847,7 +2899,7 @@ __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem
             a.g.nrec[nb + curr[u]] = r4;
         }
     }
-    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 8, E0 + enew); return; }
+    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_OVERFLOW, 8, E0 + enew); return false; }
     VC_ADD_STAMP(2);
 
     // pass D: keep VcGraph::ord a valid DP order with aligned groups contiguous.
@@ -2878,7 +2930,7 @@ __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem
     for (uint32_t p = lane; p < N0; p += 64) s_ord[p] = a.g.ord[nb + p];
     __syncthreads();
     for (uint32_t t = lane; t + 1 < nnew; t += 64) if (s_anchor[t + 1] < s_anchor[t]) err = 1;
-    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 16, 0); return; }
+    if (__any(err)) { if (lane == 0) vc_fail(a.b, w, VC_WIN_INVALID, 16, 0); return false; }
     for (uint32_t p = lane; p < N0; p += 64) {
         uint32_t lo = 0, hi = nnew;                     // first t with anchor[t] > p
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_anchor[mid] <= p) lo = mid + 1; else hi = mid; }
@@ -2896,10 +2948,10 @@ __device__ __forceinline__ void vc_addaln_body(const VcAddArgs& a, uint8_t* smem
     VC_ADD_STAMP(3);
     if (a.make_rows) vc_rows_full(a.b, a.g, a.dp, slot, w, a.NC, a.EC, (int)layer + 1, a.ring, N0 + nnew, a.kept, smem);   // the next layer's rows (full-span layers)
     VC_ADD_STAMP(4);
-    if (vc_lane() == 0) { (void)0; }
 #ifdef VC_ADD_PROF
     if (vc_lane() == 0) atomicAdd(&vc_add_prof[7], 1ull);
 #endif
+    return true;
 }
 
 __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
@@ -2908,7 +2960,15 @@ __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
     // per layer was 2 000 tiny launches per step, each waiting ~100 us for a slot beside k_fwd
     if (blockIdx.x == 0 && threadIdx.x == 0) { *a.tie_n = 0; *a.redo_n = 0; }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    vc_addaln_body(a, smem, blockIdx.x, a.layer, blockIdx.x);
+    uint32_t layer = a.layer;
+    if (a.cursor) {
+        if (blockIdx.x >= a.nslots) return;
+        const uint32_t cv = a.cursor[blockIdx.x];
+        if (cv >> 31) return;                                 // its backtrack left the band: the layer is aligned again first
+        layer = cv & 0xFFFFu;
+    }
+    const bool added = vc_addaln_body(a, smem, blockIdx.x, layer, blockIdx.x);
+    if (a.cursor && added && threadIdx.x == 0) a.cursor[blockIdx.x] = layer + 1u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3349,6 +3409,19 @@ __global__ void k_byte_presence(const uint8_t* bases, uint64_t n, uint32_t* mask
 __global__ void k_max_u32(const uint32_t* v, uint32_t n, uint32_t* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) atomicMax(out, v[i]);
+}
+
+// build phase with a layer cursor per window: how many layers the slowest window of the chunk still has to go (windows that had
+// to repeat a layer with whole rows are behind the launch count)
+__global__ void k_lag(VcBatchDev b, const uint32_t* cursor, uint32_t w0, uint32_t nslots, uint32_t* out) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t lag = 0;
+    if (slot < nslots) {
+        const uint32_t w = w0 + slot, ns = b.win_seq_off[w + 1] - b.win_seq_off[w];
+        const uint32_t at = cursor[slot] & 0xFFFFu;
+        if (ns >= 3 && b.status[w] == VC_WIN_OK && at < ns) lag = ns - at;
+    }
+    if (lag) atomicMax(out, lag);
 }
 
 // compacts the per-window consensus slots into one contiguous buffer (offsets from an exclusive scan)

@@ -123,6 +123,7 @@ class HipContext:
         d = dict(cells=int(s.cells), alignments=int(s.alignments), dp_rows=int(s.dp_rows), far_row_reads=int(s.far_row_reads), trace_steps=int(s.trace_steps), trace_spec=int(s.trace_spec), trace_rounds=int(s.trace_rounds),
                  max_nodes=int(s.max_nodes), max_edges=int(s.max_edges), chunk_windows=int(s.chunk_windows), n_streams=int(s.n_streams),
                  band_redo=int(s.band_redo), device_bytes=int(s.device_bytes),
+                 fwd_sclk_mhz=(100.0 * int(s.fwd_shader_cycles) / int(s.fwd_wall_ticks)) if int(s.fwd_wall_ticks) else None,
                  kernels={})
         for i in range(s.n_classes):
             d["kernels"][s.names[i].value.decode()] = dict(ms=float(s.ms[i]), launches=int(s.launches[i]), busy_ms=float(s.busy_ms[i]))
