@@ -167,6 +167,9 @@ int   vc_set_pipeline(vc_ctx* ctx, int on, uint32_t forward_waves, uint32_t back
  * allocations.  The counterpart of createCUDABatch sizing a batch's device memory at construction (mem_per_batch, src/cuda/cudapolisher.cpp:229-243):
  * a caller does it while its input is still being parsed.  Optional; without it vc_submit allocates what a batch needs. */
 int   vc_reserve(vc_ctx* ctx, uint64_t bytes);
+/* Gives the workspaces (and a reservation) back to the device; batch buffers and results stay.  The next vc_submit lays them out again.
+ * For a caller that needs the memory for something else in between -- e.g. a second context for windows that overflowed. */
+int   vc_release(vc_ctx* ctx);
 /* The window type is known only after the reads are (Polisher::initialize, src/polisher.cpp:300-306); a context created before that
  * takes it here.  0 = kNGS, 1 = kTGS. */
 int   vc_set_window_type(vc_ctx* ctx, int window_type);

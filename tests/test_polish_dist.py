@@ -33,6 +33,9 @@ class OracleContext:
     def set_window_type(self, window_type):
         self.params.window_type = int(window_type)
 
+    def reserve(self, nbytes=0):
+        pass
+
     def consensus(self, batch, retry_overflow=True):
         cons, pol, _ = oa.oracle_run(batch, self.params)
         return cons, np.array([capi.VC_WIN_OK if p else capi.VC_WIN_UNPOLISHED for p in pol], dtype=np.uint8)
@@ -41,9 +44,11 @@ class OracleContext:
         pass
 
 
-def _run(rank, world, port, argv, q):
+def _run(rank, world, port, argv, q, py_readers=False):
     from vechat_amd import polish
     polish.HipContext = OracleContext
+    if py_readers:
+        os.environ["VC_PY_PARSERS"] = "1"
     if world > 1:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                           VC_DIST_BACKEND="gloo")
@@ -57,8 +62,11 @@ def _run(rank, world, port, argv, q):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("py_readers", [False, True])
 @pytest.mark.parametrize("flags,key", [(["-p", "-d", "0.2", "-s", "0.2"], "hap"), ([], "linear")])
-def test_two_ranks_write_what_one_rank_writes(built, tmp_path, flags, key):
+def test_two_ranks_write_what_one_rank_writes(built, tmp_path, flags, key, py_readers):
+    """py_readers False: a rank plans and loads through the C++ readers (vc_io_target_cost / vc_io_rank_names / vc_io_load); True: the
+    Python readers (VC_PY_PARSERS=1), the second restatement -- the same text either way."""
     fx, wb = fixtures.load_plumbing()
     wb.close()
     rp, op, tp = write_inputs(fx, tmp_path, sam=True)
@@ -68,7 +76,7 @@ def test_two_ranks_write_what_one_rank_writes(built, tmp_path, flags, key):
     for world in (1, 2):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         q = ctx.Queue()
-        procs = [ctx.Process(target=_run, args=(r, world, port, argv, q)) for r in range(world)]
+        procs = [ctx.Process(target=_run, args=(r, world, port, argv, q, py_readers)) for r in range(world)]
         for p in procs:
             p.start()
         got = dict((r, (rc, text)) for r, rc, text in (q.get(timeout=240) for _ in range(world)))

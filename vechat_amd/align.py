@@ -36,3 +36,10 @@ def align_pairs(pairs, device=0, lib=None):
         raise RuntimeError(f"vc_align failed ({rc}): {lib.vc_align_last_error().decode()}")
     raw = buf.raw
     return [raw[int(off[k]):int(off[k + 1]) - 1].decode() for k in range(n)], [int(x) for x in dist]
+
+
+def release(lib=None):
+    """vc_align_release: the aligner's (large) matrix buffer goes back to the device."""
+    lib = lib or capi.load_hip()
+    lib.vc_align_release.restype = None
+    lib.vc_align_release()

@@ -303,6 +303,7 @@ def load_hip():
         lib.vc_set_pipeline.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
         lib.vc_set_pipeline.restype = C.c_int
         lib.vc_reserve.argtypes = [vp, C.c_uint64]; lib.vc_reserve.restype = C.c_int
+        lib.vc_release.argtypes = [vp]; lib.vc_release.restype = C.c_int
         lib.vc_set_window_type.argtypes = [vp, C.c_int]; lib.vc_set_window_type.restype = C.c_int
         lib.vc_stream.argtypes = [vp]
         lib.vc_stream.restype = vp

@@ -1180,6 +1180,15 @@ int vc_reserve(vc_ctx* c, uint64_t bytes) {
     return VC_OK;
 }
 
+int vc_release(vc_ctx* c) {
+    if (!c) return VC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    drain(c);
+    free_workspaces(c);
+    if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+    return VC_OK;
+}
+
 int vc_set_window_type(vc_ctx* c, int window_type) {
     if (!c || (window_type != 0 && window_type != 1)) return VC_ERR_ARG;
     drain(c);

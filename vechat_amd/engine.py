@@ -53,6 +53,10 @@ class HipContext:
         ex.shutdown(wait=False)
         return fut
 
+    def reserve(self, nbytes=0):
+        """vc_reserve: the workspaces' memory in one piece, now (0 = the default budget)."""
+        self._chk(self.lib.vc_reserve(self.h, int(nbytes)), "vc_reserve")
+
     def set_window_type(self, window_type):
         self.params.window_type = int(window_type)
         self._chk(self.lib.vc_set_window_type(self.h, int(window_type)), "vc_set_window_type")
@@ -144,6 +148,7 @@ class HipContext:
             p.max_nodes = min(2 * st["max_nodes"], MAX_NODES)
             p.max_edges = min(2 * st["max_edges"], MAX_EDGES)
             if p.max_nodes > st["max_nodes"] or p.max_edges > st["max_edges"]:
+                self.lib.vc_release(self.h)             # this context's workspaces (up to 60 % of the device) go back first: the retry plans on what is free
                 try:
                     sub = HipContext(params=p)
                 except VcError:

@@ -74,39 +74,50 @@ def main(argv=None):
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     distributed = world > 1 or os.environ.get("VC_FORCE_DIST") == "1"
     device = int(os.environ.get("LOCAL_RANK", a.device)) if distributed else a.device
-    # One process: the C++ readers behind the C ABI (vc_io_read_sequences / vc_io_read_overlaps / vc_io_load) hold the records and
-    # feed the window builder directly.  A rank of a multi-GPU run plans on names and lengths and filters by target first: that
-    # path (and VC_PY_PARSERS=1) goes through the Python readers, which give the same records (tests/test_seqio.py).
-    native = native_parsers() and not distributed
+    # The C++ readers behind the C ABI (vc_io_read_sequences / vc_io_read_overlaps / vc_io_load) hold the records and feed the window
+    # builder directly -- in one process, and in a rank of a multi-GPU run, which first plans on names, lengths and overlap records
+    # (vc_io_target_cost / vc_io_rank_names) and then loads only its own targets and the reads their overlaps mention.  The Python
+    # readers (VC_PY_PARSERS=1; MHAP in a multi-GPU run: its records name sequences by file position) give the same records
+    # (tests/test_seqio.py) and remain as the second restatement.
+    native = native_parsers() and not (distributed and str(a.overlaps).split(".gz")[0].endswith(".mhap"))
     native_targets = None
     ctx_kw = dict(device=device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
                   num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
                   max_nodes=a.max_nodes, n_streams=a.streams)
     ctx_future = None
-    if native:
-        # the device starts up and its workspaces are reserved (vc_reserve) while the files are parsed: the reference sizes its
-        # batches' device memory before the first window as well (cudapolisher.cpp:229-243)
-        ctx_future = HipContext.in_background(reserve=0, **ctx_kw)
-        native_reads, overlaps, native_targets = read_inputs_native(a.sequences, a.overlaps, a.targets)
-    else:
-        overlaps = read_overlaps(a.overlaps)
-    # window type comes from the mean length of ALL reads (polisher.cpp:300-306).  One process reads the file once and keeps
-    # the records; a rank of a multi-GPU run only needs names and lengths here and loads its own share of the reads below
     all_reads = None
-    if distributed:
-        r_index = sequence_index(a.sequences)
-        lengths = [l for _, l in r_index]
-    elif native:
+    r_idx = t_idx = None
+    if native and not distributed:
+        # the device starts up while the files are parsed (the workspaces are reserved below, once the aligner is done with the memory)
+        ctx_future = HipContext.in_background(**ctx_kw)
+        native_reads, overlaps, native_targets = read_inputs_native(a.sequences, a.overlaps, a.targets)
         all_reads = native_reads
         lengths = all_reads.lengths
+    elif native:
+        # a rank: names and lengths of everything, every overlap record -- no bases yet
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(3) as ex:
+            fo = ex.submit(NativeOverlaps, a.overlaps)
+            ft = ex.submit(NativeSequences, a.targets, None, True)
+            fr = ex.submit(NativeSequences, a.sequences, None, True)
+            overlaps, t_idx, r_idx = fo.result(), ft.result(), fr.result()
+        lengths = r_idx.lengths
     else:
-        all_reads = read_sequences(a.sequences)
-        lengths = [len(d) for _, d, _ in all_reads]
+        overlaps = read_overlaps(a.overlaps)
+        # window type comes from the mean length of ALL reads (polisher.cpp:300-306).  One process reads the file once and keeps
+        # the records; a rank of a multi-GPU run only needs names and lengths here and loads its own share of the reads below
+        if distributed:
+            r_index = sequence_index(a.sequences)
+            lengths = [l for _, l in r_index]
+        else:
+            all_reads = read_sequences(a.sequences)
+            lengths = [len(d) for _, d, _ in all_reads]
     if not len(lengths):
         raise ValueError("empty sequences set")
     window_type = 0 if float(sum(int(x) for x in lengths)) / float(len(lengths)) <= 1000 else 1
     keep_t = keep_r = None
     if distributed:
+        import ctypes as C
         import torch
         import torch.distributed as dist
         from .seqio import _resolve_indices
@@ -116,12 +127,30 @@ def main(argv=None):
         dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
         # my contiguous range of targets, by estimated work; nothing but names and lengths has been read so far
-        t_index = sequence_index(a.targets)
-        _resolve_indices(t_index, r_index, overlaps)              # MHAP names sequences by file position
-        lo, hi = shard_range_balanced(target_cost(t_index, overlaps), rank, world)
-        keep_t = {n for n, _ in t_index[lo:hi]}
-        overlaps = [o for o in overlaps if o.t_name in keep_t]
-        keep_r = {o.q_name for o in overlaps} | keep_t
+        if native:
+            lib = overlaps.lib
+            cost = np.zeros(max(len(t_idx), 1), np.float64)
+            if lib.vc_io_target_cost(overlaps.h, t_idx.h, cost.ctypes.data_as(C.POINTER(C.c_double))) != 0:
+                raise ValueError("vc_io_target_cost failed")
+            lo, hi = shard_range_balanced(cost[:len(t_idx)], rank, world)
+            nn = C.c_uint64(0)
+            blob = lib.vc_io_rank_names(overlaps.h, t_idx.h, r_idx.h, lo, hi, C.byref(nn))
+            if not blob:
+                raise ValueError("vc_io_rank_names failed")
+            try:
+                keep_blob = C.string_at(blob)
+            finally:
+                lib.vc_io_free(blob)
+            native_targets = NativeSequences(a.targets, keep=set(t_idx.names()[lo:hi]))
+            all_reads = NativeSequences(a.sequences, keep_blob=keep_blob)
+            t_idx.close(); r_idx.close()
+        else:
+            t_index = sequence_index(a.targets)
+            _resolve_indices(t_index, r_index, overlaps)              # MHAP names sequences by file position
+            lo, hi = shard_range_balanced(target_cost(t_index, overlaps), rank, world)
+            keep_t = {n for n, _ in t_index[lo:hi]}
+            overlaps = [o for o in overlaps if o.t_name in keep_t]
+            keep_r = {o.q_name for o in overlaps} | keep_t
 
     text = b""
     n_targets = n_windows = n_polished = kept = n_aligned = 0
@@ -136,7 +165,7 @@ def main(argv=None):
             wb = WindowBuilder(a.window_length, a.quality_threshold)
             if native:
                 n_aligned = align_missing_native(targets, reads, overlaps, a.error_threshold, device)
-                kept, _ = load_polisher_input_native(wb, targets, reads, overlaps, a.error_threshold)
+                kept, _ = load_polisher_input_native(wb, targets, reads, overlaps, a.error_threshold, allow_empty=distributed)
                 target_name = None
             else:
                 if reads and overlaps:
@@ -153,6 +182,17 @@ def main(argv=None):
                     ctx.set_window_type(window_type)
                 else:
                     ctx = HipContext(window_type=window_type, **ctx_kw)
+                if n_aligned:
+                    from .align import release as release_aligner
+                    release_aligner()                       # the overlap aligner's matrix buffer goes back before the workspaces are laid out
+                # Large inputs: the workspaces in one piece (vc_reserve: batches of any shape are then laid out without further
+                # allocations -- the counterpart of the reference sizing its batches' device memory up front, cudapolisher.cpp:229-243).
+                # A small input allocates the little it needs itself, and a reservation that fails is not an error.
+                if batch.n_windows >= 4096:
+                    try:
+                        ctx.reserve(0)
+                    except Exception:                       # noqa: BLE001
+                        pass
                 cons, status = ctx.consensus(batch, retry_overflow=not a.no_capacity_retry)
                 ctx.close()
                 # Every valid window is computed on the device.  What can remain is a graph beyond the 16-bit id space after the

@@ -284,10 +284,11 @@ def native_parsers():
 class NativeSequences:
     """The records of one FASTA / FASTQ(.gz) file, held by the library (vc_seqset)."""
 
-    def __init__(self, path, keep=None, names_only=False, lib=None):
+    def __init__(self, path, keep=None, names_only=False, lib=None, keep_blob=None):
+        """keep: a set of names -- the other records are passed over; keep_blob: the same as '\\n'-separated bytes (vc_io_rank_names)."""
         from . import capi
         self.lib = lib or capi.load_host()
-        kn = None if keep is None else "\n".join(sorted(keep)).encode()
+        kn = keep_blob if keep_blob is not None else (None if keep is None else "\n".join(sorted(keep)).encode())
         self.h = self.lib.vc_io_read_sequences(os.fsencode(str(path)), kn, 1 if names_only else 0)
         err = self.lib.vc_seqset_error(self.h)
         if err:
