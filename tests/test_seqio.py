@@ -212,6 +212,16 @@ def test_native_readers_odd_inputs_and_filters(built, tmp_path):
         seqio.NativeOverlaps(tmp_path / "x.txt")
     with pytest.raises(ValueError):
         seqio.NativeSequences(tmp_path / "missing.fa")
+    # coordinates out of order or beyond 32 bits: both readers refuse the record and say so (they used to wrap around / go negative)
+    bad = {"a.paf": "r\t40\t30\t10\t+\tt\t120\t4\t44\t40\t40\t60\n", "b.paf": "r\t40\t0\t40\t+\tt\t120\t44\t4\t40\t40\t60\n",
+           "c.paf": "r\t40\t0\t5000000000\t+\tt\t120\t4\t44\t40\t40\t60\n", "d.sam": "q\t0\tt\t0\t60\t10M\t*\t0\t0\t*\t*\n",
+           "e.mhap": "1 1 0.1 10 0 40 0 40 1 4 44 120\n", "f.mhap": "0 1 0.1 10 0 0 40 40 1 4 44 120\n"}
+    for name, text in bad.items():
+        (tmp_path / name).write_text(text)
+        with pytest.raises(ValueError, match="malformed"):
+            seqio.NativeOverlaps(tmp_path / name)
+        with pytest.raises(ValueError, match="malformed"):
+            seqio.read_overlaps(tmp_path / name)
     # the filters of Polisher::initialize, and a read that is also a target
     (tmp_path / "t.fa").write_text(">t\n" + "ACGT" * 30 + "\n")
     (tmp_path / "r.fa").write_text(">t\n" + "ACGT" * 30 + "\n>r\n" + "ACGT" * 10 + "\n")

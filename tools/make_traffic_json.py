@@ -45,6 +45,10 @@ if st.get("windows") and tot_valu:
     out["windows"] = st["windows"]
     out["valu_insts_per_window_all_kernels"] = tot_valu / st["windows"]
     out["valu_insts_per_window_by_kernel"] = {k: d.get("SQ_INSTS_VALU", 0.0) / st["windows"] for k, d in sorted(agg.items()) if d.get("SQ_INSTS_VALU")}
+    # every instruction class the SQ counts, all kernels, per window (bench.py: roofline.instruction_issue)
+    classes = ("VALU", "SALU", "BRANCH", "SMEM", "LDS", "VMEM_RD", "VMEM_WR")
+    out["insts_per_window_all_kernels"] = {c: sum(d.get("SQ_INSTS_" + c, 0.0) for d in agg.values()) / st["windows"] for c in classes
+                                           if any("SQ_INSTS_" + c in d for d in agg.values())}
 f = out["kernels"].get("k_fwd", {})
 if f:
     out["bytes_per_cell_written"] = f.get("hbm_write_bytes", 0) / cells

@@ -754,7 +754,8 @@ struct Plan {
     // every layer of every window of the chunk: `layers` rounds, then as many catch-up rounds as the slowest window is behind
     int build_loop(Work& wk) {
         int rc;
-        const bool defer = bt->band && !getenv("VC_INLINE_REDO");        // (development: VC_INLINE_REDO=1 keeps the redo pair in every round)
+        const char* ir = getenv("VC_INLINE_REDO");                       // (development: VC_INLINE_REDO=1 keeps the redo pair in every round)
+        const bool defer = bt->band && !(ir && std::atoi(ir) != 0);
         for (uint32_t j = 1; j <= wk.layers; ++j) if ((rc = build_layer(wk, j, !defer))) return rc;
         if (!defer) return VC_OK;
         // (the one host wait of the build phase; the re-alignment rounds have theirs: Plan::realign)

@@ -463,6 +463,11 @@ void parse_overlap_lines(vc_ovlset* o, OvlFmt fmt, const std::string& ps, const 
     auto name = [&](std::vector<uint64_t>& off, std::vector<uint32_t>& len, const std::pair<const char*, const char*>& x) {
         off.push_back((uint64_t)(x.first - base)); len.push_back((uint32_t)(x.second - x.first));
     };
+    // coordinates out of order or beyond 32 bits (the fields are u32 from here on): refused here, with the place, instead of wrapping
+    // around and surfacing much later as a generic range error (seqio.py: _check_spans is the same test)
+    auto bad_spans = [](uint64_t qb, uint64_t qe, uint64_t ql, uint64_t tb, uint64_t te) {
+        return qb > qe || tb > te || std::max(std::max(qe, ql), te) > 0xFFFFFFFFull;
+    };
     while (p < e) {
         const char* le = line_end(p, e);
         const char* a = p; const char* b = le;
@@ -471,6 +476,7 @@ void parse_overlap_lines(vc_ovlset* o, OvlFmt fmt, const std::string& ps, const 
         strip(sa, sb);
         if (sa == sb) continue;
         const std::string where = " in the record that starts at byte " + std::to_string((size_t)(a - base));
+        const std::string spans = ": coordinates out of order or beyond 32 bits";
         if (fmt == SAM) {
             if (*a == '@') continue;
             if (b > a && b[-1] == '\r') --b;
@@ -488,6 +494,7 @@ void parse_overlap_lines(vc_ovlset* o, OvlFmt fmt, const std::string& ps, const 
             uint64_t qb = qbc, qe = qbc + qa;
             const uint64_t ql = clip + qa;
             if (st) { const uint64_t nb = ql - qe, ne = ql - qb; qb = nb; qe = ne; }
+            if (pos == 0 || bad_spans(qb, qe, ql, pos - 1, pos - 1 + ta)) { o->err = ps + ": malformed SAM record" + spans + where; return; }
             const uint64_t tb = pos - 1, te = tb + ta, len = std::max(qa, ta);
             name(o->qn_off, o->qn_len, fl.f[0]); name(o->tn_off, o->tn_len, fl.f[2]);
             o->by_index.push_back(0); o->q_index.push_back(0); o->t_index.push_back(0);
@@ -502,6 +509,7 @@ void parse_overlap_lines(vc_ovlset* o, OvlFmt fmt, const std::string& ps, const 
                 !to_u64(fl.f[3].first, fl.f[3].second, qe) || !to_u64(fl.f[7].first, fl.f[7].second, tb) || !to_u64(fl.f[8].first, fl.f[8].second, te)) {
                 o->err = ps + ": malformed PAF record" + where; return;
             }
+            if (bad_spans(qb, qe, ql, tb, te)) { o->err = ps + ": malformed PAF record" + spans + where; return; }
             const uint64_t len = std::max(qe - qb, te - tb);
             name(o->qn_off, o->qn_len, fl.f[0]); name(o->tn_off, o->tn_len, fl.f[5]);
             o->by_index.push_back(0); o->q_index.push_back(0); o->t_index.push_back(0);
@@ -518,6 +526,7 @@ void parse_overlap_lines(vc_ovlset* o, OvlFmt fmt, const std::string& ps, const 
             bool ok = fl.f.size() >= 12;
             for (int k : {0, 1, 4, 5, 6, 7, 8, 9, 10}) ok = ok && to_u64(fl.f[k].first, fl.f[k].second, v[k]);
             if (!ok) { o->err = ps + ": malformed MHAP record" + where; return; }
+            if (v[0] < 1 || v[1] < 1 || v[0] > 0xFFFFFFFFull || v[1] > 0xFFFFFFFFull || bad_spans(v[5], v[6], v[7], v[9], v[10])) { o->err = ps + ": malformed MHAP record" + spans + where; return; }
             const uint64_t len = std::max(v[6] - v[5], v[10] - v[9]);
             o->qn_off.push_back(0); o->qn_len.push_back(0); o->tn_off.push_back(0); o->tn_len.push_back(0);
             o->by_index.push_back(1); o->q_index.push_back((uint32_t)(v[0] - 1)); o->t_index.push_back((uint32_t)(v[1] - 1));

@@ -1204,6 +1204,16 @@ __device__ __forceinline__ uint32_t vc_band_tile_of_row(uint32_t r1, uint32_t ti
 }
 // first band lane of row block tb (rows tb * TR + 1 ...): the diagonal at the block's middle
 __device__ __forceinline__ uint32_t vc_band_block_start(uint32_t tb, uint32_t tr, uint32_t ql) { return vc_band_start(tb * tr + 1u + tr / 2u, ql); }
+// Row-major band rows: the band MOVES only every VC_BAND_ROWS rows (a power of two) -- rows (b * VC_BAND_ROWS + 1 ...) share the lanes of the
+// diagonal at the block's middle.  The diagonal advances ~0.04 lanes per row, so a block of 8 rows shifts the band by a third of a lane at
+// most, and k_fwd works out a band (scalar multiply, clamps, exec mask, lane offsets) once per 8 rows instead of once per row.
+#ifndef VC_BAND_ROWS
+#define VC_BAND_ROWS 8
+#endif
+static_assert(VC_BAND_ROWS >= 1 && (VC_BAND_ROWS & (VC_BAND_ROWS - 1)) == 0, "rows per band block: a power of two");
+__device__ __forceinline__ uint32_t vc_band_row_start(uint32_t r1, uint32_t ql) {        // r1 = row - 1
+    return vc_band_start((r1 & ~(uint32_t)(VC_BAND_ROWS - 1)) + 1u + VC_BAND_ROWS / 2u, ql);
+}
 
 struct VcFwdArgs {
     VcBatchDev b;
@@ -1429,6 +1439,7 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     constexpr uint32_t TR = vc_band_tile_rows(NDS);
     constexpr uint32_t TBB = vc_band_block_bytes(NDS), TLB = vc_band_tile_bytes(NDS);
     uint32_t t_rin = TR, t_off = 0u - TBB;                     // row inside the current block, byte offset of the block (scalars)
+    uint32_t b_rin = 0;                                        // row-major layout: rows left in the current band block (vc_band_row_start)
     unsigned long long t_mask = 0;                             // lanes of the block's band
     uint32_t t_lane = 0;                                       // my byte offset inside a block: (lane - first band lane) * TLB
     const uint32_t lane_tlb = (uint32_t)lane * TLB;
@@ -1593,13 +1604,15 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
             // whole row: always without the band; with it only where a later row reads the row back (VC_RF_FULL)
             if (!band || (r0 & (VC_RF_FULL << 8))) put(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + srow + loff));
             if (band) {
-                if (t_rin == TR) {                        // next row block: its band, once per TR rows, on the scalar side
-                    t_rin = 0; t_off += TBB;
-                    // vc_band_start(i + TR / 2, band_ql) in scalar arithmetic (row and slope are uniform; the product stays below 2^23, so
-                    // the plain multiply equals the 24-bit one the backtrack uses).  As vector code -- v_mul_u32_u24, a clamped subtract,
-                    // a minimum, v_readfirstlane and a full-rate-quarter v_mul_lo_u32 for the lane offset -- this was 5 of a row's ~59
-                    // vector instructions
-                    const uint32_t bt_ = ((i + TR / 2u) * band_ql) >> 16;
+                bool newblock = t_rin == TR;             // tiled layout (development): a block of TR rows shares a band
+                if (newblock) { t_rin = 0; t_off += TBB; }
+                if (!VC_BAND_TILED) { newblock = b_rin == 0; if (newblock) b_rin = VC_BAND_ROWS; b_rin--; }      // row-major: the band moves every VC_BAND_ROWS rows
+                if (newblock) {                           // next row block: its band, on the scalar side
+                    // vc_band_start of the block's middle row in scalar arithmetic (row and slope are uniform; the product stays below 2^23,
+                    // so the plain multiply equals the 24-bit one the backtrack uses).  As vector code, once per row -- v_mul_u32_u24, a
+                    // clamped subtract, a minimum, v_readfirstlane and a quarter-rate v_mul_lo_u32 for the lane offset -- this was 5 of a
+                    // row's ~59 vector instructions
+                    const uint32_t bt_ = ((i + (VC_BAND_TILED ? TR / 2u : VC_BAND_ROWS / 2u)) * band_ql) >> 16;
                     // (in assembly: left to itself the compiler clamps with v_med3_u32 / a saturating v_sub -- only the vector ALU has those --
                     // and multiplies the lane offset with a quarter-rate v_mad_u64_u32)
                     constexpr uint32_t BLO = VC_BAND_LANES / 2 - 1, BHI = BLO + 64u - VC_BAND_LANES;
@@ -2321,7 +2334,7 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
         if (band) {
             const uint32_t tb = vc_band_tile_of_row(r - 1, tile_rows, tile_magic), rin = r - 1 - tb * tile_rows;
-            const uint32_t bl = lc - vc_band_block_start(tb, tile_rows, band_ql);
+            const uint32_t bl = lc - (VC_BAND_TILED ? vc_band_block_start(tb, tile_rows, band_ql) : vc_band_row_start(r - 1, band_ql));
             if (bl >= (uint32_t)VC_BAND_LANES) { oob = true; return 0; }
             return vc_packed_cell(bm32 + tb * blk_dw + bl * tile_dw + rin * nds, cc, cpl);
         }

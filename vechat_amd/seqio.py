@@ -94,6 +94,14 @@ class Overlap:
             setattr(self, k, v)
 
 
+def _check_spans(fmt, q_begin, q_end, q_length, t_begin, t_end):
+    """What both readers refuse (vc_io.cpp: parse_overlap_lines has the same test): coordinates out of order or beyond 32 bits.
+    The reference's Overlap constructors do not look (src/overlap.cpp:14-110); such a record would only surface much later."""
+    if not (0 <= q_begin <= q_end and 0 <= t_begin <= t_end and max(q_end, q_length, t_end) < (1 << 32)):
+        raise ValueError(f"malformed {fmt} record: coordinates out of order or beyond 32 bits "
+                         f"(query {q_begin}..{q_end} of {q_length}, target {t_begin}..{t_end})")
+
+
 def _sam_overlap(q_name, flag, t_name, pos, cigar):
     if flag & 0x4:
         return None
@@ -124,6 +132,7 @@ def _sam_overlap(q_name, flag, t_name, pos, cigar):
     t_begin = pos - 1
     t_end = t_begin + t_aln
     length = max(q_aln, t_aln)
+    _check_spans("SAM", q_begin, q_end, q_length, t_begin, t_end)
     return Overlap(q_name=q_name, t_name=t_name, strand=strand, q_begin=q_begin, q_end=q_end, q_length=q_length,
                    t_begin=t_begin, t_end=t_end, cigar=cigar.decode(), length=length,
                    error=1 - min(q_aln, t_aln) / float(length) if length else 1.0)
@@ -151,6 +160,7 @@ def read_paf(path):
             c = ln.rstrip(b"\n").split(b"\t")
             qb, qe, tb, te = int(c[2]), int(c[3]), int(c[7]), int(c[8])
             cg = [x[5:] for x in c[12:] if x.startswith(b"cg:Z:")]
+            _check_spans("PAF", qb, qe, int(c[1]), tb, te)
             length = max(qe - qb, te - tb)
             out.append(Overlap(q_name=c[0].decode(), t_name=c[5].decode(), strand=c[4] == b"-", q_begin=qb, q_end=qe,
                                q_length=int(c[1]), t_begin=tb, t_end=te, cigar=cg[0].decode() if cg else None, length=length,
@@ -168,6 +178,9 @@ def read_mhap(path):
             if not c:
                 continue
             a_rc, ab, ae, al, b_rc, bb, be = int(c[4]), int(c[5]), int(c[6]), int(c[7]), int(c[8]), int(c[9]), int(c[10])
+            _check_spans("MHAP", ab, ae, al, bb, be)
+            if int(c[0]) < 1 or int(c[1]) < 1:
+                raise ValueError("malformed MHAP record: sequence ids start at 1")
             length = max(ae - ab, be - bb)
             out.append(Overlap(q_name=f"#{int(c[0]) - 1}", t_name=f"#{int(c[1]) - 1}", strand=bool(a_rc ^ b_rc), q_begin=ab, q_end=ae,
                                q_length=al, t_begin=bb, t_end=be, cigar=None, length=length,
