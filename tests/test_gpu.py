@@ -487,6 +487,19 @@ def test_sequences_beyond_2048_columns_and_int32_scores(built):
         st = _check(c, big, f"3 kb windows mode{mode}")
         assert c.stats()["cells"] == st.cells
         c.close()
+    # (round 5: the classes of 32+ columns per lane build a row's profile on the fly, which needs A / C / G / T only and mismatch - gap
+    # == -1, VcFwdArgs::lean; the same windows with an N in one read, and with other scores, take k_fwd_wide -- same bytes, same cells)
+    wins3 = [big.window(w) for w in range(2)]
+    seqs3, quals3, b3, e3 = wins3[1]
+    seqs3 = list(seqs3); seqs3[2] = seqs3[2][:700] + b"N" + seqs3[2][701:]
+    with_n = capi.Batch.from_windows([wins3[0], (seqs3, quals3, b3, e3)], [int(big.win_fasta[0]), int(big.win_fasta[1])], presorted=True)
+    c = HipContext(device=0)
+    st = _check(c, with_n, "3 kb windows with an N")
+    assert c.stats()["cells"] == st.cells
+    c.close()
+    c = HipContext(device=0, match=3, mismatch=-6, gap=-4)
+    _check(c, big.slice(0, 2), "3 kb windows, mismatch - gap != -1")
+    c.close()
     good = capi.synth_batch(capi.synth_cfg(81, 120, 6), 0, 3)
     wins = [good.window(w) for w in range(3)]
     seqs, quals, b, e = good.window(1)

@@ -52,6 +52,10 @@ constexpr int kRing = VC_RING;      // build phase: DP rows kept in LDS per alig
 #define VC_KEPT 6
 #endif
 constexpr int kKept = VC_KEPT;      // build phase: slots of the kept-row ring (0: plain ring of kRing rows); see vc_frec_kept
+// Batches whose widest class has 32 or more columns per lane: a ring slot is 6 - 8 KB there, six of them left 3 waves on a CU.  Half the
+// slots (the row builders hand out as many as the batch says, Batch::kept / ring / ring_pruned): six waves per CU at 64 columns per lane,
+// eight at 48; the rows that no longer find their predecessor in the ring read it back from the stored matrix.
+constexpr int kKeptWide = 3, kRingWide = 4, kRingPrunedWide = 2;
 constexpr int kRingPruned = VC_RING_PRUNED;   // re-alignment rounds and the final alignment: a pruned graph is nearly a chain, four rows hold
                                               // its non-adjacent predecessors, and the smaller ring lets a fifth / sixth wave onto each SIMD
 constexpr int kMaxStreams = 16;
@@ -118,8 +122,10 @@ struct Batch {
     uint32_t max_layers = 0, max_len = 0, max_backbone = 0;
     uint32_t cpl = 0, cpl_min = 0;       // width classes of this batch's sequences (kernel selection)
     uint32_t kept = 0;                   // slots of the build phase's kept-row ring for this batch (0: plain ring); needs 15-bit row distances
+    uint32_t ring = VC_RING, ring_pruned = VC_RING_PRUNED;   // rows of the plain ring (build phase without the kept-row ring / pruned graphs)
     bool packed = false;                 // stored DP rows of this batch: byte-packed (both score sets within the byte bound at the widest class) or raw
     bool band = false;                   // banded matrix store (vc_band_start): packed rows, row builders that mark the rows read back, cooperative backtrack
+    uint32_t lean = 0;                   // VcFwdArgs::lean: the widest classes' on-the-fly profile is usable for global (bit 0) / local (bit 1) alignments
     uint32_t cw_run = 0, n_streams = 1;  // chunk size and chunk streams of this batch
     // ---- run state (guarded by vc_ctx::qmu while queued)
     bool queued = false;                 // on the run queue: its chunks are being handed to the stream workers
@@ -494,17 +500,18 @@ void flush_events(vc_ctx* c) {
 // nwonly: every alignment of the launch is global (mode 0 always; a re-alignment launch whose layers are all full-span)
 template <int CA, int CB>
 void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs, bool packed, bool nwonly) {
+    constexpr int KR = CB >= 32 ? kKeptWide : (kKept ? kKept : 1), PR = CB >= 32 ? kRingWide : kRing, QR = CB >= 32 ? kRingPrunedWide : kRingPruned;
     if (a.mode == 0 && a.kept) {
-        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, (kKept ? kKept : 1), true, true, true>), dim3(jobs), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_fwd<CA, CB, (kKept ? kKept : 1), false, true, true>), dim3(jobs), dim3(64), 0, st, a);
+        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, KR, true, true, true>), dim3(jobs), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_fwd<CA, CB, KR, false, true, true>), dim3(jobs), dim3(64), 0, st, a);
     } else if (a.mode == 0) {
-        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, kRing, true, false, true>), dim3(jobs), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_fwd<CA, CB, kRing, false, false, true>), dim3(jobs), dim3(64), 0, st, a);
+        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, PR, true, false, true>), dim3(jobs), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_fwd<CA, CB, PR, false, false, true>), dim3(jobs), dim3(64), 0, st, a);
     } else if (nwonly && packed) {
-        hipLaunchKernelGGL((k_fwd<CA, CB, kRingPruned, true, false, true>), dim3(jobs), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((k_fwd<CA, CB, QR, true, false, true>), dim3(jobs), dim3(64), 0, st, a);
     } else {
-        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, kRingPruned, true, false, false>), dim3(jobs), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_fwd<CA, CB, kRingPruned, false, false, false>), dim3(jobs), dim3(64), 0, st, a);
+        if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, QR, true, false, false>), dim3(jobs), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_fwd<CA, CB, QR, false, false, false>), dim3(jobs), dim3(64), 0, st, a);
     }
 }
 
@@ -641,6 +648,7 @@ struct Plan {
         fa.stat = c->d_stat; fa.wcols = c->wcols; fa.kept = bt->kept;
         fa.bmat = wk.d_bmat; fa.band_par = wk.d_band_par; fa.band = bt->band ? 1 : 0; fa.redo_list = nullptr; fa.redo_n = nullptr;
         fa.fold = 0;                  // (launch_fwd decides)
+        fa.lean = bt->lean;
         return fa;
     }
     VcTraceArgs trace_args(const Work& wk) const {
@@ -698,7 +706,7 @@ struct Plan {
             (void)hipMemsetAsync(wk.gr[gi].n_edges, 0, (size_t)ns * 4, wk.stream);   // (fewer than three sequences) included
         }
         { Timer t(c, KC_AVG, wk.stream); hipLaunchKernelGGL(k_avg, dim3(ns), dim3(64), 0, wk.stream, bt->b, w0, ns); }
-        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), bt->kept ? vc_kept_lds_bytes(NC) : 0, wk.stream, bt->b, wk.gr[0], wk.dp, w0, ns, NC, EC, (uint32_t)kRing, bt->kept, wk.d_cur_layer); }
+        { Timer t(c, KC_INIT, wk.stream); hipLaunchKernelGGL(k_init, dim3(ns), dim3(64), bt->kept ? vc_kept_lds_bytes(NC) : 0, wk.stream, bt->b, wk.gr[0], wk.dp, w0, ns, NC, EC, bt->ring, bt->kept, wk.d_cur_layer); }
     }
 
     // One round of the build loop (window.cpp:239-298) for every window of the chunk.  Every window is at a layer of its own
@@ -719,7 +727,7 @@ struct Plan {
         if (any_partial) {
             Timer t(c, KC_ROWS, wk.stream);
             const uint32_t sub_lds = std::max(8 * ((NC + 63) / 64) + 2 * NC + ((NC + 15) & ~15u) + 4 * (NC / 32 + 1) + 64, bt->kept ? vc_kept_lds_bytes(NC) : 0u);
-            hipLaunchKernelGGL(k_rows_sub, dim3(ns), dim3(64), sub_lds, wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, (uint32_t)kRing, wk.d_submask, bt->kept,
+            hipLaunchKernelGGL(k_rows_sub, dim3(ns), dim3(64), sub_lds, wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, (int)j, bt->ring, wk.d_submask, bt->kept,
                                (const uint32_t*)wk.d_cur_layer);
         }
         VcFwdArgs fa = fwd_args(wk);
@@ -744,7 +752,7 @@ struct Plan {
         if (inline_redo && (rc = redo(wk, fa, ta, ns, NC))) return rc;
         VcAddArgs aa{};
         aa.b = bt->b; aa.g = wk.gr[wk.cur]; aa.dp = wk.dp; aa.w0 = wk.w0; aa.nslots = ns; aa.NC = NC; aa.EC = EC; aa.layer = j;
-        aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16; aa.ring = (uint32_t)kRing;
+        aa.pairs = wk.d_pairs; aa.npairs = wk.d_npairs; aa.PC = PC; aa.scratch = wk.d_scratch16; aa.ring = bt->ring;
         aa.make_rows = !(c->dbg_stop_kind == 1 && c->dbg_stop_index == j); aa.kept = bt->kept;
         aa.tie_n = wk.d_tie_n; aa.redo_n = wk.d_redo_n; aa.cursor = wk.d_cur_layer;
         { Timer t(c, KC_ADDALN, wk.stream); hipLaunchKernelGGL(k_addaln, dim3(ns), dim3(64), add_lds, wk.stream, aa); }
@@ -880,7 +888,7 @@ struct Plan {
             bool tw = topo_lds_bytes(NCt, ECt, c->STK, c->MA) > kLdsCap;
             if (c->topo_hbm && c->big_ws_stride >= topo_lds_bytes(NCl, ECl, c->STK, c->MA)) { tw = true; NCt = NCl; ECt = ECl; }
             for (uint32_t rep = 0; rep < ((c->dup & 8u) ? 2u : 1u); ++rep) { Timer t(c, KC_TOPO, wk.stream);
-              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tw ? 0 : topo_lds_bytes(NCt, ECt, c->STK, c->MA), wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRingPruned, NCt, ECt,
+              hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), tw ? 0 : topo_lds_bytes(NCt, ECt, c->STK, c->MA), wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, bt->ring_pruned, NCt, ECt,
                                  (tw || c->big_ws_topo) ? wk.d_big_ws : nullptr, c->big_ws_stride, tw ? 1 : 0); }
         }
         if (more) {
@@ -931,7 +939,7 @@ struct Plan {
     int linear_tail(Work& wk) {
         const uint32_t ns = wk.ns;
         { Timer t(c, KC_TOPO, wk.stream);
-          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds > kLdsCap ? 0 : topo_lds, wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, (uint32_t)kRingPruned, NC, EC,
+          hipLaunchKernelGGL(k_topo, dim3(ns), dim3(64), topo_lds > kLdsCap ? 0 : topo_lds, wk.stream, bt->b, wk.gr[wk.cur], wk.dp, wk.w0, ns, NC, EC, c->STK, -1, 0, bt->ring_pruned, NC, EC,
                              topo_lds > kLdsCap ? wk.d_big_ws : nullptr, c->big_ws_stride, topo_lds > kLdsCap ? 1 : 0); }
         VcConsArgs ca{};
         ca.b = bt->b; ca.g = wk.gr[wk.cur]; ca.dp = wk.dp; ca.w0 = wk.w0; ca.nslots = ns; ca.NC = NC; ca.EC = EC;
@@ -1318,6 +1326,13 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         uint32_t distinct = 0;
         for (int k = 0; k < 8; ++k) distinct += (uint32_t)__builtin_popcount(hm[k]);
         if (distinct > 5) MA = (distinct - 1 + 1) & ~1u;
+        // A / C / G / T only?  Then the widest classes may build their profiles on the fly (VcFwdArgs::lean) where mismatch - gap == -1
+        uint32_t other[8];
+        for (int k = 0; k < 8; ++k) other[k] = hm[k];
+        for (unsigned char ch : {'A', 'C', 'G', 'T'}) other[ch >> 5] &= ~(1u << (ch & 31));
+        bool pure = true;
+        for (int k = 0; k < 8; ++k) pure = pure && other[k] == 0;
+        bt->lean = (pure && c->prm.mismatch - c->prm.gap == -1 ? 1u : 0u) | (pure && c->prm.sw_mismatch - c->prm.sw_gap == -1 ? 2u : 0u);
     }
 
     // capacities
@@ -1378,6 +1393,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     bool maybe_wide = ws_max_len > kMaxColumns || (have_ws && c->wcols);
     if (!vc_int16_ok(c->prm.match, c->prm.mismatch, c->prm.gap, NC, cpl, true) ||
         !vc_int16_ok(c->prm.sw_match, c->prm.sw_mismatch, c->prm.sw_gap, NC, cpl, false)) maybe_wide = true;
+    if (cpl >= 32 && bt->lean != 3u) maybe_wide = true;       // classes of 32+ columns per lane exist in the lean form only: other alphabets / scores take k_fwd_wide
     const uint32_t wcols = maybe_wide ? ((ws_max_len + 64 * VC_WIDE_CPL - 1) / (64 * VC_WIDE_CPL)) * (64 * VC_WIDE_CPL) : 0;
     // whole rows, + a quarter for the band where rows are byte-packed (raw int16 rows -- wide classes, unusual scores -- have no band)
     const uint64_t per_job = NC * rowd * (bt->packed ? 5 : 4) + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
@@ -1423,7 +1439,9 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         c->have_ws = true;
     }
     b.cons_cap = NC;
-    bt->kept = (kKept && NC < 32768 && !getenv("VC_PLAIN_RING")) ? (uint32_t)kKept : 0u;
+    const bool wide_cls = bt->cpl >= 32;                 // (launch_fwd_t instantiates the forward kernel with the same numbers)
+    bt->kept = (kKept && NC < 32768 && !getenv("VC_PLAIN_RING")) ? (uint32_t)(wide_cls ? kKeptWide : kKept) : 0u;
+    bt->ring = (uint32_t)(wide_cls ? kRingWide : kRing); bt->ring_pruned = (uint32_t)(wide_cls ? kRingPrunedWide : kRingPruned);
     bt->band = bt->packed && bt->kept && c->trace_wave && !getenv("VC_NO_BAND");
     if ((rc = salloc(c, bt, 12, &b.cons, (size_t)nw * b.cons_cap))) return rc;
     HIPCHK(c, hipMemsetAsync(b.status, 0, nw, c->stream));

@@ -1244,6 +1244,10 @@ struct VcFwdArgs {
     const uint32_t* redo_list;     // != nullptr: this launch re-runs the listed jobs with whole rows (the backtrack left the band)
     const uint32_t* redo_n;
     uint32_t fold;                 // 1: the launch is built for the two widest classes of the batch and takes every narrower sequence in the lower one
+    uint32_t lean;                 // classes of 32+ columns per lane build the row's match / mismatch profile on the fly (v_perm_b32 through a 4-entry table)
+                                   //   instead of holding four profiles in 4 x CPL / 2 registers: possible when the batch holds A / C / G / T only and
+                                   //   mismatch - gap == -1 (the selector's 0xFF constant).  bit 0: global alignments may, bit 1: local ones; otherwise
+                                   //   such sequences go to k_fwd_wide
     const uint32_t* cursor;        // build phase, != nullptr: [nslots] the layer every window is at (bits 0..15) and, in bit 31, "its last backtrack
                                    //   left the band: this layer again, with whole rows" (see Plan::build_layer); k0 is then unused
 #ifdef VC_LAB
@@ -1391,7 +1395,8 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     // below also relies on negative mismatch / gap scores (cells past the sequence end can then never strictly exceed the best
     // real cell).
     {
-        const bool ok = vc_int16_ok(m, n, g, nrows, CPL, nw) && len <= 64u * CPL && len > 0 && nrows > 0 && !(a.dp.flags[slot] & 1u);
+        const bool ok = vc_int16_ok(m, n, g, nrows, CPL, nw) && len <= 64u * CPL && len > 0 && nrows > 0 && !(a.dp.flags[slot] & 1u) &&
+                        (CPL < 32 || ((a.lean >> (nw ? 0 : 1)) & 1u));                 // (the widest classes exist in the lean form only)
         if (!ok) {
             // outside the packed-int16 envelope: not an error -- the job keeps type 255 and k_fwd_wide (int32 lanes, any
             // length, like the reference's fallback to 32-bit lanes, simd impl:699-706) takes it
@@ -1410,16 +1415,30 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
 
     // tilted match/mismatch profile (score - g) of my columns for the four usual bases (packed pairs);
     // other row bytes are compared on the fly.  Columns beyond the sequence end never match.
-    uint32_t pfA[ND], pfC[ND], pfG[ND], pfT[ND], sbp[ND];
+    // LEAN (32 and more columns per lane): four profiles would be 4 x ND registers -- 279 to 380 VGPRs with up to 156 spilled, one wave per
+    // SIMD.  Instead one selector per register pair: byte pairs (2c, 2c + 1) pick entry c of a four-entry int16 table {A, C, G, T} that the
+    // row sets up on the scalar side (entry = m - g for the row's base, n - g for the others); columns past the sequence end take the
+    // selector's constant 0xFF = -1, which is n - g for the scores this form is used with (VcFwdArgs::lean).  One v_perm_b32 more per
+    // register pair and row, a quarter of the registers.
+    constexpr bool LEAN = CPL >= 32;
+    uint32_t pfA[LEAN ? 1 : ND], pfC[LEAN ? 1 : ND], pfG[LEAN ? 1 : ND], pfT[LEAN ? 1 : ND], sbp[LEAN ? 1 : ND], sel[LEAN ? ND : 1];
     const int mt = m - g, nt = n - g;
 #pragma unroll
     for (int q = 0; q < ND; ++q) {
         const uint32_t i0 = lane * CPL + 2 * q, i1 = i0 + 1;
         const uint32_t b0 = i0 < len ? a.b.bases[so + i0] : 0xFFu;
         const uint32_t b1 = i1 < len ? a.b.bases[so + i1] : 0xFFu;
-        sbp[q] = b0 | (b1 << 16);
-        auto sc = [&](uint32_t x) { return ((uint32_t)((b0 == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)((b1 == x) ? mt : nt) << 16); };
-        pfA[q] = sc('A'); pfC[q] = sc('C'); pfG[q] = sc('G'); pfT[q] = sc('T');
+        if constexpr (LEAN) {
+            auto pick = [](uint32_t b) -> uint32_t {
+                const uint32_t c2 = b == 'A' ? 0u : b == 'C' ? 2u : b == 'G' ? 4u : b == 'T' ? 6u : 0xFFu;
+                return c2 == 0xFFu ? 0x0D0Du : (c2 | ((c2 + 1u) << 8));
+            };
+            sel[q] = pick(b0) | (pick(b1) << 16);
+        } else {
+            sbp[q] = b0 | (b1 << 16);
+            auto sc = [&](uint32_t x) { return ((uint32_t)((b0 == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)((b1 == x) ? mt : nt) << 16); };
+            pfA[q] = sc('A'); pfC[q] = sc('C'); pfG[q] = sc('G'); pfT[q] = sc('T');
+        }
     }
     const uint32_t gg = pk_dup(g);
     uint32_t njg[ND];                         // -(j*g) of my columns: the tilted image of H == 0 (SW floor, SW row 0)
@@ -1495,6 +1514,14 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
 #pragma unroll
         for (int q = 0; q < ND; ++q) P[q] = __builtin_amdgcn_alignbit(acc[q], q == 0 ? left : acc[q - 1], 16);
         const uint32_t bi = (r0 >> 24) & 7u;
+        if constexpr (LEAN) {
+            // the row's table on the scalar side: entries A, C in the low dword, G, T in the high one (a row byte outside A/C/G/T cannot
+            // occur in a batch that passed VcFwdArgs::lean; it would score as a mismatch everywhere)
+            const uint32_t x = (uint32_t)(mt ^ nt) & 0xFFFFu, nt2 = pk_dup(nt);
+            const uint32_t lo = nt2 ^ (bi == 0 ? x : bi == 1 ? x << 16 : 0u), hi = nt2 ^ (bi == 2 ? x : bi == 3 ? x << 16 : 0u);
+#pragma unroll
+            for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], __builtin_amdgcn_perm(hi, lo, sel[q]));
+        } else
         if (bi < 2) {
             if (bi == 0) {
 #pragma unroll
