@@ -159,9 +159,17 @@ def e2e_rate(batch, device, reps=1):
     library's stream workers go from the last chunk of one batch straight to the first of the next.
     Returns (windows/s, consensus bytes by window)."""
     n = batch.n_windows
-    cuts = [0, min(E2E_FIRST, n)]
-    while cuts[-1] < n:
-        cuts.append(min(cuts[-1] + E2E_BATCH, n))
+    # batch sizes are the caller's choice: a small first batch (the device starts after 0.5 GB of H2D, not 1.1 GB), the odd remainder
+    # next -- it runs beside full batches -- and full batches to the end, so that the last windows drain on all chunk streams
+    sizes = [min(E2E_FIRST, n)]
+    rem = (n - sizes[0]) % E2E_BATCH
+    if rem:
+        sizes.append(rem)
+    sizes += [E2E_BATCH] * ((n - sum(sizes)) // E2E_BATCH)
+    cuts = [0]
+    for k in sizes:
+        cuts.append(cuts[-1] + k)
+    assert cuts[-1] == n
     parts = [batch.slice(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
     ctx = HipContext(device=device)
     out = [None] * len(parts)
@@ -176,7 +184,7 @@ def e2e_rate(batch, device, reps=1):
         return time.perf_counter() - t0
 
     # first use allocates the workspaces and both batch slots (seconds): not part of the rate
-    ctx.submit(parts[min(1, len(parts) - 1)]); ctx.run(); ctx.submit(parts[0]); ctx.run(); ctx.collect(); ctx.collect()
+    ctx.submit(parts[-1]); ctx.run(); ctx.submit(parts[0]); ctx.run(); ctx.collect(); ctx.collect()
     dt = min(once() for _ in range(reps))
     ctx.close()
     cons = [x for p in out for x in p[0]]

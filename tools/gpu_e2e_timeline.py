@@ -10,12 +10,17 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 bsz = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 first = int(sys.argv[3]) if len(sys.argv) > 3 else bsz
 b = capi.synth_batch(capi.synth_cfg(1002, 500, 64), 0, n)
-cuts = [0, min(first, n)]
-while cuts[-1] < n:
-    cuts.append(min(cuts[-1] + bsz, n))
+sizes = [min(first, n)]
+rem = (n - sizes[0]) % bsz
+if rem:
+    sizes.append(rem)                      # the odd remainder early (it runs beside full batches), full batches to the end
+sizes += [bsz] * ((n - sum(sizes)) // bsz)
+cuts = [0]
+for k in sizes:
+    cuts.append(cuts[-1] + k)
 parts = [b.slice(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
 ctx = HipContext(device=0)
-ctx.submit(parts[-2 if len(parts) > 1 else 0]); ctx.run(); ctx.submit(parts[0]); ctx.run(); ctx.collect(); ctx.collect()
+ctx.submit(parts[-1]); ctx.run(); ctx.submit(parts[0]); ctx.run(); ctx.collect(); ctx.collect()
 for rep in range(2):
     ev = []
     t0 = time.perf_counter()
