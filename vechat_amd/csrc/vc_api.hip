@@ -1284,7 +1284,9 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     bt->have = false; bt->ran = false; bt->collected = false;
     uint32_t want_streams = c->n_streams;
-    if (c->auto_streams) want_streams = nw >= kAutoStreamsFrom ? kAutoStreamsMany : kAutoStreamsFew;
+    // (a context whose workspaces already serve the larger number keeps it for medium batches: in a stream of batches queued behind each
+    // other a batch of 8 192 windows runs beside its neighbours, and on four streams it would leave the other four to them alone)
+    if (c->auto_streams) want_streams = (nw >= kAutoStreamsFrom || (c->have_ws && c->n_streams == kAutoStreamsMany && nw >= 8192)) ? kAutoStreamsMany : kAutoStreamsFew;
     VcBatchDev& b = bt->b;
     b = VcBatchDev{};
     b.n_windows = nw;
