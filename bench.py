@@ -13,7 +13,7 @@ per step, config D's shape).
 
 The one JSON line also carries
   value_e2e   the same windows from host memory to host memory (vc_submit -> vc_run -> vc_collect, H2D and D2H
-              included), batches of 16 384 windows queued behind each other in one context -- SURVEY 8(d)'s definition
+              included), batches of 32 768 windows queued behind each other in one context -- SURVEY 8(d)'s definition
               of the metric; `value` is the resident-input rate the driver's contract asks for
   roofline    the bound that holds: VALU issue.  VALU wave-instructions of a step (rocprofv3 PMC counts per window, profiles/
               r4_hbm_traffic.json, refused when taken for other kernel sources than the ones built here) / step wall time / SIMDs,
@@ -44,7 +44,7 @@ from vechat_amd.shard import gather_consensus
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_CELL = 4.0           # one int16 score store + one load by a successor row
-E2E_BATCH = 16384
+E2E_BATCH = 32768            # windows per host batch of the host-to-host pass (16 384: 34.5 k, 25 088: 34.6 k, 32 768: 35.4 k windows/s on one box, profiles/r5_e2e_timeline.txt)
 E2E_FIRST = 8192             # the first batch of the host-to-host pass is smaller: the device starts after 0.5 GB of H2D instead of 1.1 GB
 
 
