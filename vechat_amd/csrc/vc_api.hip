@@ -379,6 +379,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
     if ((rc = dalloc(c, c->chunk_allocs, &wk->dp.nrows, CW)) || (rc = dalloc(c, c->chunk_allocs, &wk->dp.flags, CW)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rec, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.frec, CW * NC)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->dp.fie, CW * (NC + 4))) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
@@ -1388,7 +1389,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint64_t budget_default = budget;
     if (c->arena) budget = (c->arena_bytes - std::min<size_t>(c->arena_bytes, 1u << 20)) / S;      // vc_reserve: the arena IS the budget (less the padding between its pieces)
     const uint64_t rowd = 64ull * (bt->packed ? (uint64_t)vc_nds((int)cpl) : cpl / 2);      // dwords per stored row: byte-packed (NDS per lane) or raw int16 pairs
-    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6 + 16) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2) + EC * 2ull + 32) +
+    const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6 + 16) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2 + 1) + EC * 2ull + 36) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
     // Can any alignment of this batch leave the packed-int16 kernel's envelope (vc_fwd_body's check, vc_int16_ok, on the worst
     // case the capacities allow)?  Then k_fwd_wide and its int32 matrices are needed.

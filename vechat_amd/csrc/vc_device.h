@@ -58,6 +58,9 @@ struct VcDp {
     uint32_t* flags;      // [CW] bit0: outside the kernel envelope; bit1: rows follow VcGraph::ord, not the reference's rank
     uint4*    rec;        // [CW*NC]
     uint4*    frec;       // [CW*NC] the forward kernel's view of the same row (see vc_make_frec)
+    uint8_t*  fie;        // [CW*(NC+4)] by ROW NUMBER (1-based; entry 0 = the virtual row = 0): distance to the row of the first in-edge when it is
+                          //   1..15 and the list is inline, else 0 -- what the backtrack's speculation table holds (4 bits per row in LDS).  Written
+                          //   beside `rec` by the row builders, so that a backtrack wave loads 1 byte per row instead of the 16-byte record
     uint16_t* rank2node;  // [CW*NC]
     uint16_t* ovf;        // [CW*EC]
 };

@@ -93,6 +93,13 @@ __device__ __forceinline__ bool vc_full_span(uint32_t begin, uint32_t end, uint3
     return begin < offset && end > L - offset;              // window.cpp:253-254
 }
 
+// the backtrack's first-in-edge entry of a row record (VcDp::fie)
+__device__ __forceinline__ uint8_t vc_fie_entry(uint32_t rec_x, uint32_t rec_y) {
+    const uint32_t d0 = rec_y & 0xFFFFu;
+    return (uint8_t)((((rec_x >> 8) & VC_RF_OVF) || d0 > 15u) ? 0u : d0);
+}
+#define VC_FIE_STRIDE(NC) ((NC) + 4u)
+
 // The forward kernel's view of a row (16 B): byte0 code, byte1 flags, byte2 number of listed predecessors,
 // byte3 base index (0..3 = ACGT, 4 = other), then up to 6 x u16 row distances of the predecessors OTHER than
 // the row directly above (that one is flagged VC_RF_PREV and taken from registers).  The order of the
@@ -488,6 +495,8 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             dp.rec[nb + r] = rec;
+            dp.fie[(uint64_t)slot * VC_FIE_STRIDE(NC) + r + 1] = vc_fie_entry(rec.x, rec.y);
+            if (r == 0) dp.fie[(uint64_t)slot * VC_FIE_STRIDE(NC)] = 0;
             dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl, is_ovf, hasprev, r, ring);
         }
         ovf_base += tot_ovf;
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, u
 // list beyond VC_INLINE_PRED entries is walked through the in-edge chain into VcDp::ovf (rare).
 struct VcOtf {
     const uint16_t* ord; const uint16_t* pos; const uint4* nrec; const uint16_t* out_first; const uint16_t* in_first; const uint32_t* e_tn;
-    uint4* rec; uint4* frec; uint16_t* rank2node; uint16_t* ovf;
+    uint4* rec; uint4* frec; uint16_t* rank2node; uint16_t* ovf; uint8_t* fie;
     uint32_t N, EC;
 };
 template <int U>
@@ -617,6 +626,8 @@ __device__ __forceinline__ void vc_otf_rows(const VcOtf& o, uint32_t r0, uint32_
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             o.rec[r[u]] = rec;
+            o.fie[r[u] + 1] = vc_fie_entry(rec.x, rec.y);
+            if (r[u] == 0) o.fie[0] = 0;
             o.rank2node[r[u]] = (uint16_t)v[u];
             if (plain_frec) o.frec[r[u]] = vc_make_frec(code, fl, npu, dl, is_ovf, hasprev, r[u], ring);
         }
@@ -770,7 +781,7 @@ __device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph&
     const uint64_t nb = (uint64_t)slot * NC, eb = (uint64_t)slot * EC;
     VcOtf ot;
     ot.ord = g.ord + nb; ot.pos = g.pos + nb; ot.nrec = g.nrec + nb; ot.out_first = g.out_first + nb; ot.in_first = g.in_first + nb;
-    ot.e_tn = g.e_tn + eb; ot.rec = dp.rec + nb; ot.frec = dp.frec + nb; ot.rank2node = dp.rank2node + nb; ot.ovf = dp.ovf + eb;
+    ot.e_tn = g.e_tn + eb; ot.rec = dp.rec + nb; ot.frec = dp.frec + nb; ot.rank2node = dp.rank2node + nb; ot.ovf = dp.ovf + eb; ot.fie = dp.fie + (uint64_t)slot * VC_FIE_STRIDE(NC);
     ot.N = N; ot.EC = EC;
     uint32_t ovf_base = 0;
     int bad = 0;
@@ -943,6 +954,8 @@ __device__ __forceinline__ void vc_rows_sub_body(const VcBatchDev& b, const VcGr
             rec.z = dl[2] | ((uint32_t)dl[3] << 16);
             rec.w = dl[4] | ((uint32_t)dl[5] << 16);
             dp.rec[nb + r] = rec;
+            dp.fie[(uint64_t)slot * VC_FIE_STRIDE(NC) + r + 1] = vc_fie_entry(rec.x, rec.y);
+            if (r == 0) dp.fie[(uint64_t)slot * VC_FIE_STRIDE(NC)] = 0;
             dp.frec[nb + r] = vc_make_frec(rec.x & 0xFF, fl, np, dl, is_ovf, hasprev, r, ring);
             dp.rank2node[nb + r] = (uint16_t)v;
         }
@@ -2389,35 +2402,37 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
         const uint32_t nr = (uint32_t)__shfl((int)nrows, src, 64);
         const uint32_t nb_lo = (uint32_t)__shfl((int)(uint32_t)nb, src, 64), nb_hi = (uint32_t)__shfl((int)(uint32_t)(nb >> 32), src, 64);
         const uint64_t nbs = ((uint64_t)nb_hi << 32) | nb_lo;
-        // lane k packs the entries of rows 2k and 2k + 1 (row numbers; row 0 is the virtual row)
-        auto entry = [&](uint32_t rr) __attribute__((always_inline)) -> uint32_t {
-            if (rr == 0 || rr > nr) return 0u;
-            const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nbs + rr - 1]);
-            const uint32_t d0 = q.y & 0xFFFF;
-            return (((q.x >> 8) & VC_RF_OVF) || d0 > 15) ? 0u : d0;
+        // lane k packs the entries of rows 2k and 2k + 1 (row numbers; row 0 is the virtual row): one 16-bit load of the rows' entries
+        // (VcDp::fie, written beside the row records) -- the 16-byte records themselves used to be read here, a quarter of the bytes the
+        // backtrack fetched
+        const uint8_t* fie = a.dp.fie + (uint64_t)(uint32_t)__shfl((int)slot, src, 64) * VC_FIE_STRIDE(a.NC);
+        (void)nbs;
+        auto pair = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t {
+            if (2 * k > nr) return 0u;
+            const uint32_t v = *reinterpret_cast<const uint16_t*>(fie + 2 * k);
+            return (v & 0xFu) | ((2 * k + 1 <= nr ? (v >> 8) & 0xFu : 0u) << 4);
         };
-        // (two blocks of entries per pass: four record loads in flight per lane instead of two on a chain)
+        // (two blocks of entries per pass: loads in flight per lane instead of a chain)
         for (uint32_t k0 = lane; 2 * k0 <= nr; k0 += 2 * TG * TL) {
             const uint32_t k1 = k0 + TG * TL;
-            const uint32_t e0 = entry(2 * k0), e1 = entry(2 * k0 + 1), e2 = entry(2 * k1), e3 = entry(2 * k1 + 1);
-            tab[k0] = (uint8_t)(e0 | (e1 << 4));
-            if (2 * k1 <= nr) tab[k1] = (uint8_t)(e2 | (e3 << 4));
+            const uint32_t p0 = pair(k0), p1 = pair(k1);
+            tab[k0] = (uint8_t)p0;
+            if (2 * k1 <= nr) tab[k1] = (uint8_t)p1;
         }
     } else {
-        auto entry = [&](uint32_t rr) __attribute__((always_inline)) -> uint32_t {
-            if (rr == 0 || rr > nrows) return 0u;
-            const uint2 q = *reinterpret_cast<const uint2*>(&a.dp.rec[nb + rr - 1]);
-            const uint32_t d0 = q.y & 0xFFFF;
-            return (((q.x >> 8) & VC_RF_OVF) || d0 > 15) ? 0u : d0;
+        const uint8_t* fie = a.dp.fie + (uint64_t)slot * VC_FIE_STRIDE(a.NC);
+        auto pair = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t {
+            if (2 * k > nrows) return 0u;
+            const uint32_t v = *reinterpret_cast<const uint16_t*>(fie + 2 * k);
+            return (v & 0xFu) | ((2 * k + 1 <= nrows ? (v >> 8) & 0xFu : 0u) << 4);
         };
-        // (four blocks of entries per pass: eight record loads in flight per lane -- the table of a 2 200-row graph was 70 dependent
-        // round trips per alignment, a sixth of a backtrack round)
+        // (four blocks of entries per pass: the loads of a pass are in flight together)
         for (uint32_t k0 = gl; walking && 2 * k0 <= nrows; k0 += 4 * TL) {
-            uint32_t e[8];
+            uint32_t e[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) { const uint32_t k2 = k0 + u * TL; e[2 * u] = entry(2 * k2); e[2 * u + 1] = entry(2 * k2 + 1); }
+            for (uint32_t u = 0; u < 4; ++u) e[u] = pair(k0 + u * TL);
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) { const uint32_t k2 = k0 + u * TL; if (2 * k2 <= nrows) tab[k2] = (uint8_t)(e[2 * u] | (e[2 * u + 1] << 4)); }
+            for (uint32_t u = 0; u < 4; ++u) { const uint32_t k2 = k0 + u * TL; if (2 * k2 <= nrows) tab[k2] = (uint8_t)e[u]; }
         }
     }
     __syncthreads();
