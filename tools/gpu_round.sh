@@ -28,4 +28,11 @@ timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $
 cd /tmp
 rm -rf /tmp/prof_stats
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --no-cpu --no-extras > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
-f=$(grep -l k_fwd $(find /tmp/prof_stats -name "*kernel_stats.csv") | head -1); cp "$f" $O/kernel_stats.csv; head -12 $O/kernel_stats.csv      # (the calibration binary the bench starts writes a stats file of its own)
+f=$(grep -l k_fwd $(find /tmp/prof_stats -name "*kernel_stats.csv") /dev/null < /dev/null | head -1); cp "$f" $O/kernel_stats.csv; head -12 $O/kernel_stats.csv      # (the calibration binary the bench starts writes a stats file of its own)
+# the same bench with the process pinned to two cores (an 8-rank node leaves each rank about two): stream workers and the host side must not need more
+cd $R
+{ echo "# python bench.py --no-cpu --no-extras --steps 3: all host cores, then taskset -c 0-1"
+  for pin in "" "taskset -c 0-1"; do
+    timeout 600 $pin python bench.py --no-cpu --no-extras --steps 3 2> /dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-16s value %.0f windows/s  value_e2e %s  ms_per_step %.1f' % ('${pin:-all cores}', j['value'], j.get('value_e2e'), j['ms_per_step']))"
+  done; } > $O/two_core_bench.txt 2>&1 < /dev/null
+cat $O/two_core_bench.txt

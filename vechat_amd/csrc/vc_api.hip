@@ -33,6 +33,8 @@
 #include "vc_kernels.h"
 #include "vc_pipe.h"
 
+extern "C" __attribute__((visibility("hidden"))) int vc_launch_fwdn(uint32_t cpl, uint32_t ns_w, uint32_t grid, void* stream, const VcFwdArgs* a);
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -56,7 +58,8 @@ constexpr int kKept = VC_KEPT;      // build phase: slots of the kept-row ring (
 // slots (the row builders hand out as many as the batch says, Batch::kept / ring / ring_pruned): six waves per CU at 64 columns per lane,
 // eight at 48; the rows that no longer find their predecessor in the ring read it back from the stored matrix.
 constexpr int kKeptWide = 3, kRingWide = 4, kRingPrunedWide = 2;
-constexpr int kRingPruned = VC_RING_PRUNED;   // re-alignment rounds and the final alignment: a pruned graph is nearly a chain, four rows hold
+constexpr int kRingPruned = VC_RING_PRUNED;
+static_assert(VC_RING_PRUNED == VC_RING_PRUNED_N, "vc_fwdn.hip instantiates k_fwdn with the pruned graphs' ring");   // re-alignment rounds and the final alignment: a pruned graph is nearly a chain, four rows hold
                                               // its non-adjacent predecessors, and the smaller ring lets a fifth / sixth wave onto each SIMD
 constexpr int kMaxStreams = 16;
 constexpr uint32_t kAutoStreamsMany = 8, kAutoStreamsFew = 4, kAutoStreamsFrom = 12288;   // windows from which a batch runs on the larger number of chunk streams
@@ -181,6 +184,8 @@ struct vc_ctx {
     uint32_t trace_tl = 8;        // lanes per alignment of the lock-step k_tracew (development: VC_TRACE_TL=16)
     bool fold = true;             // launch_fwd: more than two width classes in one launch (development: VC_NO_FOLD=1 launches once per class)
     uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
+    uint32_t multi = 1;           // re-alignment rounds: sequences of a window per forward wave.  1 (default): one, as in the build phase; VC_MULTI=2 / 4:
+                                  // k_fwdn -- bit-identical, and 5 % / 16 % slower on the job at config C (NOTES.md, round 5), so it stays an experiment
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};      // the process's chunk streams of this device (pooled_stream): not owned
     hipStream_t own_stream = nullptr;        // this context's stream for copies, fills and small kernels
@@ -540,6 +545,17 @@ int launch_fwd(vc_ctx* c, const Batch* bt, hipStream_t st, const VcFwdArgs& a0, 
     // more than two classes (partial-span layers: pieces of reads of any length): one launch built for the two widest ones, every
     // narrower sequence in the lower of them -- four launches per layer, each waiting for its slowest alignment, become one
     if (hi - lo > 1 && c->fold) { lo = hi - 1; a.fold = 1; }
+    // re-alignment rounds whose alignments are all global: several sequences of a window per wave (k_fwdn), every one in the widest class
+    if (a.all_hi && c->multi > 1 && !a.redo_list && jobs == a.nslots * a.group) {
+        bool done;
+        { Timer t(c, KC_FWD, st);
+          const uint32_t ns_w = c->multi;
+          const uint32_t grid = a.nslots * ((a.group + ns_w - 1u) / ns_w);
+          done = vc_launch_fwdn(opts[hi], ns_w, grid, (void*)st, &a) == 0;          // (vc_fwdn.hip: a translation unit of its own)
+        }
+        if (done) { wide(); return VC_OK; }
+        return fail(c, VC_ERR_STATE, "k_fwdn: no instantiation for %u columns per lane", opts[hi]);
+    }
     if (hi - lo == 1) {
         { Timer t(c, KC_FWD, st);
         switch (hi) {
@@ -922,6 +938,22 @@ struct Plan {
             if (bt->band) HIPCHK(c, hipMemsetAsync(wk.d_redo_n, 0, 4, wk.stream));
             bool nwonly = true;                                // no partial-span layer among these sequences in any window of the batch?
             for (uint32_t k = std::max(k0, 1u); k < k0 + gsz; ++k) nwonly = nwonly && !(k < bt->h_layer_partial.size() && bt->h_layer_partial[k]);
+            // all global, byte-packed rows, one or two adjacent classes of the usual widths: several sequences of a window per forward wave
+            // (k_fwdn), every sequence in the batch's widest class -- the backtrack and the redo pass then read / write the rows in that class
+            bool multi = false;
+            {
+                const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
+                int lo = -1, hi = -1;
+                for (int i = 0; i < 11; ++i) { if (opts[i] == bt->cpl_min) lo = i; if (opts[i] == bt->cpl) hi = i; }
+#ifdef VC_FAST_BUILD
+                const bool built = bt->cpl == 8 || bt->cpl == 10;
+#else
+                const bool built = bt->cpl == 6 || bt->cpl == 8 || bt->cpl == 10 || bt->cpl == 12;
+#endif
+                multi = nwonly && bt->packed && (c->multi > 1 || getenv("VC_ALL_HI")) && lo >= 0 && hi - lo <= 1 && built && gsz >= 2;      // (VC_ALL_HI: development -- the class forcing without k_fwdn)
+            }
+            fa.all_hi = multi ? 1u : 0u;
+            ta.cpl_lo = multi ? bt->cpl : fold_lo(c, bt);
             int rc = launch_fwd(c, bt, wk.stream, fa, ns * gsz, &wk, nwonly);
             if (rc) return rc;
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
@@ -1071,6 +1103,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     c->fold = getenv("VC_NO_FOLD") == nullptr;
+    if (const char* d = getenv("VC_MULTI")) { const int v = std::atoi(d); c->multi = v == 4 ? 4u : v == 2 ? 2u : 1u; }
     if (const char* d = getenv("VC_TRACE_TL")) c->trace_tl = std::atoi(d) == 16 ? 16u : 8u;
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack

@@ -18,10 +18,18 @@
 //   k_consensus     wave / window          graph.cpp:450-638 GenerateConsensus (+ window.cpp:141-171 trim), racon-linear overload
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
 #include "vc_device.h"
 #include "vechat_hip.h"
 
 #define VC_INT_MIN (-2147483647 - 1)
+// linkage of the kernels: external in vc_api.hip; `static` in a second translation unit that includes this header for a few templates only
+// (vc_fwdn.hip), so that the host stubs of the non-template kernels are not defined twice
+#ifndef VC_KL
+#define VC_KL
+#endif
+#define VC_RING_PRUNED_N 4     // rows of the plain ring on pruned graphs (vc_api.hip: VC_RING_PRUNED; vc_fwdn.hip instantiates k_fwdn with it)
 // The latency-bound single-lane kernels of one chunk run next to the throughput-bound k_fwd of another
 // chunk (separate streams).  The CU issues the oldest ready wave first, which starves them; raising the
 // wave priority lets their few instructions through at once and costs k_fwd almost nothing.
@@ -148,7 +156,7 @@ __device__ __forceinline__ uint4 vc_make_frec(uint32_t code, uint32_t fl, uint32
 // in rank order, window.cpp:225-236,283,292-296), so the ORDER of the additions is kept; what is parallel is
 // only the fetch: 64 lanes load 64 qualities and their table values at once, then every lane performs the
 // same 64 dependent additions on values broadcast with v_readlane.
-__global__ __launch_bounds__(64) void k_avg(VcBatchDev b, uint32_t w0, uint32_t nw) {
+VC_KL __global__ __launch_bounds__(64) void k_avg(VcBatchDev b, uint32_t w0, uint32_t nw) {
     VC_LATENCY_KERNEL_PRIO();
     const uint32_t t = blockIdx.x;
     if (t >= nw) return;
@@ -186,7 +194,7 @@ __device__ __forceinline__ void vc_rows_full(const VcBatchDev& b, const VcGraph&
 // ------------------------------------------------------------------------------------------------
 // k_init: backbone chain graph (AddAlignment with an empty alignment, graph.cpp:207-212)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+VC_KL __global__ __launch_bounds__(64) void k_init(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                              uint32_t NC, uint32_t EC, uint32_t ring, uint32_t kept, uint32_t* cursor) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];          // kept != 0: vc_kept_lds_bytes(NC)
     uint32_t slot = blockIdx.x;
@@ -367,7 +375,7 @@ __device__ int vc_topo_dfs(const VcTopoLds& ls, uint32_t N, uint32_t STK, bool m
     return err;
 }
 
-__global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+VC_KL __global__ __launch_bounds__(64) void k_topo(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                              uint32_t NC, uint32_t EC, uint32_t STK, int next_layer, int only_masked, uint32_t ring,
                                              uint32_t NCl, uint32_t ECl, uint8_t* ws, uint32_t ws_stride, int ws_only) {
     // ws != nullptr: the graph image does not fit the 160 KB LDS; work from this workgroup's HBM workspace
@@ -976,7 +984,7 @@ __device__ __forceinline__ void vc_rows_sub_body(const VcBatchDev& b, const VcGr
     }
 }
 
-__global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+VC_KL __global__ __launch_bounds__(64) void k_rows_sub(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                                  uint32_t NC, uint32_t EC, int next_layer, uint32_t ring, uint32_t* submask, uint32_t kept,
                                                  const uint32_t* cursor) {
     VC_LATENCY_KERNEL_PRIO();
@@ -1151,7 +1159,7 @@ __device__ void vc_resolve_one(uint8_t* smem, uint8_t* gws, uint32_t slot, const
 #ifndef VC_RESOLVE_OCC
 #define VC_RESOLVE_OCC __attribute__((amdgpu_waves_per_eu(7, 8)))
 #endif
-__global__ __launch_bounds__(64) VC_RESOLVE_OCC void k_resolve(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
+VC_KL __global__ __launch_bounds__(64) VC_RESOLVE_OCC void k_resolve(VcBatchDev b, VcGraph g, VcDp dp, uint32_t w0, uint32_t nslots,
                                                 uint32_t NC, uint32_t EC, uint32_t STK,
                                                 const uint16_t* tie_rows, const uint32_t* tie_cnt, const uint32_t* tie_over, uint32_t tie_over_stride, uint32_t* job_end,
                                                 const uint32_t* tie_list, const uint32_t* tie_n,
@@ -1257,6 +1265,8 @@ struct VcFwdArgs {
     const uint32_t* redo_list;     // != nullptr: this launch re-runs the listed jobs with whole rows (the backtrack left the band)
     const uint32_t* redo_n;
     uint32_t fold;                 // 1: the launch is built for the two widest classes of the batch and takes every narrower sequence in the lower one
+    uint32_t all_hi;               // 1: every sequence of the launch runs in the launch's widest class (k_fwdn and its redo pass; the backtrack reads the
+                                   //   rows in that class: VcTraceArgs::cpl_lo)
     uint32_t lean;                 // classes of 32+ columns per lane build the row's match / mismatch profile on the fly (v_perm_b32 through a 4-entry table)
                                    //   instead of holding four profiles in 4 x CPL / 2 registers: possible when the batch holds A / C / G / T only and
                                    //   mismatch - gap == -1 (the selector's 0xFF constant).  bit 0: global alignments may, bit 1: local ones; otherwise
@@ -1390,7 +1400,7 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     // than two classes -- is built for the two widest classes of a batch and takes everything narrower in the lower of them: a lane
     // simply owns more columns than the sequence needs, the matrix is the same -- its backtrack reads the rows in the same class,
     // VcTraceArgs::cpl_lo.)
-    if ((PIPE || a.fold) ? len > 64u * CPL : vc_cpl_for(len) != (uint32_t)CPL) return VC_FWD_NONE;
+    if ((PIPE || a.fold || a.all_hi) ? len > 64u * CPL : vc_cpl_for(len) != (uint32_t)CPL) return VC_FWD_NONE;
     const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
     // NW or SW is fixed per instantiation (the caller looked at the layer, window.cpp:336-349): the row loop
     // then carries no alignment-type branches
@@ -1665,10 +1675,12 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
                 // the band lanes store under their own exec mask (all 64 lanes are active here: one wave, uniform control flow);
                 // the store is not visible to the compiler's vmcnt bookkeeping, which only makes its waits longer, never shorter
                 const char* bp = brow0 + t_off + t_rin * (NDS * 4u);
+                // (the s_nop: gfx950 wants two wait states between a store of more than 64 bits and a VALU write of its data registers; the
+                // compiler's hazard pass cannot see a store inside an asm block, and the instruction after it may well be the next row's pack)
                 if (NDS == 3) {
                     typedef uint32_t vc_u3 __attribute__((ext_vector_type(3)));
                     const vc_u3 d = {wv[0], wv[1], wv[2]};
-                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx3 %1, %2, %3\n\ts_mov_b64 exec, -1" :: "s"(t_mask), "v"(t_lane), "v"(d), "s"(bp) : "memory");
+                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx3 %1, %2, %3\n\ts_mov_b64 exec, -1\n\ts_nop 0" :: "s"(t_mask), "v"(t_lane), "v"(d), "s"(bp) : "memory");
                 } else if (NDS == 2) {
                     typedef uint32_t vc_u2 __attribute__((ext_vector_type(2)));
                     const vc_u2 d = {wv[0], wv[1]};
@@ -1676,7 +1688,7 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
                 } else if (NDS == 4) {
                     typedef uint32_t vc_u4 __attribute__((ext_vector_type(4)));
                     const vc_u4 d = {wv[0], wv[1], wv[2], wv[3]};
-                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_mov_b64 exec, -1" :: "s"(t_mask), "v"(t_lane), "v"(d), "s"(bp) : "memory");
+                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_mov_b64 exec, -1\n\ts_nop 0" :: "s"(t_mask), "v"(t_lane), "v"(d), "s"(bp) : "memory");
                 } else {
                     if ((t_mask >> lane) & 1ull) {
                         uint32_t* hr = reinterpret_cast<uint32_t*>(const_cast<char*>(bp) + t_lane);
@@ -1903,7 +1915,7 @@ __device__ __forceinline__ void vc_fwd_any(const VcFwdArgs& a, uint32_t* ring_ra
 #define VC_FWD_OCC            // development: e.g. -DVC_FWD_OCC='__attribute__((amdgpu_waves_per_eu(4,4)))' caps the forward kernel's waves per SIMD
 #endif
 template <int CA, int CB, int RING, bool PACKED, bool KEPT, bool NWONLY>
-__global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
+VC_KL __global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
     __shared__ uint32_t ring_raw[RING * (CB / 2) * 64];
 #ifdef VC_FWD_VGPR_PAD
     asm volatile("; keep the register allocation at 104: four forward waves per SIMD leave LDS and registers to the other kernels" ::: "v103");
@@ -1916,9 +1928,365 @@ __global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
         uint32_t cls = CB;
         if (jb.k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + jb.k + 1] - a.b.seq_off[s0 + jb.k]));
-        if (cls == (uint32_t)CA || (a.fold && cls < (uint32_t)CA)) { vc_fwd_any<CA, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb); return; }
+        if (!a.all_hi && (cls == (uint32_t)CA || (a.fold && cls < (uint32_t)CA))) { vc_fwd_any<CA, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb); return; }
     }
     vc_fwd_any<CB, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb);
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop over sequences whose index is a compile-time constant in every instance.
+// (As `#pragma unroll` loops some of them stayed rolled -- the ones around inline assembly -- and acc[s][q] then lived in scratch memory:
+// ten dwords loaded and stored per DP row.)
+template <class F, int... I>
+__device__ __forceinline__ void vc_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void vc_static_for(F&& f) { vc_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// ------------------------------------------------------------------------------------------------
+// k_fwdn: the re-alignment rounds, NS sequences of a window per wave.  Every sequence of a window is aligned to the same pruned graph
+// (window.cpp:329-372): same rows, same row records, same predecessors, same column 0.  A DP row of k_fwd is ~54 vector and ~50
+// scalar / branch instructions, and the SIMDs issue ~94 % of what they can: the scalar half -- record decode, flag
+// tests, ring slot arithmetic, loop control -- is paid once per row whatever the number of sequences, so a wave that carries NS sequences
+// through the row loop spends it once for all of them, and their independent lane scans fill each other's DPP wait states.  Restates the
+// same recurrence as vc_fwd_body (sisd_alignment_engine.cpp:118-254, 292-360), global alignments on byte-packed rows with the plain ring
+// and the banded store, every sequence in the launch's one width class (VcFwdArgs::all_hi; the backtrack reads the rows in that class,
+// VcTraceArgs::cpl_lo); a group with a sequence that cannot (a window with fewer sequences, one outside the envelope) goes through
+// vc_fwd_body in the same wave, one sequence after the other.
+// MEASURED (round 5, config C, 100 000 windows): bit-identical, and slower on the job -- 34.3 k (NS = 2) / 30.3 k (NS = 4) against 36.0 k
+// windows/s.  The re-alignment rounds are 12 % of the job's kernel time, so the scalar half saved is worth ~3 % at best; the one class for
+// the whole launch costs the 76 % of sequences that fit 512 columns a fifth more vector work; and with half the waves of twice the
+// registers the launch gets a smaller share of a machine it runs on beside the other streams' kernels.  Off by default (VC_MULTI).
+// ------------------------------------------------------------------------------------------------
+template <int CPL, int RING, int NS>
+__device__ __forceinline__ void vc_fwd_multi(const VcFwdArgs& a, uint32_t* ring_raw, const uint32_t slot, const uint32_t job0, const uint32_t k0) {
+    static_assert((RING & (RING - 1)) == 0 && CPL < 32, "plain ring, narrow classes");
+    constexpr int ND = CPL / 2, NDS = vc_nds(CPL);
+    constexpr uint32_t RS = RING * ND * 64;                   // dwords of one sequence's ring
+    const int lane = vc_lane();
+    const uint32_t w = a.w0 + slot;
+    const uint32_t s0 = a.b.win_seq_off[w];
+    const int m = a.m, n = a.n, g = a.g;
+    const uint32_t nrows = a.dp.nrows[slot];
+    const uint64_t nb = (uint64_t)slot * a.NC;
+    uint64_t so[NS]; uint32_t len[NS];
+    uint32_t lensum = 0;
+    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; { so[s] = a.b.seq_off[s0 + k0 + s]; len[s] = (uint32_t)(a.b.seq_off[s0 + k0 + s + 1] - so[s]); lensum += len[s]; } });
+    if (lane == 0) {
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; { a.job_type[job0 + s] = 1; a.tie_cnt[job0 + s] = 0; } });
+        unsigned long long* st = vc_stat_slot(a.stat);
+        atomicAdd(st + 0, (unsigned long long)nrows * lensum);
+        atomicAdd(st + 1, (unsigned long long)NS * nrows);
+    }
+    uint32_t pfA[NS][ND], pfC[NS][ND], pfG[NS][ND], pfT[NS][ND], sbp[NS][ND];
+    const int mt = m - g, nt = n - g;
+    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; {
+#pragma unroll
+        for (int q = 0; q < ND; ++q) {
+            const uint32_t i0 = lane * CPL + 2 * q, i1 = i0 + 1;
+            const uint32_t b0 = i0 < len[s] ? a.b.bases[so[s] + i0] : 0xFFu;
+            const uint32_t b1 = i1 < len[s] ? a.b.bases[so[s] + i1] : 0xFFu;
+            sbp[s][q] = b0 | (b1 << 16);
+            auto sc = [&](uint32_t x) { return ((uint32_t)((b0 == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)((b1 == x) ? mt : nt) << 16); };
+            pfA[s][q] = sc('A'); pfC[s][q] = sc('C'); pfG[s][q] = sc('G'); pfT[s][q] = sc('T');
+        }
+    } });
+    const uint32_t gg = pk_dup(g);
+    uint32_t band_ql[NS], lane_e[NS], c_e[NS];
+    int best[NS];
+    uint32_t best_row[NS];
+    const bool band = a.band != 0;
+    // the matrices, band rows and column 0 of the NS jobs lie one behind the other: job0 + s
+    uint32_t* const hrow00 = a.hmat + (uint64_t)job0 * a.hstride;
+    const uint64_t bstride = vc_band_job_dwords(a.hstride) * 4ull;      // bytes between the band rows of consecutive jobs
+    const char* const brow00 = reinterpret_cast<const char*>(a.bmat) + (uint64_t)job0 * bstride;
+    int16_t* const c0p_out0 = a.c0 + (uint64_t)job0 * a.NC;
+    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; {
+        band_ql[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_slope(len[s], nrows, CPL));
+        if (band && lane == 0) a.band_par[job0 + s] = band_ql[s];
+        lane_e[s] = (len[s] - 1) / CPL; c_e[s] = (len[s] - 1) % CPL;
+        best[s] = VC_INT_MIN; best_row[s] = 0;
+    } });
+    constexpr uint32_t TLB = NDS * 4u, TBB = VC_BAND_LANES * TLB;
+    static_assert(!VC_BAND_TILED, "row-major band rows");
+    uint32_t t_off = 0u - TBB;
+    unsigned long long t_mask[NS];
+    uint32_t t_lane[NS];
+    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; { t_mask[s] = 0; t_lane[s] = 0; } });
+    const uint32_t lane_tlb = (uint32_t)lane * TLB;
+    const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
+    uint32_t far_reads = 0;
+    // (one array per sequence, picked by the compile-time index: as one two-dimensional array the compiler kept the rows in scratch memory)
+    uint32_t acc0[ND], acc1[ND], acc2[ND], acc3[ND];
+#define VC_ACC_S (*(s == 0 ? &acc0 : s == 1 ? &acc1 : s == 2 ? &acc2 : &acc3))
+    int c0prev = 0, c0vec = 0;                                // column 0 depends on the graph only: one copy for all sequences
+    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S;
+#pragma unroll
+        for (int q = 0; q < ND; ++q) acc_s[q] = 0; });
+    uint4 myrec = make_uint4(0, 0, 0, 0), nextrec = make_uint4(0, 0, 0, 0);
+    if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
+    constexpr uint32_t rowdw = NDS * 64;
+    const uint32_t loff = (uint32_t)lane * NDS * 4u;
+    uint32_t srow = 0;
+
+    auto ring_slot_merge = [&](uint32_t rslot, uint32_t c0lane, int& c0m) __attribute__((always_inline)) {
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
+            const uint32_t* rp = ring_raw + s * RS + rslot * (ND * 64) + lane;
+            uint32_t hp[ND];
+#pragma unroll
+            for (int q = 0; q < ND; ++q) hp[q] = rp[q * 64];
+#pragma unroll
+            for (int q = 0; q < ND; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc_s[q]) : "v"(hp[q]));
+        } });
+        c0m = max(c0m, __builtin_amdgcn_readlane(c0vec, c0lane));
+    };
+    auto row_tail = [&](const uint32_t r0, const int c0m, const uint32_t i, const uint32_t ri) __attribute__((always_inline)) {
+        const uint32_t bi = (r0 >> 24) & 7u;
+        const int col0 = c0m + g;
+        uint32_t P[NS][ND];
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
+            const uint32_t left = (uint32_t)VC_DPP_SHR((int)acc_s[ND - 1], (int)((uint32_t)c0m << 16), 0x138, 0xF);
+#pragma unroll
+            for (int q = 0; q < ND; ++q) P[s][q] = __builtin_amdgcn_alignbit(acc_s[q], q == 0 ? left : acc_s[q - 1], 16);
+        } });
+        if (bi < 2) {
+            if (bi == 0) {
+                vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value;
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) P[s][q] = pk_add(P[s][q], pfA[s][q]); });
+            } else {
+                vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value;
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) P[s][q] = pk_add(P[s][q], pfC[s][q]); });
+            }
+        } else if (bi == 2) {
+            vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value;
+#pragma unroll
+                for (int q = 0; q < ND; ++q) P[s][q] = pk_add(P[s][q], pfG[s][q]); });
+        } else if (bi == 3) {
+            vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value;
+#pragma unroll
+                for (int q = 0; q < ND; ++q) P[s][q] = pk_add(P[s][q], pfT[s][q]); });
+        } else {
+            const uint32_t x = r0 & 0xFF;
+            vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value;
+#pragma unroll
+                for (int q = 0; q < ND; ++q)
+                    P[s][q] = pk_add(P[s][q], ((uint32_t)(((sbp[s][q] & 0xFFFFu) == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)(((sbp[s][q] >> 16) == x) ? mt : nt) << 16)); });
+        }
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) P[s][q] = pk_max(P[s][q], pk_add(acc_s[q], gg));
+            P[s][0] = pk_max_hi_with_lo(P[s][0]);
+#pragma unroll
+            for (int q = 1; q < ND; ++q) P[s][q] = pk_max_bcast_hi(pk_max_hi_with_lo(P[s][q]), P[s][q - 1]);
+        } });
+        // the lane scans of the sequences are independent: their DPP steps alternate, each filling the others' wait states
+        int sc[NS];
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = (int)P[s][ND - 1]; });
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x111, 0xF)); });
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x112, 0xF)); });
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x114, 0xF)); });
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x118, 0xF)); });
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x142, 0xA)); });
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x143, 0xC)); });
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
+            int carry = VC_DPP_SHR(sc[s], VC_INT_MIN, 0x138, 0xF);
+            carry = max(carry, (int)((uint32_t)col0 << 16));
+#pragma unroll
+            for (int q = 0; q < ND; ++q) acc_s[q] = pk_max_bcast_hi(P[s][q], (uint32_t)carry);
+        } });
+        // end cell (sisd :353-355): the first sink row with the best score
+        if (r0 & (VC_RF_SINK << 8)) {
+            vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
+                uint32_t hv = acc_s[0];
+#pragma unroll
+                for (int q = 1; q < ND; ++q) {               // (the copy through an empty asm keeps this a chain of selects: as plain code it was folded into one load at a
+                    uint32_t t = acc_s[q];                   //  run-time index, which put the whole row array into scratch memory)
+                    asm("" : "+v"(t));
+                    hv = (c_e[s] / 2 == (uint32_t)q) ? t : hv;
+                }
+                int v = (c_e[s] & 1) ? pk_hi(hv) : pk_lo(hv);
+                v = __builtin_amdgcn_readlane(v, lane_e[s]);
+                if (v > best[s]) { best[s] = v; best_row[s] = i; }
+            } });
+        }
+        c0prev = col0;
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(c0vec) : "s"(col0), "s"(ri) : "m0");
+        __builtin_amdgcn_wave_barrier();
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
+            uint32_t* wp = ring_raw + s * RS + (i & (RING - 1)) * (ND * 64) + lane;
+#pragma unroll
+            for (int q = 0; q < ND; ++q) wp[q * 64] = acc_s[q];
+        } });
+        // (from the row number, not from a counter carried round the loop: as a carried value the compiler took it for lane-dependent)
+        const bool newblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)((i - 1u) & (uint32_t)(VC_BAND_ROWS - 1))) == 0u;
+        t_off += TBB;
+        // (one instance per sequence with a compile-time index: as a loop the compiler left this part rolled -- it holds inline assembly --
+        // and then indexes acc / t_mask / t_lane at run time, i.e. keeps them in scratch memory)
+        auto store_seq = [&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            uint32_t (&acc_s)[ND] = VC_ACC_S;
+            uint32_t wv[NDS];
+            vc_pack_row<ND, NDS>(acc_s, wv);
+            if (!band || (r0 & (VC_RF_FULL << 8))) {
+                uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow00 + (uint64_t)s * a.hstride) + srow + loff);
+                if (NDS == 2) *reinterpret_cast<uint2*>(hr) = make_uint2(wv[0], wv[1]);
+                else if (NDS == 4) *reinterpret_cast<uint4*>(hr) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                else if (NDS == 3) { struct __attribute__((packed, aligned(4))) u3 { uint32_t a, b, c; }; *reinterpret_cast<u3*>(hr) = u3{wv[0], wv[1], wv[2]}; }
+                else {
+#pragma unroll
+                    for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
+                }
+            }
+            if (band) {
+                if (newblock) {
+                    const uint32_t bt_ = ((i + VC_BAND_ROWS / 2u) * band_ql[s]) >> 16;
+                    constexpr uint32_t BLO = VC_BAND_LANES / 2 - 1, BHI = BLO + 64u - VC_BAND_LANES;
+                    uint32_t bs, bso;
+                    asm("s_max_u32 %0, %2, %3\n\ts_min_u32 %0, %0, %4\n\ts_sub_u32 %0, %0, %3\n\ts_mul_i32 %1, %0, %5"
+                        : "=&s"(bs), "=s"(bso) : "s"(bt_), "n"(BLO), "n"(BHI), "n"(TLB) : "scc");
+                    t_mask[s] = (unsigned long long)((1u << VC_BAND_LANES) - 1u) << bs;
+                    t_lane[s] = lane_tlb - bso;
+                }
+                const char* bp = brow00 + (uint64_t)s * bstride + t_off;
+                // (the exec mask of the store below must BE a scalar whatever the compiler thinks of it: an "s" operand is taken as it stands)
+                const unsigned long long tm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_mask[s] >> 32)) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t_mask[s]);
+                if (NDS == 3) {
+                    typedef uint32_t vc_u3 __attribute__((ext_vector_type(3)));
+                    const vc_u3 d = {wv[0], wv[1], wv[2]};
+                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx3 %1, %2, %3\n\ts_mov_b64 exec, -1\n\ts_nop 0" :: "s"(tm), "v"(t_lane[s]), "v"(d), "s"(bp) : "memory");
+                } else if (NDS == 2) {
+                    typedef uint32_t vc_u2 __attribute__((ext_vector_type(2)));
+                    const vc_u2 d = {wv[0], wv[1]};
+                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %1, %2, %3\n\ts_mov_b64 exec, -1" :: "s"(tm), "v"(t_lane[s]), "v"(d), "s"(bp) : "memory");
+                } else if (NDS == 4) {
+                    typedef uint32_t vc_u4 __attribute__((ext_vector_type(4)));
+                    const vc_u4 d = {wv[0], wv[1], wv[2], wv[3]};
+                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_mov_b64 exec, -1\n\ts_nop 0" :: "s"(tm), "v"(t_lane[s]), "v"(d), "s"(bp) : "memory");
+                } else {
+                    if ((t_mask[s] >> lane) & 1ull) {
+                        uint32_t* hr = reinterpret_cast<uint32_t*>(const_cast<char*>(bp) + t_lane[s]);
+#pragma unroll
+                        for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
+                    }
+                }
+            }
+        };
+        store_seq(std::integral_constant<int, 0>{});
+        if constexpr (NS > 1) store_seq(std::integral_constant<int, 1>{});
+        if constexpr (NS > 2) store_seq(std::integral_constant<int, 2>{});
+        if constexpr (NS > 3) store_seq(std::integral_constant<int, 3>{});
+        srow += rowdw * 4u;
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (uint32_t i0 = 1; i0 <= nrows; i0 += 64) {
+        myrec = nextrec;
+        {
+            const uint32_t r = i0 - 1 + 64 + lane;
+            if (r < nrows) nextrec = a.dp.frec[nb + r];
+        }
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, nrows - i0 + 1));
+        for (uint32_t ri = 0; ri < cnt; ++ri) {
+            const uint32_t i = i0 + ri;
+            const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
+            int c0m = c0prev;
+            if (!(r0 & (VC_RF_PLAIN << 8))) {
+                if (!(r0 & (VC_RF_PREV << 8))) {
+                    c0m = VC_INT_MIN;
+                    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S;
+#pragma unroll
+                        for (int q = 0; q < ND; ++q) asm volatile("v_mov_b32 %0, %1" : "+v"(acc_s[q]) : "s"(0x80008000u)); });
+                }
+                const uint32_t fl = (r0 >> 8) & 0xFF, nq = (r0 >> 16) & 0xFF;
+                const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
+                const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
+                const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
+                const uint32_t nlist = (fl & VC_RF_OVF) ? r2 : nq;
+                for (uint32_t p = 0; p < nlist; ++p) {
+                    uint32_t delta;
+                    if (fl & VC_RF_OVF) {
+                        delta = ovfp[r1 + p];
+                        if ((fl & VC_RF_PREV) && delta == 1) continue;
+                    } else {
+                        const uint32_t wsel = p < 2 ? r1 : (p < 4 ? r2 : r3);
+                        delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
+                    }
+                    const uint32_t pr = i - delta;
+                    if (pr == 0) {                                             // the virtual row: H[0][j] = j*g, column 0: 0
+                        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S;
+#pragma unroll
+                            for (int q = 0; q < ND; ++q) { const uint32_t z = 0u; asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc_s[q]) : "v"(z)); } });
+                        c0m = max(c0m, 0);
+                    } else if (delta <= (uint32_t)RING) {
+                        ring_slot_merge((i - delta) & (RING - 1), (i - delta - 1u) & 63u, c0m);
+                    } else {
+                        __threadfence_block();                                  // my own earlier stores must have landed
+                        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
+                            const uint32_t* hr = hrow00 + (uint64_t)s * a.hstride + (uint64_t)(pr - 1) * (NDS * 64) + lane * NDS;
+                            uint32_t wv[NDS], hA[ND];
+#pragma unroll
+                            for (int t = 0; t < NDS; ++t) wv[t] = hr[t];
+                            vc_unpack_row<ND, NDS>(wv, hA);
+#pragma unroll
+                            for (int q = 0; q < ND; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc_s[q]) : "v"(hA[q]));
+                        } });
+                        far_reads += NS;
+                        int cA;
+                        if (delta <= 64) cA = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
+                        else cA = (int)__builtin_amdgcn_readfirstlane((int)c0p_out0[pr - 1]);
+                        c0m = max(c0m, cA);
+                    }
+                }
+            }
+            row_tail(r0, c0m, i, ri);
+        }
+        if ((uint32_t)lane < cnt) {
+            vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; c0p_out0[(uint64_t)s * a.NC + i0 - 1 + lane] = (int16_t)c0vec; });
+        }
+        __threadfence_block();
+    }
+    if (lane == 0 && far_reads) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
+    if (lane == 0) {
+        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; a.job_end[job0 + s] = (best_row[s] << 16) | len[s]; });
+    }
+}
+#undef VC_ACC_S
+
+// can sequence k of window slot take the multi-sequence body of class CPL?  (what vc_fwd_body's prologue asks, for a global alignment)
+template <int CPL>
+__device__ __forceinline__ bool vc_fwd_multi_ok(const VcFwdArgs& a, uint32_t slot, uint32_t k) {
+    const uint32_t w = a.w0 + slot;
+    if (a.b.status[w] != VC_WIN_OK) return false;
+    const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
+    if (k >= ns) return false;
+    const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k + 1] - a.b.seq_off[s0 + k]);
+    const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
+    if (!(k == 0 || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L))) return false;
+    const uint32_t nrows = a.dp.nrows[slot];
+    return len > 0 && len <= 64u * CPL && nrows > 0 && !(a.dp.flags[slot] & 1u) && vc_int16_ok(a.m, a.n, a.g, nrows, CPL, true);
+}
+
+// wave p of a window takes its sequences k0 + NS p ... k0 + NS p + NS - 1, all in width class CPL (VcFwdArgs::all_hi)
+template <int CPL, int RING, int NS>
+VC_KL __global__ __launch_bounds__(64) void k_fwdn(VcFwdArgs a) {
+    __shared__ uint32_t ring_raw[NS * RING * (CPL / 2) * 64];
+    const uint32_t hp = (a.group + NS - 1u) / NS;
+    const uint32_t slot = blockIdx.x / hp, p = blockIdx.x % hp;
+    if (slot >= a.nslots) return;
+    const uint32_t job0 = slot * a.group + NS * p, k0 = a.k0 + NS * p;
+    const uint32_t have = min((uint32_t)NS, a.group - NS * p);           // sequences of the launch this wave is responsible for
+    bool all = have == (uint32_t)NS;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) all = all && vc_fwd_multi_ok<CPL>(a, slot, k0 + s);
+    if (all) { vc_fwd_multi<CPL, RING, NS>(a, ring_raw, slot, job0, k0); return; }
+    // one after the other, exactly as k_fwd would have run them
+#pragma unroll 1
+    for (uint32_t s = 0; s < have; ++s) {
+        VcJob jb; jb.job = job0 + s; jb.slot = slot; jb.k = k0 + s; jb.redo = false;
+        __syncthreads();
+        vc_fwd_any<CPL, RING, true, false, true>(a, ring_raw, jb);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1933,7 +2301,7 @@ __global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
 #define VC_WIDE_CPL 8
 #define VC_WIDE_RING 8          // rows of the current tile kept in LDS (16 KB per wave; this kernel never fills a CU)
 #define VC_WIDE_NEG (-(1 << 29))
-__global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_t wstride, uint32_t wcols, int* c0w) {
+VC_KL __global__ __launch_bounds__(64) void k_fwd_wide(VcFwdArgs a, int* wmat, uint64_t wstride, uint32_t wcols, int* c0w) {
     // the last VC_WIDE_RING rows of the tile in LDS (slot = row % VC_WIDE_RING): the predecessors that are not the row directly
     // above are nearly always among them, and a read back from the stored matrix costs a fence and a memory round trip
     __shared__ int wring[VC_WIDE_RING][VC_WIDE_CPL][64];
@@ -2182,7 +2550,7 @@ struct VcTraceArgs {
 // stream (wave-per-alignment and LDS-tiled variants were measured slower end to end: they take issue
 // slots and CUs away from k_fwd).  Loads stop at the first matching move, like the reference's scan.
 #define VC_TRACE_LANES 8     // alignments per wave: lanes walk in lockstep, so fewer per wave = less waiting on the slowest
-__global__ void k_trace(VcTraceArgs a) {
+VC_KL __global__ void k_trace(VcTraceArgs a) {
     VC_LATENCY_KERNEL_PRIO();
     if (threadIdx.x >= VC_TRACE_LANES) return;
     const uint32_t job = blockIdx.x * VC_TRACE_LANES + threadIdx.x;
@@ -2602,7 +2970,7 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
 }
 
 template <int TL>
-__global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
+VC_KL __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int TG = 64 / TL;
@@ -3009,7 +3377,7 @@ __device__ __forceinline__ bool vc_addaln_body(const VcAddArgs& a, uint8_t* smem
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
+VC_KL __global__ __launch_bounds__(64) void k_addaln(VcAddArgs a) {
     VC_LATENCY_KERNEL_PRIO();
     // every reader of the layer's counters (k_resolve, the redo pass) is an earlier kernel of this stream; a memset per counter
     // per layer was 2 000 tiny launches per step, each waiting ~100 us for a slot beside k_fwd
@@ -3044,7 +3412,7 @@ __host__ __device__ inline uint32_t vc_prune_lds_bytes(uint32_t NC, uint32_t EC)
     return ((2 * (NC + 1) + 15) & ~15u) + 4 * EC + 2 * NC + 2 * NC + ((EC + 15) & ~15u) + 8 * NC + 64;
 }
 
-__global__ __launch_bounds__(64) void k_prune_lcc(VcPruneArgs a) {
+VC_KL __global__ __launch_bounds__(64) void k_prune_lcc(VcPruneArgs a) {
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t slot = blockIdx.x;
@@ -3231,7 +3599,7 @@ struct VcAddwArgs {
     const uint32_t* pairs; const uint32_t* npairs; uint32_t PC; uint32_t pair_group;
 };
 
-__global__ __launch_bounds__(64) void k_addw(VcAddwArgs a) {
+VC_KL __global__ __launch_bounds__(64) void k_addw(VcAddwArgs a) {
     VC_LATENCY_KERNEL_PRIO();
     const uint32_t slot = blockIdx.x;
     if (slot >= a.nslots) return;
@@ -3279,7 +3647,7 @@ struct VcFinishArgs {
     const uint32_t* pairs; const uint32_t* npairs; uint32_t PC;
 };
 
-__global__ __launch_bounds__(64) void k_finish(VcFinishArgs a) {
+VC_KL __global__ __launch_bounds__(64) void k_finish(VcFinishArgs a) {
     VC_LATENCY_KERNEL_PRIO();
     const uint32_t slot = blockIdx.x;
     if (slot >= a.nslots) return;
@@ -3327,7 +3695,7 @@ struct VcConsArgs {
 
 __host__ __device__ inline uint32_t vc_cons_lds_bytes(uint32_t NC, uint32_t EC) { return 12 * NC + 12 * EC + 8 * NC + 128; }
 
-__global__ __launch_bounds__(64) void k_consensus(VcConsArgs a) {
+VC_KL __global__ __launch_bounds__(64) void k_consensus(VcConsArgs a) {
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t slot = blockIdx.x;
@@ -3437,7 +3805,7 @@ __global__ __launch_bounds__(64) void k_consensus(VcConsArgs a) {
 }
 
 // which byte values occur in the batch (256-bit mask): sizes the aligned lists (VcGraph::ma)
-__global__ void k_byte_presence(const uint8_t* bases, uint64_t n, uint32_t* mask) {
+VC_KL __global__ void k_byte_presence(const uint8_t* bases, uint64_t n, uint32_t* mask) {
     __shared__ uint32_t s_m[8];
     if (threadIdx.x < 8) s_m[threadIdx.x] = 0;
     __syncthreads();
@@ -3461,14 +3829,14 @@ __global__ void k_byte_presence(const uint8_t* bases, uint64_t n, uint32_t* mask
     if (threadIdx.x < 8 && s_m[threadIdx.x]) atomicOr(&mask[threadIdx.x], s_m[threadIdx.x]);
 }
 
-__global__ void k_max_u32(const uint32_t* v, uint32_t n, uint32_t* out) {
+VC_KL __global__ void k_max_u32(const uint32_t* v, uint32_t n, uint32_t* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) atomicMax(out, v[i]);
 }
 
 // build phase with a layer cursor per window: how many layers the slowest window of the chunk still has to go (windows that had
 // to repeat a layer with whole rows are behind the launch count)
-__global__ void k_lag(VcBatchDev b, const uint32_t* cursor, uint32_t w0, uint32_t nslots, uint32_t* out) {
+VC_KL __global__ void k_lag(VcBatchDev b, const uint32_t* cursor, uint32_t w0, uint32_t nslots, uint32_t* out) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t lag = 0;
     if (slot < nslots) {
@@ -3480,7 +3848,7 @@ __global__ void k_lag(VcBatchDev b, const uint32_t* cursor, uint32_t w0, uint32_
 }
 
 // compacts the per-window consensus slots into one contiguous buffer (offsets from an exclusive scan)
-__global__ void k_gather_cons(VcBatchDev b, const uint64_t* off, uint8_t* out, uint64_t cap) {
+VC_KL __global__ void k_gather_cons(VcBatchDev b, const uint64_t* off, uint8_t* out, uint64_t cap) {
     const uint32_t w = blockIdx.x;
     if (w >= b.n_windows) return;
     const uint64_t o = off[w];
