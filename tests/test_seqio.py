@@ -191,6 +191,42 @@ def test_native_readers_give_the_same_batch(built, tmp_path, sam):
     wb.close(); wb0.close()
 
 
+def test_overlaps_without_cigar_native_and_python_pick_the_same_pairs(built, tmp_path, monkeypatch):
+    """align_missing_native (library-held records, sequences sliced from the readers' buffers, pairs sent in batches) hands the aligner
+    the pairs align_missing hands it, and files the answers under the same records -- the aligner itself replaced by a stand-in
+    that answers with a digest of the pair (the device aligner has its own GPU tests, tests/test_align.py)."""
+    import zlib
+    from vechat_amd import align
+    fx, wb = fixtures.load_plumbing()
+    wb.close()
+    rp, op, tp = write_inputs(fx, tmp_path, sam=False)
+    lines = [ln.split("\tcg:Z:") for ln in open(op).read().strip().split("\n")]
+    lines = [a if k % 5 == 0 else a + "\tcg:Z:" + cg for k, (a, cg) in enumerate(lines)]          # every fifth record keeps no CIGAR ...
+    c = lines[0].split("\t"); lines.append("\t".join(["nobody"] + c[1:]))                      # ... one names an unknown read,
+    lines.append("\t".join(c[:5] + [c[0]] + c[6:]))                                           # one is a self-overlap
+    open(op, "w").write("\n".join(lines) + "\n")
+    seen = []
+
+    def fake(pairs, device=0, lib=None):
+        seen.append(len(pairs))
+        return ["%dM" % (zlib.crc32(q + b"|" + t) % 1000 + 1) for q, t in pairs], [(-1 if len(q) % 7 == 0 else len(q)) for q, _ in pairs]
+    monkeypatch.setattr(align, "align_pairs", fake)
+    targets, reads, ovl = seqio.read_sequences(tp), seqio.read_sequences(rp), seqio.read_overlaps(op)
+    n_py = seqio.align_missing(targets, reads, ovl, 0.3)
+    n_missing = sum(seen)
+    seen.clear()
+    nt, nr, no = seqio.NativeSequences(tp), seqio.NativeSequences(rp), seqio.NativeOverlaps(op)
+    n_nat = seqio.align_missing_native(nt, nr, no, 0.3, batch_pairs=3)
+    assert n_nat == n_py and sum(seen) == n_missing and max(seen) <= 3 and len(seen) > 1
+    got = no.records()
+    for a, b in zip(ovl, got):
+        if a.cigar is not None:                  # (records the Python path leaves untouched are marked "" natively: load drops both)
+            assert b.cigar == a.cigar
+        else:
+            assert b.cigar in (None, "")
+    assert sum(1 for o in got if o.cigar) == sum(1 for o in ovl if o.cigar)
+
+
 def test_native_readers_odd_inputs_and_filters(built, tmp_path):
     import random
     rnd = random.Random(9)

@@ -393,31 +393,77 @@ class NativeOverlaps:
         self.lib.vc_ovlset_set_cigar(self.h, i, None if cigar is None else cigar.encode())
 
 
-def align_missing_native(targets, reads, overlaps, error_threshold=0.3, device=0):
-    """align_missing() for the library-held records: every overlap without a CIGAR that load would keep is aligned on the device."""
-    todo = [(i, o) for i, o in ((i, overlaps.get(i)) for i in range(len(overlaps))) if o.cigar is None]
-    if not todo:
-        return 0
+class _OverlapRecRaw(C.Structure):
+    """vc_overlap_rec with the CIGAR as a bare pointer: looking at a record does not copy its CIGAR into a Python string."""
+    _fields_ = [
+        ("q_name", C.c_void_p), ("q_name_len", C.c_uint32), ("t_name", C.c_void_p), ("t_name_len", C.c_uint32),
+        ("by_index", C.c_uint8), ("q_index", C.c_uint32), ("t_index", C.c_uint32), ("strand", C.c_uint8),
+        ("q_begin", C.c_uint32), ("q_end", C.c_uint32), ("q_length", C.c_uint32), ("t_begin", C.c_uint32), ("t_end", C.c_uint32),
+        ("length", C.c_uint32), ("error", C.c_double), ("cigar", C.c_void_p), ("dropped", C.c_uint8),
+    ]
+
+
+def _seq_view(s):
+    """(names, offsets, bases) of a NativeSequences: the bases as a view into the library's buffer, not a copy"""
+    off = s._arr(s.lib.vc_seqset_data_off, s.n + 1)
+    tot = int(off[-1]) if s.n else 0
+    data = np.frombuffer((C.c_uint8 * tot).from_address(s.lib.vc_seqset_data(s.h)), np.uint8) if tot else np.zeros(0, np.uint8)
+    return s.names(), off, data
+
+
+def align_missing_native(targets, reads, overlaps, error_threshold=0.3, device=0, batch_pairs=1 << 16):
+    """align_missing() for the library-held records: every overlap without a CIGAR that load would keep is aligned on the device.
+    The sequences stay where the readers put them (views, sliced per pair); only the records without a CIGAR are looked at beyond
+    their header, and the pairs go to the device `batch_pairs` at a time, so the host holds one batch of pieces, not a second copy
+    of the input."""
     from .align import align_pairs
-    trec, rrec = targets.records(), reads.records()
-    pseudo = [o for _, o in todo]
-    _resolve_indices(trec, rrec, pseudo)
-    seq = {n: d for n, d, _ in rrec}
-    tgt = {n: d for n, d, _ in trec}
-    sel = [(i, o) for i, o in todo if o.q_name in seq and o.t_name in tgt and o.error <= error_threshold and o.q_name != o.t_name]
-    pairs = []
-    for _, o in sel:
-        q = seq[o.q_name][o.q_begin:o.q_end]
-        pairs.append((q.translate(_COMP)[::-1] if o.strand else q, tgt[o.t_name][o.t_begin:o.t_end]))
-    cigars, dist = align_pairs(pairs, device=device)
-    n_ok = 0
-    for (i, _), cg, d in zip(sel, cigars, dist):
-        overlaps.set_cigar(i, cg if d >= 0 else None)          # beyond the aligner's envelope: dropped rather than guessed
-        n_ok += d >= 0
-    done = {i for i, _ in sel}
-    for i, _ in todo:
-        if i not in done:
+    lib, n = overlaps.lib, len(overlaps)
+    r = _OverlapRecRaw()
+    get = lib.vc_ovlset_get
+    rp = C.cast(C.byref(r), get.argtypes[2])
+    views = None
+    pend, n_ok, any_missing = [], 0, False
+
+    def flush():
+        nonlocal n_ok
+        if not pend:
+            return
+        _, roff, rdata = views[1]
+        _, toff, tdata = views[0]
+        pairs = []
+        for _, qi, ti, qb, qe, tb, te, strand in pend:
+            q = rdata[int(roff[qi]) + qb:int(roff[qi]) + qe].tobytes()
+            pairs.append((q.translate(_COMP)[::-1] if strand else q, tdata[int(toff[ti]) + tb:int(toff[ti]) + te].tobytes()))
+        cigars, dist = align_pairs(pairs, device=device)
+        for (i, *_), cg, d in zip(pend, cigars, dist):
+            overlaps.set_cigar(i, cg if d >= 0 else None)      # beyond the aligner's envelope: dropped rather than guessed
+            n_ok += d >= 0
+        pend.clear()
+
+    for i in range(n):
+        if get(overlaps.h, i, rp) != 0:
+            raise IndexError(i)
+        if r.cigar:
+            continue
+        if views is None:                                      # first record without a CIGAR: names -> position (the last record of a name wins,
+            tv, rv = _seq_view(targets), _seq_view(reads)      # as in the dictionaries of align_missing)
+            views = (tv, rv, {nm: k for k, nm in enumerate(tv[0])}, {nm: k for k, nm in enumerate(rv[0])})
+        (tnames, toff, _), (rnames, roff, _), tmap, rmap = views
+        if r.by_index:                                         # MHAP: file positions (overlap.cpp:129-166)
+            qn = rnames[r.q_index] if r.q_index < len(rnames) else None
+            tn = tnames[r.t_index] if r.t_index < len(tnames) else None
+        else:
+            qn, tn = C.string_at(r.q_name, r.q_name_len).decode(), C.string_at(r.t_name, r.t_name_len).decode()
+        qi, ti = rmap.get(qn), tmap.get(tn)
+        err = 2.0 if r.dropped else r.error
+        if qi is None or ti is None or not err <= error_threshold or qn == tn:
             overlaps.set_cigar(i, "")                          # load filters it out anyway (unknown names, error, self-overlap)
+            continue
+        ql, tl = int(roff[qi + 1] - roff[qi]), int(toff[ti + 1] - toff[ti])
+        pend.append((i, qi, ti, min(r.q_begin, ql), min(r.q_end, ql), min(r.t_begin, tl), min(r.t_end, tl), bool(r.strand)))
+        if len(pend) >= batch_pairs:
+            flush()
+    flush()
     return n_ok
 
 
