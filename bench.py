@@ -525,6 +525,7 @@ def main():
         torch.cuda.empty_cache()
         rate, cons_e2e = e2e_rate(batch, local, reps=2)     # (best of two passes: the first can run into the driver still clearing the memory the headline context gave back)
         line["value_e2e"] = rate
+        line["value_resident"] = line["value"]          # (`value` IS the resident-input rate the bench contract defines; named once more beside the host-to-host rate)
         line["e2e"] = {"definition": "host arrays -> vc_submit -> vc_run -> vc_collect -> host bytes, H2D and D2H included (SURVEY 8(d)'s metric): one context, "
                                      f"one host thread, batches of {E2E_BATCH} windows (the first: {E2E_FIRST}) queued behind each other (submit of batch i+1 and collect of batch i-1 "
                                      "while batch i runs)",

@@ -10,7 +10,7 @@ echo "ROCm: $(cat /opt/rocm/.info/version 2>/dev/null)  hipcc: $(/opt/rocm/bin/h
 for lib in product plain; do
   [ $lib = plain ] && export VECHAT_HIP_LIB=$P || unset VECHAT_HIP_LIB
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_$lib.log 2>&1; echo "$lib: pytest exit $? $(grep -E 'passed|failed' $O/pytest_$lib.log)"
-  timeout 900 python tools/gpu_stress.py 120 23 > $O/stress_$lib.log 2>&1; echo "$lib: sweep exit $? $(tail -1 $O/stress_$lib.log)"
+  timeout 1500 python tools/gpu_stress.py 300 29 > $O/stress_$lib.log 2>&1; echo "$lib: sweep exit $? $(tail -1 $O/stress_$lib.log)"
 done
 unset VECHAT_HIP_LIB
 python - <<PY
