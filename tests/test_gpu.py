@@ -294,12 +294,13 @@ def test_launch_plans_of_round_four_agree(built, monkeypatch):
 
 
 def test_several_sequences_per_forward_wave(built, monkeypatch):
-    """The experimental re-alignment kernel (k_fwdn, VC_MULTI=2 / 4: sequences of a window share a wave's row loop) gives the default
-    path's bytes, statuses and cell counts -- run three times each, because the bug it once had (a store hazard inside an asm block)
-    showed on a different set of windows from run to run."""
+    """The experimental re-alignment kernels (VC_MULTI=2 / 4: k_fwdn, sequences of a window share a wave's row loop; VC_MULTI=32: k_fwdh,
+    two sequences on 32 lanes each, rows stored and walked in that geometry) give the default path's bytes, statuses and cell counts --
+    run three times each, because the bug k_fwdn once had (a store hazard inside an asm block) showed on a different set of windows
+    from run to run."""
     batch = capi.synth_batch(capi.synth_cfg(1002, 500, 64), 0, 24)            # config C's shape: classes of 8 and 10 columns per lane
     ref, _, ost = oa.oracle_run(batch, capi.default_params())
-    for multi in ("1", "2", "4"):
+    for multi in ("1", "2", "4", "32"):
         monkeypatch.setenv("VC_MULTI", multi)
         c = HipContext(device=0)
         for _ in range(3):

@@ -185,7 +185,8 @@ struct vc_ctx {
     bool fold = true;             // launch_fwd: more than two width classes in one launch (development: VC_NO_FOLD=1 launches once per class)
     uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
     uint32_t multi = 1;           // re-alignment rounds: sequences of a window per forward wave.  1 (default): one, as in the build phase; VC_MULTI=2 / 4:
-                                  // k_fwdn -- bit-identical, and 5 % / 16 % slower on the job at config C (NOTES.md, round 5), so it stays an experiment
+                                  // k_fwdn; VC_MULTI=32: k_fwdh (two sequences on 32 lanes each) -- bit-identical, and 5 % / 16 % / 3 % slower on the job
+                                  // at config C (NOTES.md, round 5), so they stay experiments
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};      // the process's chunk streams of this device (pooled_stream): not owned
     hipStream_t own_stream = nullptr;        // this context's stream for copies, fills and small kernels
@@ -549,8 +550,8 @@ int launch_fwd(vc_ctx* c, const Batch* bt, hipStream_t st, const VcFwdArgs& a0, 
     if (a.all_hi && c->multi > 1 && !a.redo_list && jobs == a.nslots * a.group) {
         bool done;
         { Timer t(c, KC_FWD, st);
-          const uint32_t ns_w = c->multi;
-          const uint32_t grid = a.nslots * ((a.group + ns_w - 1u) / ns_w);
+          const uint32_t ns_w = c->multi, per_wave = ns_w == 32u ? 2u : ns_w;          // (32: k_fwdh, two sequences on 32 lanes each)
+          const uint32_t grid = a.nslots * ((a.group + per_wave - 1u) / per_wave);
           done = vc_launch_fwdn(opts[hi], ns_w, grid, (void*)st, &a) == 0;          // (vc_fwdn.hip: a translation unit of its own)
         }
         if (done) { wide(); return VC_OK; }
@@ -951,6 +952,8 @@ struct Plan {
                 const bool built = bt->cpl == 6 || bt->cpl == 8 || bt->cpl == 10 || bt->cpl == 12;
 #endif
                 multi = nwonly && bt->packed && (c->multi > 1 || getenv("VC_ALL_HI")) && lo >= 0 && hi - lo <= 1 && built && gsz >= 2;      // (VC_ALL_HI: development -- the class forcing without k_fwdn)
+                // half geometry: a lane owns twice the columns, the byte-packed row form must still hold there
+                if (c->multi == 32u && !vc_row_packed(c->prm.match, c->prm.mismatch, c->prm.gap, 2 * (int)bt->cpl)) multi = false;
             }
             fa.all_hi = multi ? 1u : 0u;
             ta.cpl_lo = multi ? bt->cpl : fold_lo(c, bt);
@@ -1103,7 +1106,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     c->fold = getenv("VC_NO_FOLD") == nullptr;
-    if (const char* d = getenv("VC_MULTI")) { const int v = std::atoi(d); c->multi = v == 4 ? 4u : v == 2 ? 2u : 1u; }
+    if (const char* d = getenv("VC_MULTI")) { const int v = std::atoi(d); c->multi = v == 32 ? 32u : v == 4 ? 4u : v == 2 ? 2u : 1u; }
     if (const char* d = getenv("VC_TRACE_TL")) c->trace_tl = std::atoi(d) == 16 ? 16u : 8u;
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack

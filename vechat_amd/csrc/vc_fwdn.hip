@@ -11,7 +11,8 @@
 // -> 0 launched, 1 no instantiation for this width class.  (Internal to the library: not part of include/vechat_hip.h.)
 extern "C" __attribute__((visibility("hidden"))) int vc_launch_fwdn(uint32_t cpl, uint32_t ns_w, uint32_t grid, void* stream, const VcFwdArgs* a) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define VC_FN(C) if (cpl == C) { if (ns_w == 4) hipLaunchKernelGGL((k_fwdn<C, VC_RING_PRUNED_N, 4>), dim3(grid), dim3(64), 0, st, *a); \
+#define VC_FN(C) if (cpl == C) { if (ns_w == 32) hipLaunchKernelGGL((k_fwdh<C, VC_RING_PRUNED_N>), dim3(grid), dim3(64), 0, st, *a);  /* two sequences on 32 lanes each */ \
+                                 else if (ns_w == 4) hipLaunchKernelGGL((k_fwdn<C, VC_RING_PRUNED_N, 4>), dim3(grid), dim3(64), 0, st, *a); \
                                  else hipLaunchKernelGGL((k_fwdn<C, VC_RING_PRUNED_N, 2>), dim3(grid), dim3(64), 0, st, *a); return 0; }
     VC_FN(8) VC_FN(10)
 #ifndef VC_FAST_BUILD

@@ -2290,6 +2290,312 @@ VC_KL __global__ __launch_bounds__(64) void k_fwdn(VcFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_fwdh: the re-alignment rounds, TWO sequences of a window per wave, each on 32 lanes ("half geometry").  Where k_fwdn repeats the
+// vector half of a row per sequence, here every vector instruction serves both: lanes 0-31 hold sequence k, lanes 32-63 sequence k + 1,
+// a lane owns CPL columns of its own sequence (twice the columns per lane of the 64-lane class, so 7 instructions per pair of cells
+// as before), and what a row costs beyond its cells -- the lane scan, the shifts, the carry, the row's pack, the whole scalar half --
+// is paid once for the two.  The scan stops at the half boundary (no row_bcast:31 step) and lane 32 takes what lane 0 takes (column 0).
+// Stored rows: [32 lanes][NDS] whole, VC_BAND_LANES_H lanes around the diagonal banded; the job's type carries VC_JOB_HALF so that
+// the backtrack reads them in this geometry (vc_tracew_body).
+// MEASURED (round 5, config C): bit-identical; per sequence-row 54 vector instructions as before (the per-row overhead it shares is what
+// the doubled per-lane merges and the one width class for the launch cost) and 18 scalar ones instead of 50 -- and the same time: alone
+// on one stream k_fwd's launches take 348.6 against 345.8 ms per 16 384 windows, in the eight-stream job 35.1 against 36.1 k windows/s.
+// The re-alignment launches are bound by the VECTOR port; halving their scalar half buys nothing (as trimming the scalar side of k_fwd's
+// row tail bought nothing, NOTES.md).  Off by default (VC_MULTI=32).
+// ------------------------------------------------------------------------------------------------
+#define VC_BAND_LANES_H 8
+#define VC_JOB_HALF 4u          // job_type bit: rows stored in half geometry (32 lanes of 2 x the class's columns, VC_BAND_LANES_H band lanes)
+__device__ __forceinline__ uint32_t vc_band_start_g(uint32_t i, uint32_t ql, uint32_t bl, uint32_t ln) {      // vc_band_start for bl band lanes of ln
+    const uint32_t t = __umul24(i, ql) >> 16;
+    return min(max(t, bl / 2 - 1) - (bl / 2 - 1), ln - bl);
+}
+template <int CPL, int RING>
+__device__ __forceinline__ void vc_fwd_half(const VcFwdArgs& a, uint32_t* ring_raw, const uint32_t slot, const uint32_t job0, const uint32_t k0) {
+    static_assert((RING & (RING - 1)) == 0 && CPL < 32 && !VC_BAND_TILED, "plain ring, narrow classes, row-major band rows");
+    constexpr int ND = CPL / 2, NDS = vc_nds(CPL);
+    static_assert(NDS >= 4 && NDS <= 8, "stored row of 4..8 dwords per lane");
+    const int lane = vc_lane();
+    const uint32_t hs = (uint32_t)lane >> 5, hl = (uint32_t)lane & 31u;
+    const bool lane32 = lane == 32;
+    const uint32_t w = a.w0 + slot;
+    const uint32_t s0 = a.b.win_seq_off[w];
+    const int m = a.m, n = a.n, g = a.g;
+    const uint32_t nrows = a.dp.nrows[slot];
+    const uint64_t nb = (uint64_t)slot * a.NC;
+    const uint64_t so = a.b.seq_off[s0 + k0 + hs];                                   // my half's sequence
+    const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k0 + hs + 1] - so);
+    const uint32_t len0 = (uint32_t)__builtin_amdgcn_readlane((int)len, 0), len1 = (uint32_t)__builtin_amdgcn_readlane((int)len, 32);
+    if (lane == 0) {
+        a.job_type[job0] = (uint8_t)(1u | VC_JOB_HALF); a.job_type[job0 + 1] = (uint8_t)(1u | VC_JOB_HALF);
+        a.tie_cnt[job0] = 0; a.tie_cnt[job0 + 1] = 0;
+        unsigned long long* st = vc_stat_slot(a.stat);
+        atomicAdd(st + 0, (unsigned long long)nrows * (len0 + len1));
+        atomicAdd(st + 1, 2ull * nrows);
+    }
+    uint32_t pfA[ND], pfC[ND], pfG[ND], pfT[ND], sbp[ND];
+    const int mt = m - g, nt = n - g;
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+        const uint32_t i0 = hl * CPL + 2 * q, i1 = i0 + 1;
+        const uint32_t b0 = i0 < len ? a.b.bases[so + i0] : 0xFFu;
+        const uint32_t b1 = i1 < len ? a.b.bases[so + i1] : 0xFFu;
+        sbp[q] = b0 | (b1 << 16);
+        auto sc = [&](uint32_t x) { return ((uint32_t)((b0 == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)((b1 == x) ? mt : nt) << 16); };
+        pfA[q] = sc('A'); pfC[q] = sc('C'); pfG[q] = sc('G'); pfT[q] = sc('T');
+    }
+    const uint32_t gg = pk_dup(g);
+    const bool band = a.band != 0;
+    const uint32_t ql_v = vc_band_slope(len, nrows, CPL);
+    const uint32_t ql0 = (uint32_t)__builtin_amdgcn_readlane((int)ql_v, 0), ql1 = (uint32_t)__builtin_amdgcn_readlane((int)ql_v, 32);
+    if (band && hl == 0) a.band_par[job0 + hs] = ql_v;
+    const uint32_t le_v = (len - 1) / CPL, ce_v = (len - 1) % CPL;                   // end cell of my half: lane (inside the half) and column inside the lane
+    const uint32_t le0 = (uint32_t)__builtin_amdgcn_readlane((int)le_v, 0), le1 = 32u + (uint32_t)__builtin_amdgcn_readlane((int)le_v, 32);
+    int best0 = VC_INT_MIN, best1 = VC_INT_MIN;
+    uint32_t best_row0 = 0, best_row1 = 0;
+    // the matrices, band rows and column 0 of the two jobs lie one behind the other
+    const uint64_t bstride = vc_band_job_dwords(a.hstride) * 4ull;                    // bytes between the band rows of consecutive jobs
+    uint32_t* const hrow_l = a.hmat + (uint64_t)(job0 + hs) * a.hstride;             // (per lane: my half's job)
+    const char* const brow00 = reinterpret_cast<const char*>(a.bmat) + (uint64_t)job0 * bstride;
+    int16_t* const c0p_out0 = a.c0 + (uint64_t)job0 * a.NC;
+    constexpr uint32_t TLB = NDS * 4u, TBB = VC_BAND_LANES_H * TLB;
+    uint32_t t_off = 0u - TBB;
+    unsigned long long t_mask = 0;
+    uint32_t t_lane = 0;
+    const uint32_t lane_tlb = hl * TLB + hs * (uint32_t)bstride;
+    const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
+    uint32_t far_reads = 0;
+    uint32_t acc[ND];
+    int c0prev = 0, c0vec = 0;                                // column 0 depends on the graph only: one copy for both sequences
+#pragma unroll
+    for (int q = 0; q < ND; ++q) acc[q] = 0;
+    uint4 myrec = make_uint4(0, 0, 0, 0), nextrec = make_uint4(0, 0, 0, 0);
+    if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
+    constexpr uint32_t rowdw = NDS * 32;                      // dwords of one sequence's whole row
+    const uint32_t loff = hl * NDS * 4u;
+    uint32_t srow = 0;
+
+    auto ring_slot_merge = [&](uint32_t rslot, uint32_t c0lane, int& c0m) __attribute__((always_inline)) {
+        const uint32_t* rp = ring_raw + rslot * (ND * 64) + lane;
+        uint32_t hp[ND];
+#pragma unroll
+        for (int q = 0; q < ND; ++q) hp[q] = rp[q * 64];
+#pragma unroll
+        for (int q = 0; q < ND; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc[q]) : "v"(hp[q]));
+        c0m = max(c0m, __builtin_amdgcn_readlane(c0vec, c0lane));
+    };
+    auto row_tail = [&](const uint32_t r0, const int c0m, const uint32_t i, const uint32_t ri) __attribute__((always_inline)) {
+        const uint32_t bi = (r0 >> 24) & 7u;
+        const int col0 = c0m + g;
+        uint32_t P[ND];
+        {
+            const uint32_t fill = (uint32_t)c0m << 16;
+            uint32_t left = (uint32_t)VC_DPP_SHR((int)acc[ND - 1], (int)fill, 0x138, 0xF);
+            left = lane32 ? fill : left;                                       // the first lane of the upper half starts a sequence, too
+#pragma unroll
+            for (int q = 0; q < ND; ++q) P[q] = __builtin_amdgcn_alignbit(acc[q], q == 0 ? left : acc[q - 1], 16);
+        }
+        if (bi < 2) {
+            if (bi == 0) {
+#pragma unroll
+                for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfA[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfC[q]);
+            }
+        } else if (bi == 2) {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfG[q]);
+        } else if (bi == 3) {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfT[q]);
+        } else {
+            const uint32_t x = r0 & 0xFF;
+#pragma unroll
+            for (int q = 0; q < ND; ++q)
+                P[q] = pk_add(P[q], ((uint32_t)(((sbp[q] & 0xFFFFu) == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)(((sbp[q] >> 16) == x) ? mt : nt) << 16));
+        }
+#pragma unroll
+        for (int q = 0; q < ND; ++q) P[q] = pk_max(P[q], pk_add(acc[q], gg));
+        P[0] = pk_max_hi_with_lo(P[0]);
+#pragma unroll
+        for (int q = 1; q < ND; ++q) P[q] = pk_max_bcast_hi(pk_max_hi_with_lo(P[q]), P[q - 1]);
+        // the lane scan, inside each half: rows of 16 lanes, then row 0 -> row 1 and row 2 -> row 3; nothing crosses lane 31 | 32
+        int sc = (int)P[ND - 1];
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x111, 0xF));
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x112, 0xF));
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x114, 0xF));
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x118, 0xF));
+        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x142, 0xA));
+        {
+            int carry = VC_DPP_SHR(sc, VC_INT_MIN, 0x138, 0xF);
+            carry = lane32 ? VC_INT_MIN : carry;
+            carry = max(carry, (int)((uint32_t)col0 << 16));
+#pragma unroll
+            for (int q = 0; q < ND; ++q) acc[q] = pk_max_bcast_hi(P[q], (uint32_t)carry);
+        }
+        // end cell (sisd :353-355): the first sink row with the best score, per half
+        if (r0 & (VC_RF_SINK << 8)) {
+            uint32_t hv = acc[0];
+#pragma unroll
+            for (int q = 1; q < ND; ++q) {                   // (a chain of selects; the empty asm keeps the compiler from folding it into one indexed load -> scratch)
+                uint32_t t = acc[q];
+                asm("" : "+v"(t));
+                hv = (ce_v / 2 == (uint32_t)q) ? t : hv;
+            }
+            const int v = (ce_v & 1) ? pk_hi(hv) : pk_lo(hv);
+            const int v0 = __builtin_amdgcn_readlane(v, le0), v1 = __builtin_amdgcn_readlane(v, le1);
+            if (v0 > best0) { best0 = v0; best_row0 = i; }
+            if (v1 > best1) { best1 = v1; best_row1 = i; }
+        }
+        c0prev = col0;
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(c0vec) : "s"(col0), "s"(ri) : "m0");
+        __builtin_amdgcn_wave_barrier();
+        {
+            uint32_t* wp = ring_raw + (i & (RING - 1)) * (ND * 64) + lane;
+#pragma unroll
+            for (int q = 0; q < ND; ++q) wp[q * 64] = acc[q];
+        }
+        const bool newblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)((i - 1u) & (uint32_t)(VC_BAND_ROWS - 1))) == 0u;
+        t_off += TBB;
+        uint32_t wv[NDS];
+        vc_pack_row<ND, NDS>(acc, wv);
+        if (!band || (r0 & (VC_RF_FULL << 8))) {
+            uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow_l) + srow + loff);
+#pragma unroll
+            for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
+        }
+        if (band) {
+            if (newblock) {                                   // the two bands of the next VC_BAND_ROWS rows, on the scalar side
+                constexpr uint32_t BLO = VC_BAND_LANES_H / 2 - 1, BHI = BLO + 32u - VC_BAND_LANES_H;
+                const uint32_t bt0 = ((i + VC_BAND_ROWS / 2u) * ql0) >> 16, bt1 = ((i + VC_BAND_ROWS / 2u) * ql1) >> 16;
+                uint32_t bs0, bso0, bs1, bso1;
+                asm("s_max_u32 %0, %2, %3\n\ts_min_u32 %0, %0, %4\n\ts_sub_u32 %0, %0, %3\n\ts_mul_i32 %1, %0, %5"
+                    : "=&s"(bs0), "=s"(bso0) : "s"(bt0), "n"(BLO), "n"(BHI), "n"(TLB) : "scc");
+                asm("s_max_u32 %0, %2, %3\n\ts_min_u32 %0, %0, %4\n\ts_sub_u32 %0, %0, %3\n\ts_mul_i32 %1, %0, %5"
+                    : "=&s"(bs1), "=s"(bso1) : "s"(bt1), "n"(BLO), "n"(BHI), "n"(TLB) : "scc");
+                t_mask = ((unsigned long long)((1u << VC_BAND_LANES_H) - 1u) << bs0) | ((unsigned long long)((1u << VC_BAND_LANES_H) - 1u) << (32u + bs1));
+                t_lane = lane_tlb - (hs ? bso1 : bso0);
+            }
+            const char* bp = brow00 + t_off;
+            // (the exec mask of the store below must BE a scalar whatever the compiler thinks of it: an "s" operand is taken as it stands)
+            const unsigned long long tm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_mask >> 32)) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t_mask);
+            typedef uint32_t vc_u4 __attribute__((ext_vector_type(4)));
+            const vc_u4 d = {wv[0], wv[1], wv[2], wv[3]};
+            // (two wait states between a store of more than 64 bits and a VALU write of its data registers: the s_nop)
+            if (NDS == 4) {
+                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_mov_b64 exec, -1\n\ts_nop 0" :: "s"(tm), "v"(t_lane), "v"(d), "s"(bp) : "memory");
+            } else if (NDS == 5) {
+                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %4\n\tglobal_store_dword %1, %3, %4 offset:16\n\ts_mov_b64 exec, -1\n\ts_nop 0"
+                             :: "s"(tm), "v"(t_lane), "v"(d), "v"(wv[NDS - 1]), "s"(bp) : "memory");
+            } else if (NDS == 6) {
+                typedef uint32_t vc_u2 __attribute__((ext_vector_type(2)));
+                const vc_u2 e = {wv[4], wv[NDS - 1]};
+                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %4\n\tglobal_store_dwordx2 %1, %3, %4 offset:16\n\ts_mov_b64 exec, -1\n\ts_nop 0"
+                             :: "s"(tm), "v"(t_lane), "v"(d), "v"(e), "s"(bp) : "memory");
+            } else {
+                if ((t_mask >> lane) & 1ull) {
+                    uint32_t* hr = reinterpret_cast<uint32_t*>(const_cast<char*>(bp) + t_lane);
+#pragma unroll
+                    for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
+                }
+            }
+        }
+        srow += rowdw * 4u;
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (uint32_t i0 = 1; i0 <= nrows; i0 += 64) {
+        myrec = nextrec;
+        {
+            const uint32_t r = i0 - 1 + 64 + lane;
+            if (r < nrows) nextrec = a.dp.frec[nb + r];
+        }
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, nrows - i0 + 1));
+        for (uint32_t ri = 0; ri < cnt; ++ri) {
+            const uint32_t i = i0 + ri;
+            const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
+            int c0m = c0prev;
+            if (!(r0 & (VC_RF_PLAIN << 8))) {
+                if (!(r0 & (VC_RF_PREV << 8))) {
+                    c0m = VC_INT_MIN;
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) asm volatile("v_mov_b32 %0, %1" : "+v"(acc[q]) : "s"(0x80008000u));
+                }
+                const uint32_t fl = (r0 >> 8) & 0xFF, nq = (r0 >> 16) & 0xFF;
+                const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
+                const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
+                const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
+                const uint32_t nlist = (fl & VC_RF_OVF) ? r2 : nq;
+                for (uint32_t p = 0; p < nlist; ++p) {
+                    uint32_t delta;
+                    if (fl & VC_RF_OVF) {
+                        delta = ovfp[r1 + p];
+                        if ((fl & VC_RF_PREV) && delta == 1) continue;
+                    } else {
+                        const uint32_t wsel = p < 2 ? r1 : (p < 4 ? r2 : r3);
+                        delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
+                    }
+                    const uint32_t pr = i - delta;
+                    if (pr == 0) {                                             // the virtual row: H[0][j] = j*g, column 0: 0
+#pragma unroll
+                        for (int q = 0; q < ND; ++q) { const uint32_t z = 0u; asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc[q]) : "v"(z)); }
+                        c0m = max(c0m, 0);
+                    } else if (delta <= (uint32_t)RING) {
+                        ring_slot_merge((i - delta) & (RING - 1), (i - delta - 1u) & 63u, c0m);
+                    } else {
+                        __threadfence_block();                                  // my own earlier stores must have landed
+                        const uint32_t* hr = hrow_l + (uint64_t)(pr - 1) * rowdw + hl * NDS;
+                        uint32_t fw[NDS], hA[ND];
+#pragma unroll
+                        for (int t = 0; t < NDS; ++t) fw[t] = hr[t];
+                        vc_unpack_row<ND, NDS>(fw, hA);
+#pragma unroll
+                        for (int q = 0; q < ND; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc[q]) : "v"(hA[q]));
+                        far_reads += 2;
+                        int cA;
+                        if (delta <= 64) cA = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
+                        else cA = (int)__builtin_amdgcn_readfirstlane((int)c0p_out0[pr - 1]);
+                        c0m = max(c0m, cA);
+                    }
+                }
+            }
+            row_tail(r0, c0m, i, ri);
+        }
+        if ((uint32_t)lane < cnt) {
+            c0p_out0[i0 - 1 + lane] = (int16_t)c0vec;
+            c0p_out0[(uint64_t)a.NC + i0 - 1 + lane] = (int16_t)c0vec;
+        }
+        __threadfence_block();
+    }
+    if (lane == 0 && far_reads) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
+    if (lane == 0) {
+        a.job_end[job0] = (best_row0 << 16) | len0;
+        a.job_end[job0 + 1] = (best_row1 << 16) | len1;
+    }
+}
+
+// wave p of a window takes its sequences k0 + 2p and k0 + 2p + 1, both in the 32-lane class of 2 x CPL columns per lane (VcFwdArgs::all_hi:
+// CPL is the launch's widest 64-lane class); a pair that cannot -- an odd one out, a sequence outside the envelope -- goes through vc_fwd_body
+// in the same wave, one after the other, in class CPL (its rows then carry no VC_JOB_HALF)
+template <int CPL, int RING>
+VC_KL __global__ __launch_bounds__(64) void k_fwdh(VcFwdArgs a) {
+    __shared__ uint32_t ring_raw[RING * CPL * 64];
+    const uint32_t hp = (a.group + 1u) / 2u;
+    const uint32_t slot = blockIdx.x / hp, p = blockIdx.x % hp;
+    if (slot >= a.nslots) return;
+    const uint32_t job0 = slot * a.group + 2u * p, k0 = a.k0 + 2u * p;
+    const uint32_t have = min(2u, a.group - 2u * p);
+    if (have == 2u && vc_fwd_multi_ok<CPL>(a, slot, k0) && vc_fwd_multi_ok<CPL>(a, slot, k0 + 1u)) { vc_fwd_half<2 * CPL, RING>(a, ring_raw, slot, job0, k0); return; }
+#pragma unroll 1
+    for (uint32_t s = 0; s < have; ++s) {
+        VcJob jb; jb.job = job0 + s; jb.slot = slot; jb.k = k0 + s; jb.redo = false;
+        __syncthreads();
+        vc_fwd_any<CPL, RING, true, false, true>(a, ring_raw, jb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_fwd_wide: the general forward pass for alignments the packed-int16 kernel declines -- score range beyond int16
 // (the reference switches to 32-bit lanes there, simd_alignment_engine_implementation.hpp:699-706), sequences longer
 // than 64 lanes x 32 columns, unusual score signs.  Same recurrence (sisd_alignment_engine.cpp:118-254, 292-360), int32,
@@ -2560,7 +2866,7 @@ VC_KL __global__ void k_trace(VcTraceArgs a) {
     const uint64_t pj = a.cursor ? (uint64_t)slot : (uint64_t)slot * a.pair_group + (k - a.pair_k0);
     const uint8_t type = a.job_type[job];
     if (type == 255) return;
-    const bool wide = type >= 2;
+    const bool wide = type == 2 || type == 3;                 // (4 and up: VC_JOB_HALF rows, k_tracew's)
     if (a.only_wide && !wide) return;
     if (a.b.status[w] != VC_WIN_OK) return;
     uint32_t* out = a.pairs + pj * a.PC;
@@ -2708,7 +3014,10 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     uint8_t* tab = smem + (shared_tab ? 0u : grp) * (vc_tracew_tab_len(a.tab_rows) / 2u);       // two entries per byte
     auto tab_at = [&](uint32_t r) __attribute__((always_inline)) -> uint32_t { return ((uint32_t)tab[r >> 1] >> ((r & 1u) * 4u)) & 15u; };
     const uint32_t w = a.w0 + slot;
-    const uint8_t type = valid ? a.job_type[job] : (uint8_t)255;
+    const uint8_t type_raw = valid ? a.job_type[job] : (uint8_t)255;
+    // rows stored by k_fwdh: 32 lanes of twice the columns, VC_BAND_LANES_H band lanes (a redo pass stores 64-lane rows again)
+    const bool half = type_raw != 255 && (type_raw & VC_JOB_HALF) != 0 && !redo;
+    const uint8_t type = type_raw == 255 ? type_raw : (uint8_t)(type_raw & ~VC_JOB_HALF);
     valid = valid && type < 2;                                // 255: nothing to walk; 2, 3: k_fwd_wide's, walked by k_trace
     if (valid && a.b.status[w] != VC_WIN_OK) valid = false;
     if (!__any(valid)) return false;
@@ -2722,14 +3031,15 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     const uint32_t* hm32 = a.hmat + (uint64_t)(valid ? job : 0) * a.hstride;
     const uint16_t* hm = (const uint16_t*)hm32;
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
-    const uint32_t cpl = max(vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), a.cpl_lo), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
+    const uint32_t cpl = max(vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), a.cpl_lo) << (half ? 1 : 0), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
     const bool packed = a.packed != 0;
+    const uint32_t band_lanes = half ? (uint32_t)VC_BAND_LANES_H : (uint32_t)VC_BAND_LANES, row_lanes = half ? 32u : 64u;
     // banded store: global alignments of a banded launch keep VC_BAND_LANES lanes per row around the rank diagonal
     const bool band = a.band != 0 && !redo && valid && type == 1;
     const uint32_t* bm32 = a.bmat + (uint64_t)(valid ? job : 0) * vc_band_job_dwords(a.hstride);
     const uint32_t band_ql = band ? a.band_par[job] : 0u;
     const uint32_t tile_rows = vc_band_tile_rows(nds ? nds : 3u), tile_magic = tile_rows > 1 ? 0xFFFFFFFFu / tile_rows + 1u : 0u;     // rows < 65536: the multiply-high divides exactly
-    const uint32_t blk_dw = vc_band_block_bytes(nds ? nds : 3u) / 4u, tile_dw = vc_band_tile_bytes(nds ? nds : 3u) / 4u;
+    const uint32_t blk_dw = (half ? (uint32_t)VC_BAND_LANES_H * nds * 4u : vc_band_block_bytes(nds ? nds : 3u)) / 4u, tile_dw = vc_band_tile_bytes(nds ? nds : 3u) / 4u;
     bool oob = false;                                          // this lane asked for a cell outside the band (its value is then meaningless)
     const uint32_t nrows = valid ? min(a.dp.nrows[slot], a.tab_rows) : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
@@ -2742,8 +3052,9 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
         if (band) {
             const uint32_t tb = vc_band_tile_of_row(r - 1, tile_rows, tile_magic), rin = r - 1 - tb * tile_rows;
-            const uint32_t bl = lc - (VC_BAND_TILED ? vc_band_block_start(tb, tile_rows, band_ql) : vc_band_row_start(r - 1, band_ql));
-            if (bl >= (uint32_t)VC_BAND_LANES) { oob = true; return 0; }
+            const uint32_t bl = lc - (VC_BAND_TILED ? vc_band_block_start(tb, tile_rows, band_ql)
+                                                    : vc_band_start_g(((r - 1) & ~(uint32_t)(VC_BAND_ROWS - 1)) + 1u + VC_BAND_ROWS / 2u, band_ql, band_lanes, row_lanes));
+            if (bl >= band_lanes) { oob = true; return 0; }
             return vc_packed_cell(bm32 + tb * blk_dw + bl * tile_dw + rin * nds, cc, cpl);
         }
         if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl);
