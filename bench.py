@@ -56,7 +56,7 @@ def kernel_hash():
     Comments and whitespace do not count (a reworded comment does not invalidate a measurement)."""
     import re
     h = hashlib.sha256()
-    for f in ("vc_kernels.h", "vc_api.hip", "vc_device.h", "vc_pipe.h"):
+    for f in ("vc_kernels.h", "vc_fwd_dt.h", "vc_api.hip", "vc_device.h", "vc_pipe.h"):
         src = open(os.path.join(ROOT, "vechat_amd", "csrc", f), "r").read()
         src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
         src = re.sub(r"//[^\n]*", " ", src)
@@ -537,7 +537,8 @@ def main():
                            # the hard cases of SURVEY 8(d): partial-span layers (Subgraph + local re-alignment), two haplotypes
                            # (graphs that stay branched after pruning), and the per-rank shards of configs D and E on this one GPU
                            # the other execution plan of the build loop, on the same workload (32 768 windows of config C)
-                           "C_pipeline": short_config(local, 1002, 500, 64, 32768, capi.PACBIO, check=256, pipeline=True, chunk=16384, streams=1),
+                           **({"C_pipeline": short_config(local, 1002, 500, 64, 32768, capi.PACBIO, check=256, pipeline=True, chunk=16384, streams=1)}
+                              if capi.load_hip().vc_has_experiments() else {}),      # (an experiment: only in a library built with VC_EXPERIMENTS=1)
                            "C_mixed": short_config(local, 1011, 500, 64, 16384, capi.PACBIO, frac_partial=0.2, check=256),
                            "C_hap2": short_config(local, 1012, 500, 64, 16384, capi.PACBIO, n_haplotypes=2, snp_rate=0.01, check=256),
                            "D_shard": short_config(local, 1002, 500, 64, 125000, capi.PACBIO, first=3 * 125000, check=256),

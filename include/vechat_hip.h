@@ -162,6 +162,10 @@ int   vc_set_profile(vc_ctx* ctx, int profile);       /* change vc_params.profil
  * Results are identical either way; the environment variable VC_PIPE=0/1 sets the default of a new context.
  * forward_waves / backtrack_waves: resident workgroups of the two kernels (0: 15 and 5 per CU). */
 int   vc_set_pipeline(vc_ctx* ctx, int on, uint32_t forward_waves, uint32_t backtrack_waves);
+/* 1 when the library was built with -DVC_EXPERIMENTS (VC_EXPERIMENTS=1 python __graft_entry__.py): the persistent pipeline above is a
+ * measured experiment (bit-identical, slower than the lock-step plan) and is left out of the default build -- vc_set_pipeline(ctx, 1, ..)
+ * then returns VC_ERR_ARG, as do vc_debug_pipe_state / vc_debug_pipe_prof. */
+int   vc_has_experiments(void);
 /* Allocates the workspaces' memory now, in one piece (bytes = 0: the default budget, vc_params.scratch_bytes or 60 % of the free
  * memory up to 96 GiB), instead of under the first vc_submit; batches of any shape are then laid out inside it without further
  * allocations.  The counterpart of createCUDABatch sizing a batch's device memory at construction (mem_per_batch, src/cuda/cudapolisher.cpp:229-243):

@@ -189,7 +189,13 @@ def test_persistent_build_pipeline_agrees_with_the_lock_step_plan(built):
     resident forward / backtrack waves handing windows over through device-side queues.  Same bytes, same statuses, same work
     counters (cells, rows, alignments that left the band); partial-span layers (Subgraph rows inside the forward wave), two
     haplotypes, ragged depths, a window that overflows its capacity, several chunks, both overloads, and a pipeline squeezed
-    into very few resident waves (every hand-over then waits for a free wave)."""
+    into very few resident waves (every hand-over then waits for a free wave).  The pipeline is an experiment (measured slower): it is
+    compiled only with VC_EXPERIMENTS=1, the default library refuses vc_set_pipeline(on)."""
+    if not capi.load_hip().vc_has_experiments():
+        c = HipContext(device=0)
+        assert c.lib.vc_set_pipeline(c.h, 1, 0, 0) == capi.VC_ERR_ARG
+        c.close()
+        pytest.skip("library built without VC_EXPERIMENTS")
     cases = [(capi.synth_cfg(1002, 500, 24), 24, {}),
              (capi.synth_cfg(13, 400, 20, n_haplotypes=2, snp_rate=0.02, frac_partial=0.3), 40, dict(chunk_windows=16, n_streams=2)),
              (capi.synth_cfg(77, 250, 12, frac_partial=0.5, fastq=0, backbone_fastq=0), 30, dict(mode=1)),
@@ -293,23 +299,51 @@ def test_launch_plans_of_round_four_agree(built, monkeypatch):
     c.close()
 
 
-def test_several_sequences_per_forward_wave(built, monkeypatch):
-    """The experimental re-alignment kernels (VC_MULTI=2 / 4: k_fwdn, sequences of a window share a wave's row loop; VC_MULTI=32: k_fwdh,
-    two sequences on 32 lanes each, rows stored and walked in that geometry) give the default path's bytes, statuses and cell counts --
-    run three times each, because the bug k_fwdn once had (a store hazard inside an asm block) showed on a different set of windows
-    from run to run."""
-    batch = capi.synth_batch(capi.synth_cfg(1002, 500, 64), 0, 24)            # config C's shape: classes of 8 and 10 columns per lane
-    ref, _, ost = oa.oracle_run(batch, capi.default_params())
-    for multi in ("1", "2", "4", "32"):
-        monkeypatch.setenv("VC_MULTI", multi)
-        c = HipContext(device=0)
-        for _ in range(3):
-            cons, status = c.consensus(batch, retry_overflow=False)
-            assert [int(x) for x in status] == [capi.VC_WIN_OK] * 24
-            assert cons == list(ref)
-            assert c.stats()["cells"] == ost.cells
-        c.close()
-    monkeypatch.delenv("VC_MULTI")
+def test_a_staged_batch_cannot_run_on_released_workspaces(built):
+    """vc_release / vc_reserve give the chunk workspaces back; a batch staged before that must not be runnable (its plan would
+    launch on freed pointers) -- vc_run says VC_ERR_STATE until the batch is submitted again.  Results of a finished run stay collectable."""
+    batch = capi.synth_batch(capi.synth_cfg(21, 200, 10), 0, 6)
+    ref, pol, _ = oa.oracle_run(batch, capi.default_params())
+    c = HipContext(device=0)
+    c.submit(batch)
+    c.release()
+    assert c.lib.vc_run(c.h) == capi.VC_ERR_STATE
+    c.submit(batch); c.run(); c.sync()
+    c.release()                                       # ran, not yet collected: the results live in the batch's own buffers
+    cons, status = c.collect()
+    assert cons == list(ref)
+    assert c.lib.vc_run(c.h) == capi.VC_ERR_STATE      # "the same batch again" needs its workspaces
+    c.reserve(2 << 30)
+    assert c.lib.vc_run(c.h) == capi.VC_ERR_STATE
+    cons, status = c.consensus(batch, retry_overflow=False)
+    assert cons == list(ref)
+    c.close()
+
+
+def test_both_forward_kernels_give_the_same_bytes(built, monkeypatch):
+    """Global alignments on byte-packed rows run on k_fwd_dt (doubly tilted unsigned rows, buffer stores: vc_fwd_dt.h); VC_DT=0 keeps them
+    on k_fwd (singly tilted, signed).  Same bytes, statuses, cell counts and number of alignments that left the band -- on config C's
+    shape, with partial-span layers (local alignments stay on k_fwd either way), two haplotypes, and a batch of several width classes;
+    three runs each: a hazard between a store and the next row's pack would show on different windows from run to run."""
+    cases = [(capi.synth_cfg(1002, 500, 64), 24), (capi.synth_cfg(13, 400, 20, n_haplotypes=2, snp_rate=0.02, frac_partial=0.3), 40),
+             (capi.synth_cfg(8, 120, 9), 16), (capi.synth_cfg(1005, 1000, 40, profile=capi.ONT), 6)]
+    for cfg, n in cases:
+        batch = capi.synth_batch(cfg, 0, n)
+        ref, pol, ost = oa.oracle_run(batch, capi.default_params())
+        seen = []
+        for dt in ("1", "0"):
+            monkeypatch.setenv("VC_DT", dt)
+            c = HipContext(device=0)
+            for _ in range(3):
+                cons, status = c.consensus(batch, retry_overflow=False)
+                assert [int(x) for x in status] == [capi.VC_WIN_OK if p else capi.VC_WIN_UNPOLISHED for p in pol]
+                assert cons == list(ref)
+                st = c.stats()
+                assert st["cells"] == ost.cells
+                seen.append((dt, st["band_redo"], st["dp_rows"]))
+            c.close()
+        assert len({x[1:] for x in seen}) == 1, seen
+    monkeypatch.delenv("VC_DT")
 
 
 def _digest(cons):

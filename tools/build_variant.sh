@@ -8,8 +8,7 @@ name=$1; shift
 mkdir -p vechat_amd/lib/variants
 FAST="-mllvm -structurizecfg-skip-uniform-regions"
 [ "$VC_PLAIN_CFG" = "1" ] && FAST=""
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC $FAST -I include "$@" -c vechat_amd/csrc/vc_fwdn.hip -o vechat_amd/lib/variants/vc_fwdn_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $FAST -I include "$@" \
-  vechat_amd/lib/variants/vc_fwdn_$name.o vechat_amd/csrc/vc_api.hip vechat_amd/csrc/vc_align.hip vechat_amd/csrc/vc_host.cpp vechat_amd/csrc/vc_windows.cpp vechat_amd/csrc/vc_io.cpp \
+  vechat_amd/csrc/vc_api.hip vechat_amd/csrc/vc_align.hip vechat_amd/csrc/vc_host.cpp vechat_amd/csrc/vc_windows.cpp vechat_amd/csrc/vc_io.cpp \
   -lz -o vechat_amd/lib/variants/libvechat_hip_$name.so
 echo built $name

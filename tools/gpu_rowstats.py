@@ -15,7 +15,7 @@ f.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINT
 for layer in (4, 16, 32, 48, 62):
     ctx.lib.vc_debug_stop_after(ctx.h, 1, layer)
     ctx.run(); ctx.sync()
-    hist = collections.Counter(); npred = collections.Counter()
+    hist = collections.Counter(); npred = collections.Counter(); rtype = collections.Counter()
     rows_tot = keep_tot = 0
     hits = {k: [0, 0] for k in (4, 5, 6, 8, 10, 12)}           # plain ring of k rows: [hits, reads]
     khits = {k: [0, 0] for k in (3, 4, 5, 6, 8)}               # ring of k KEPT rows
@@ -33,6 +33,7 @@ for layer in (4, 16, 32, 48, 62):
             d = [int(rec[r, 1]) & 0xFFFF, int(rec[r, 1]) >> 16, int(rec[r, 2]) & 0xFFFF, int(rec[r, 2]) >> 16, int(rec[r, 3]) & 0xFFFF, int(rec[r, 3]) >> 16][:k]
             d = [v for v in d if v <= r]                        # drop the virtual row
             preds.append(d); npred[len(d)] += 1
+            rtype[('prev' if 1 in d else 'noprev', len([v for v in d if v != 1]), 'sink' if fl & 1 else '')] += 1
             for v in d:
                 hist[min(v, 20)] += 1
                 if v >= 2: keep[r - v] = True
@@ -47,6 +48,7 @@ for layer in (4, 16, 32, 48, 62):
     tot = sum(hist.values())
     print(f"layer {layer}: rows/window {rows_tot / n:.0f}  kept rows {100 * keep_tot / rows_tot:.1f} %  preds/row {tot / rows_tot:.2f}  non-adjacent reads/row {sum(v for k, v in hist.items() if k >= 2) / rows_tot:.3f}")
     print("   distance histogram %:", {k: round(100 * v / tot, 1) for k, v in sorted(hist.items())})
+    print("   row types % (row above a predecessor?, other predecessors, sink):", {k: round(100 * v / rows_tot, 1) for k, v in sorted(rtype.items(), key=lambda kv: -kv[1])[:12]})
     print("   in-degree %:", {k: round(100 * v / rows_tot, 1) for k, v in sorted(npred.items())})
     print("   plain ring hit % of non-adjacent reads:", {k: round(100 * a / max(b, 1), 2) for k, (a, b) in hits.items()})
     print("   kept-row ring hit %:", {k: round(100 * a / max(b, 1), 2) for k, (a, b) in khits.items()}, flush=True)

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 VC_WIN_OK, VC_WIN_UNPOLISHED, VC_WIN_OVERFLOW, VC_WIN_UNSUPPORTED, VC_WIN_INVALID = range(5)
+VC_OK, VC_ERR_ARG, VC_ERR_HIP, VC_ERR_NO_DEVICE, VC_ERR_STATE, VC_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
 
 
 class VcParams(C.Structure):
@@ -302,6 +303,8 @@ def load_hip():
         lib.vc_set_profile.restype = C.c_int
         lib.vc_set_pipeline.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
         lib.vc_set_pipeline.restype = C.c_int
+        lib.vc_has_experiments.argtypes = []
+        lib.vc_has_experiments.restype = C.c_int
         lib.vc_reserve.argtypes = [vp, C.c_uint64]; lib.vc_reserve.restype = C.c_int
         lib.vc_release.argtypes = [vp]; lib.vc_release.restype = C.c_int
         lib.vc_set_window_type.argtypes = [vp, C.c_int]; lib.vc_set_window_type.restype = C.c_int

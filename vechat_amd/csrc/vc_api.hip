@@ -31,9 +31,11 @@
 #include <vector>
 
 #include "vc_kernels.h"
+// The persistent build pipeline (vc_pipe.h: built, bit-identical, slower than the lock-step plan -- DESIGN section 10) is an experiment:
+// compiled only with -DVC_EXPERIMENTS (VC_EXPERIMENTS=1 python __graft_entry__.py); without it vc_set_pipeline(on) is refused.
+#ifdef VC_EXPERIMENTS
 #include "vc_pipe.h"
-
-extern "C" __attribute__((visibility("hidden"))) int vc_launch_fwdn(uint32_t cpl, uint32_t ns_w, uint32_t grid, void* stream, const VcFwdArgs* a);
+#endif
 
 namespace {
 
@@ -59,8 +61,8 @@ constexpr int kKept = VC_KEPT;      // build phase: slots of the kept-row ring (
 // eight at 48; the rows that no longer find their predecessor in the ring read it back from the stored matrix.
 constexpr int kKeptWide = 3, kRingWide = 4, kRingPrunedWide = 2;
 constexpr int kRingPruned = VC_RING_PRUNED;
-static_assert(VC_RING_PRUNED == VC_RING_PRUNED_N, "vc_fwdn.hip instantiates k_fwdn with the pruned graphs' ring");   // re-alignment rounds and the final alignment: a pruned graph is nearly a chain, four rows hold
-                                              // its non-adjacent predecessors, and the smaller ring lets a fifth / sixth wave onto each SIMD
+// (re-alignment rounds and the final alignment: a pruned graph is nearly a chain, four rows hold its non-adjacent predecessors, and the
+// smaller ring lets a fifth / sixth wave onto each SIMD)
 constexpr int kMaxStreams = 16;
 constexpr uint32_t kAutoStreamsMany = 8, kAutoStreamsFew = 4, kAutoStreamsFrom = 12288;   // windows from which a batch runs on the larger number of chunk streams
 constexpr uint32_t kTraceTabRows = 8188;           // rows covered by k_tracew's first-in-edge table (4 tables x 2 B x 8192 = 64 KB); later rows are walked without speculation
@@ -182,11 +184,9 @@ struct vc_ctx {
     uint32_t dbg_stop_kind = 0, dbg_stop_index = 0;   // vc_debug_stop_after: leave the chunk's graphs as they are after that stage
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
     uint32_t trace_tl = 8;        // lanes per alignment of the lock-step k_tracew (development: VC_TRACE_TL=16)
+    bool dt = true;               // global alignments on byte-packed rows run on k_fwd_dt (development: VC_DT=0 keeps them on k_fwd)
     bool fold = true;             // launch_fwd: more than two width classes in one launch (development: VC_NO_FOLD=1 launches once per class)
     uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
-    uint32_t multi = 1;           // re-alignment rounds: sequences of a window per forward wave.  1 (default): one, as in the build phase; VC_MULTI=2 / 4:
-                                  // k_fwdn; VC_MULTI=32: k_fwdh (two sequences on 32 lanes each) -- bit-identical, and 5 % / 16 % / 3 % slower on the job
-                                  // at config C (NOTES.md, round 5), so they stay experiments
     Work works[kMaxStreams];
     hipStream_t streams[kMaxStreams]{};      // the process's chunk streams of this device (pooled_stream): not owned
     hipStream_t own_stream = nullptr;        // this context's stream for copies, fills and small kernels
@@ -348,6 +348,13 @@ void free_list(std::vector<void*>& l) {
     for (void* p : l) (void)hipFree(p);
     l.clear();
 }
+// The workspaces a staged batch was planned on are gone (vc_release / vc_reserve): such a batch can no longer be run -- its plan would
+// launch on freed pointers.  Results of a finished run stay collectable (they live in the batch's own buffers); vc_run asks for a new
+// vc_submit.
+void unstage(vc_ctx* c) {
+    for (Batch& b : c->bt) if (!b.ran || b.collected) b.have = false;       // (a finished run that nobody has collected keeps its results)
+    if (c->cur && !c->cur->have) c->cur = nullptr;
+}
 void free_workspaces(vc_ctx* c) {         // the chunk workspaces: what was allocated piece by piece, and the arena's bump pointer
     free_list(c->chunk_allocs);
     c->arena_used = 0;
@@ -418,11 +425,13 @@ int alloc_work(vc_ctx* c, Work* wk) {
         wk->pipe_cap = cap;
         // (the exact-DFS fallback of the end-cell resolver works from an HBM image of the graph: one per backtrack workgroup)
         wk->pipe_ws_bytes = (size_t)std::min<uint64_t>((CW + VC_TG - 1) / VC_TG, 256u * 8u) * ((topo_lds_bytes(NC, c->EC, c->STK, c->MA) + 15u) & ~15u);
+        if ((rc = dalloc(c, c->chunk_allocs, &wk->d_cur_layer, CW))) return rc;
+#ifdef VC_EXPERIMENTS
         if ((rc = dalloc(c, c->chunk_allocs, &wk->d_pipe_ctl, (size_t)VC_PC_N * VC_PIPE_CTL_STRIDE)) ||
             (rc = dalloc(c, c->chunk_allocs, &wk->d_pipe_slots, (size_t)2 * cap)) ||
-            (rc = dalloc(c, c->chunk_allocs, &wk->d_cur_layer, CW)) ||
             (rc = dalloc(c, c->chunk_allocs, &wk->d_pipe_ws, wk->pipe_ws_bytes)))
             return rc;
+#endif
     }
     return VC_OK;
 }
@@ -505,9 +514,18 @@ void flush_events(vc_ctx* c) {
 }
 
 // nwonly: every alignment of the launch is global (mode 0 always; a re-alignment launch whose layers are all full-span)
+// dt: global alignments on byte-packed rows take the doubly tilted kernel (k_fwd_dt, vc_fwd_dt.h) -- decided per batch (launch_fwd)
 template <int CA, int CB>
-void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs, bool packed, bool nwonly) {
+void launch_fwd_t(hipStream_t st, const VcFwdArgs& a, uint32_t jobs, bool packed, bool nwonly, bool dt) {
     constexpr int KR = CB >= 32 ? kKeptWide : (kKept ? kKept : 1), PR = CB >= 32 ? kRingWide : kRing, QR = CB >= 32 ? kRingPrunedWide : kRingPruned;
+    if constexpr (CB < 32) {
+        if (dt && packed && (a.mode == 0 || (a.mode == 1 && nwonly))) {
+            if (a.mode == 0 && a.kept) hipLaunchKernelGGL((k_fwd_dt<CA, CB, KR, true>), dim3(jobs), dim3(64), 0, st, a);
+            else if (a.mode == 0) hipLaunchKernelGGL((k_fwd_dt<CA, CB, PR, false>), dim3(jobs), dim3(64), 0, st, a);
+            else hipLaunchKernelGGL((k_fwd_dt<CA, CB, QR, false>), dim3(jobs), dim3(64), 0, st, a);
+            return;
+        }
+    }
     if (a.mode == 0 && a.kept) {
         if (packed) hipLaunchKernelGGL((k_fwd<CA, CB, KR, true, true, true>), dim3(jobs), dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_fwd<CA, CB, KR, false, true, true>), dim3(jobs), dim3(64), 0, st, a);
@@ -546,33 +564,24 @@ int launch_fwd(vc_ctx* c, const Batch* bt, hipStream_t st, const VcFwdArgs& a0, 
     // more than two classes (partial-span layers: pieces of reads of any length): one launch built for the two widest ones, every
     // narrower sequence in the lower of them -- four launches per layer, each waiting for its slowest alignment, become one
     if (hi - lo > 1 && c->fold) { lo = hi - 1; a.fold = 1; }
-    // re-alignment rounds whose alignments are all global: several sequences of a window per wave (k_fwdn), every one in the widest class
-    if (a.all_hi && c->multi > 1 && !a.redo_list && jobs == a.nslots * a.group) {
-        bool done;
-        { Timer t(c, KC_FWD, st);
-          const uint32_t ns_w = c->multi, per_wave = ns_w == 32u ? 2u : ns_w;          // (32: k_fwdh, two sequences on 32 lanes each)
-          const uint32_t grid = a.nslots * ((a.group + per_wave - 1u) / per_wave);
-          done = vc_launch_fwdn(opts[hi], ns_w, grid, (void*)st, &a) == 0;          // (vc_fwdn.hip: a translation unit of its own)
-        }
-        if (done) { wide(); return VC_OK; }
-        return fail(c, VC_ERR_STATE, "k_fwdn: no instantiation for %u columns per lane", opts[hi]);
-    }
+    // the doubly tilted form (vc_fwd_dt.h): judged on the workspaces' row capacity, so that every window of the batch takes the same kernel
+    const bool dt = c->dt && bt->packed && bt->cpl < 32 && vc_dt_ok(c->prm.match, c->prm.mismatch, c->prm.gap, c->NC, bt->cpl);
     if (hi - lo == 1) {
         { Timer t(c, KC_FWD, st);
         switch (hi) {
 #ifndef VC_FAST_BUILD          // development builds (-DVC_FAST_BUILD) carry only the width classes of the benchmark
-            case 1: launch_fwd_t<4, 6>(st, a, jobs, bt->packed, nwonly); break;
-            case 2: launch_fwd_t<6, 8>(st, a, jobs, bt->packed, nwonly); break;
+            case 1: launch_fwd_t<4, 6>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 2: launch_fwd_t<6, 8>(st, a, jobs, bt->packed, nwonly, dt); break;
 #endif
-            case 3: launch_fwd_t<8, 10>(st, a, jobs, bt->packed, nwonly); break;
+            case 3: launch_fwd_t<8, 10>(st, a, jobs, bt->packed, nwonly, dt); break;
 #ifndef VC_FAST_BUILD
-            case 4: launch_fwd_t<10, 12>(st, a, jobs, bt->packed, nwonly); break;
-            case 5: launch_fwd_t<12, 16>(st, a, jobs, bt->packed, nwonly); break;
-            case 6: launch_fwd_t<16, 20>(st, a, jobs, bt->packed, nwonly); break;
-            case 7: launch_fwd_t<20, 24>(st, a, jobs, bt->packed, nwonly); break;
-            case 8: launch_fwd_t<24, 32>(st, a, jobs, bt->packed, nwonly); break;
-            case 9: launch_fwd_t<32, 48>(st, a, jobs, bt->packed, nwonly); break;
-            case 10: launch_fwd_t<48, 64>(st, a, jobs, bt->packed, nwonly); break;
+            case 4: launch_fwd_t<10, 12>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 5: launch_fwd_t<12, 16>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 6: launch_fwd_t<16, 20>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 7: launch_fwd_t<20, 24>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 8: launch_fwd_t<24, 32>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 9: launch_fwd_t<32, 48>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 10: launch_fwd_t<48, 64>(st, a, jobs, bt->packed, nwonly, dt); break;
 #else
             default: return fail(c, VC_ERR_ARG, "development build: width classes 8 / 10 only");
 #endif
@@ -585,19 +594,19 @@ int launch_fwd(vc_ctx* c, const Batch* bt, hipStream_t st, const VcFwdArgs& a0, 
         Timer t(c, KC_FWD, st);
         switch (opts[i]) {
 #ifndef VC_FAST_BUILD
-            case 4:  launch_fwd_t<4, 4>(st, a, jobs, bt->packed, nwonly); break;
-            case 6:  launch_fwd_t<6, 6>(st, a, jobs, bt->packed, nwonly); break;
+            case 4:  launch_fwd_t<4, 4>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 6:  launch_fwd_t<6, 6>(st, a, jobs, bt->packed, nwonly, dt); break;
 #endif
-            case 8:  launch_fwd_t<8, 8>(st, a, jobs, bt->packed, nwonly); break;
-            case 10: launch_fwd_t<10, 10>(st, a, jobs, bt->packed, nwonly); break;
+            case 8:  launch_fwd_t<8, 8>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 10: launch_fwd_t<10, 10>(st, a, jobs, bt->packed, nwonly, dt); break;
 #ifndef VC_FAST_BUILD
-            case 12: launch_fwd_t<12, 12>(st, a, jobs, bt->packed, nwonly); break;
-            case 16: launch_fwd_t<16, 16>(st, a, jobs, bt->packed, nwonly); break;
-            case 20: launch_fwd_t<20, 20>(st, a, jobs, bt->packed, nwonly); break;
-            case 24: launch_fwd_t<24, 24>(st, a, jobs, bt->packed, nwonly); break;
-            case 32: launch_fwd_t<32, 32>(st, a, jobs, bt->packed, nwonly); break;
-            case 48: launch_fwd_t<48, 48>(st, a, jobs, bt->packed, nwonly); break;
-            case 64: launch_fwd_t<64, 64>(st, a, jobs, bt->packed, nwonly); break;
+            case 12: launch_fwd_t<12, 12>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 16: launch_fwd_t<16, 16>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 20: launch_fwd_t<20, 20>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 24: launch_fwd_t<24, 24>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 32: launch_fwd_t<32, 32>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 48: launch_fwd_t<48, 48>(st, a, jobs, bt->packed, nwonly, dt); break;
+            case 64: launch_fwd_t<64, 64>(st, a, jobs, bt->packed, nwonly, dt); break;
 #else
             default: return fail(c, VC_ERR_ARG, "development build: width classes 8 / 10 only");
 #endif
@@ -608,6 +617,7 @@ int launch_fwd(vc_ctx* c, const Batch* bt, hipStream_t st, const VcFwdArgs& a0, 
     return VC_OK;
 }
 
+#ifdef VC_EXPERIMENTS
 // the forward kernel of the persistent build pipeline for this batch's width classes (one class, or two adjacent ones)
 template <int CA, int CB>
 int launch_pipe_fwd_t(vc_ctx* c, hipStream_t st, const VcPipeFwdArgs& a, uint32_t grid, uint32_t lds) {
@@ -642,6 +652,7 @@ int launch_pipe_fwd(vc_ctx* c, const Batch* bt, hipStream_t st, const VcPipeFwdA
 #undef VC_PF
     return fail(c, VC_ERR_ARG, "persistent pipeline: width classes %u..%u not built", lo, hi);
 }
+#endif
 
 uint32_t pick_cpl(uint32_t max_len) {
     const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
@@ -795,6 +806,10 @@ struct Plan {
         return VC_OK;
     }
 
+#ifndef VC_EXPERIMENTS
+    bool pipe_ok() const { return false; }
+    int build_pipe(Work&) { return VC_ERR_STATE; }
+#else
     // The whole build loop of the chunk (window.cpp:239-298, every layer of every window) as ONE set of resident kernels working
     // off device-side queues (vc_pipe.h) instead of build_layer() once per layer.
     bool pipe_ok() const {
@@ -865,6 +880,7 @@ struct Plan {
         HIPCHK(c, hipStreamWaitEvent(wk.stream, wk.ev_t, 0));
         return VC_OK;
     }
+#endif
 
     // PruneGraph + LargestSubgraph + its TopologicalSort (window.cpp:318-321,374-383); `more` = a
     // re-alignment round follows, so ask the device how tall the pruned graphs are
@@ -939,24 +955,7 @@ struct Plan {
             if (bt->band) HIPCHK(c, hipMemsetAsync(wk.d_redo_n, 0, 4, wk.stream));
             bool nwonly = true;                                // no partial-span layer among these sequences in any window of the batch?
             for (uint32_t k = std::max(k0, 1u); k < k0 + gsz; ++k) nwonly = nwonly && !(k < bt->h_layer_partial.size() && bt->h_layer_partial[k]);
-            // all global, byte-packed rows, one or two adjacent classes of the usual widths: several sequences of a window per forward wave
-            // (k_fwdn), every sequence in the batch's widest class -- the backtrack and the redo pass then read / write the rows in that class
-            bool multi = false;
-            {
-                const uint32_t opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
-                int lo = -1, hi = -1;
-                for (int i = 0; i < 11; ++i) { if (opts[i] == bt->cpl_min) lo = i; if (opts[i] == bt->cpl) hi = i; }
-#ifdef VC_FAST_BUILD
-                const bool built = bt->cpl == 8 || bt->cpl == 10;
-#else
-                const bool built = bt->cpl == 6 || bt->cpl == 8 || bt->cpl == 10 || bt->cpl == 12;
-#endif
-                multi = nwonly && bt->packed && (c->multi > 1 || getenv("VC_ALL_HI")) && lo >= 0 && hi - lo <= 1 && built && gsz >= 2;      // (VC_ALL_HI: development -- the class forcing without k_fwdn)
-                // half geometry: a lane owns twice the columns, the byte-packed row form must still hold there
-                if (c->multi == 32u && !vc_row_packed(c->prm.match, c->prm.mismatch, c->prm.gap, 2 * (int)bt->cpl)) multi = false;
-            }
-            fa.all_hi = multi ? 1u : 0u;
-            ta.cpl_lo = multi ? bt->cpl : fold_lo(c, bt);
+            ta.cpl_lo = fold_lo(c, bt);
             int rc = launch_fwd(c, bt, wk.stream, fa, ns * gsz, &wk, nwonly);
             if (rc) return rc;
             ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
@@ -1106,11 +1105,13 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     c->fold = getenv("VC_NO_FOLD") == nullptr;
-    if (const char* d = getenv("VC_MULTI")) { const int v = std::atoi(d); c->multi = v == 32 ? 32u : v == 4 ? 4u : v == 2 ? 2u : 1u; }
     if (const char* d = getenv("VC_TRACE_TL")) c->trace_tl = std::atoi(d) == 16 ? 16u : 8u;
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
+    if (const char* d = getenv("VC_DT")) c->dt = std::atoi(d) != 0;
+#ifdef VC_EXPERIMENTS
     if (const char* d = getenv("VC_PIPE")) c->pipe = std::atoi(d) != 0;
+#endif
     if (const char* d = getenv("VC_PIPE_F")) c->pipe_f = (uint32_t)std::atoi(d);
     if (const char* d = getenv("VC_PIPE_T")) c->pipe_t = (uint32_t)std::atoi(d);
     if (const char* d = getenv("VC_PIPE_PATIENCE")) c->pipe_patience_s = std::min(40u, std::max(1u, (uint32_t)std::atoi(d)));
@@ -1145,8 +1146,11 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     uint32_t lw[256]; double ld[256];
     vc_weight_lut(lw);
     for (int ch = 0; ch < 256; ++ch) ld[ch] = 1 - pow(10, (33 - (int)(signed char)ch) / 10.0);
-    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, VC_STAT_WORDS) ||
-        dalloc(c, c->allocs, &c->d_pipe_abort, 64) || dalloc(c, c->allocs, &c->d_pipe_prof, VC_PP_TOTAL)) {
+    if (dalloc(c, c->allocs, &c->d_lut_w, 256) || dalloc(c, c->allocs, &c->d_lut_d, 256) || dalloc(c, c->allocs, &c->d_stat, VC_STAT_WORDS)
+#ifdef VC_EXPERIMENTS
+        || dalloc(c, c->allocs, &c->d_pipe_abort, 64) || dalloc(c, c->allocs, &c->d_pipe_prof, VC_PP_TOTAL)
+#endif
+        ) {
         g_create_error = c->err; vc_destroy(c); return VC_ERR_HIP;
     }
     (void)hipMemcpy(c->d_lut_w, lw, sizeof(lw), hipMemcpyHostToDevice);
@@ -1197,8 +1201,19 @@ int vc_set_profile(vc_ctx* c, int profile) {
     return VC_OK;
 }
 
+int vc_has_experiments(void) {
+#ifdef VC_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int vc_set_pipeline(vc_ctx* c, int on, uint32_t forward_waves, uint32_t backtrack_waves) {
     if (!c) return VC_ERR_ARG;
+#ifndef VC_EXPERIMENTS
+    if (on) return fail(c, VC_ERR_ARG, "the persistent build pipeline is an experiment: this library was built without -DVC_EXPERIMENTS");
+#endif
     drain(c);
     c->pipe = on != 0; c->pipe_f = forward_waves; c->pipe_t = backtrack_waves;
     return VC_OK;
@@ -1209,6 +1224,7 @@ int vc_reserve(vc_ctx* c, uint64_t bytes) {
     HIPCHK(c, hipSetDevice(c->device));
     drain(c);
     free_workspaces(c);
+    unstage(c);
     if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
     if (!bytes) {                                         // the default budget of vc_submit
         size_t free_b = 0, total_b = 0;
@@ -1231,6 +1247,7 @@ int vc_release(vc_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     drain(c);
     free_workspaces(c);
+    unstage(c);
     if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
     return VC_OK;
 }
@@ -1505,7 +1522,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
 int vc_run(vc_ctx* c) {
     if (!c) return VC_ERR_ARG;
     Batch* bt = c->cur;
-    if (!bt || !bt->have) return fail(c, VC_ERR_STATE, "vc_run before vc_submit");
+    if (!bt || !bt->have) return fail(c, VC_ERR_STATE, "vc_run before vc_submit (or after vc_release / vc_reserve gave the staged batch's workspaces back)");
+    if (!c->have_ws) return fail(c, VC_ERR_STATE, "vc_run: the workspaces are gone; submit the batch again");
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = wait_batch(c, bt))) return rc;             // the same batch again: its last run must have left its buffers
@@ -1525,8 +1543,10 @@ int vc_run(vc_ctx* c) {
     { std::lock_guard<std::mutex> lk(c->qmu); alone = c->runq.empty(); }
     if (alone) {
         HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 8 * VC_STAT_WORDS, c->stream));
+#ifdef VC_EXPERIMENTS
         HIPCHK(c, hipMemsetAsync(c->d_pipe_abort, 0, 64, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_pipe_prof, 0, VC_PP_TOTAL * 8, c->stream));
+#endif
     }
     HIPCHK(c, hipMemsetAsync(b.status, 0, b.n_windows, c->stream));
     if (!bt->h_pre_status.empty()) HIPCHK(c, hipMemcpyAsync(b.status, bt->h_pre_status.data(), b.n_windows, hipMemcpyHostToDevice, c->stream));
@@ -1880,6 +1900,10 @@ int vc_debug_fwd_lab(vc_ctx* c, uint32_t layer, uint32_t reps, uint32_t flags, f
 // of chunk stream 0: out[0..VC_PC_N) counters, then per window {layer, job_end, job_type, npairs}
 int vc_debug_pipe_state(vc_ctx* c, uint32_t* out, uint32_t n) {
     if (!c || !out || !(c->cur && c->cur->have)) return VC_ERR_ARG;
+#ifndef VC_EXPERIMENTS
+    (void)n;
+    return fail(c, VC_ERR_ARG, "built without -DVC_EXPERIMENTS: no persistent pipeline");
+#else
     HIPCHK(c, hipSetDevice(c->device));
     sync_all(c);
     const Work& wk = c->works[c->cur->first_stream];
@@ -1904,15 +1928,20 @@ int vc_debug_pipe_state(vc_ctx* c, uint32_t* out, uint32_t n) {
         }
     }
     return VC_OK;
+#endif
 }
 
 // development: phase clocks of the persistent pipeline's waves over the last run (VC_PP_* order, ticks of 100 MHz / counts)
 int vc_debug_pipe_prof(vc_ctx* c, unsigned long long* out) {
     if (!c || !out) return VC_ERR_ARG;
+#ifndef VC_EXPERIMENTS
+    return fail(c, VC_ERR_ARG, "built without -DVC_EXPERIMENTS: no persistent pipeline");
+#else
     HIPCHK(c, hipSetDevice(c->device));
     sync_all(c);
     HIPCHK(c, hipMemcpy(out, c->d_pipe_prof, VC_PP_TOTAL * 8, hipMemcpyDeviceToHost));
     return VC_OK;
+#endif
 }
 
 int vc_get_stats(vc_ctx* c, vc_stats* s) {

@@ -1265,8 +1265,6 @@ struct VcFwdArgs {
     const uint32_t* redo_list;     // != nullptr: this launch re-runs the listed jobs with whole rows (the backtrack left the band)
     const uint32_t* redo_n;
     uint32_t fold;                 // 1: the launch is built for the two widest classes of the batch and takes every narrower sequence in the lower one
-    uint32_t all_hi;               // 1: every sequence of the launch runs in the launch's widest class (k_fwdn and its redo pass; the backtrack reads the
-                                   //   rows in that class: VcTraceArgs::cpl_lo)
     uint32_t lean;                 // classes of 32+ columns per lane build the row's match / mismatch profile on the fly (v_perm_b32 through a 4-entry table)
                                    //   instead of holding four profiles in 4 x CPL / 2 registers: possible when the batch holds A / C / G / T only and
                                    //   mismatch - gap == -1 (the selector's 0xFF constant).  bit 0: global alignments may, bit 1: local ones; otherwise
@@ -1358,6 +1356,11 @@ __device__ __forceinline__ int vc_packed_cell(const uint32_t* w, uint32_t cc, ui
     return (int)(short)an + (int)((b - an) & 0xFFu);
 }
 
+// Rows written by k_fwd_dt (vc_fwd_dt.h) are DOUBLY tilted: T''[i][j] = H[i][j] - (i + j) * g, kept as unsigned 16-bit numbers (job_type bit
+// VC_JOB_DT).  A reader turns a cell it has rebuilt with vc_packed_cell back into the singly tilted T the backtrack compares.
+#define VC_JOB_DT 8u
+__device__ __forceinline__ int vc_dt_cell(int v, uint32_t row, int g) { return (v & 0xFFFF) + (int)row * g; }
+
 // The forward DP works on the TILTED matrix T[i][j] = H[i][j] - j*g.  In that domain the horizontal
 // pass of sisd :347-349 is a plain prefix maximum (T[i][j] = max(T[i][j], T[i][j-1])), the vertical move
 // adds g, and the diagonal move adds (P[c][j] - g) -- folded into the profile once.  Since the row's
@@ -1400,7 +1403,7 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     // than two classes -- is built for the two widest classes of a batch and takes everything narrower in the lower of them: a lane
     // simply owns more columns than the sequence needs, the matrix is the same -- its backtrack reads the rows in the same class,
     // VcTraceArgs::cpl_lo.)
-    if ((PIPE || a.fold || a.all_hi) ? len > 64u * CPL : vc_cpl_for(len) != (uint32_t)CPL) return VC_FWD_NONE;
+    if ((PIPE || a.fold) ? len > 64u * CPL : vc_cpl_for(len) != (uint32_t)CPL) return VC_FWD_NONE;
     const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
     // NW or SW is fixed per instantiation (the caller looked at the layer, window.cpp:336-349): the row loop
     // then carries no alignment-type branches
@@ -1928,672 +1931,12 @@ VC_KL __global__ __launch_bounds__(64) VC_FWD_OCC void k_fwd(VcFwdArgs a) {
         const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
         uint32_t cls = CB;
         if (jb.k < ns) cls = vc_cpl_for((uint32_t)(a.b.seq_off[s0 + jb.k + 1] - a.b.seq_off[s0 + jb.k]));
-        if (!a.all_hi && (cls == (uint32_t)CA || (a.fold && cls < (uint32_t)CA))) { vc_fwd_any<CA, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb); return; }
+        if ((cls == (uint32_t)CA || (a.fold && cls < (uint32_t)CA))) { vc_fwd_any<CA, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb); return; }
     }
     vc_fwd_any<CB, RING, PACKED, KEPT, NWONLY>(a, ring_raw, jb);
 }
 
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop over sequences whose index is a compile-time constant in every instance.
-// (As `#pragma unroll` loops some of them stayed rolled -- the ones around inline assembly -- and acc[s][q] then lived in scratch memory:
-// ten dwords loaded and stored per DP row.)
-template <class F, int... I>
-__device__ __forceinline__ void vc_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void vc_static_for(F&& f) { vc_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-// ------------------------------------------------------------------------------------------------
-// k_fwdn: the re-alignment rounds, NS sequences of a window per wave.  Every sequence of a window is aligned to the same pruned graph
-// (window.cpp:329-372): same rows, same row records, same predecessors, same column 0.  A DP row of k_fwd is ~54 vector and ~50
-// scalar / branch instructions, and the SIMDs issue ~94 % of what they can: the scalar half -- record decode, flag
-// tests, ring slot arithmetic, loop control -- is paid once per row whatever the number of sequences, so a wave that carries NS sequences
-// through the row loop spends it once for all of them, and their independent lane scans fill each other's DPP wait states.  Restates the
-// same recurrence as vc_fwd_body (sisd_alignment_engine.cpp:118-254, 292-360), global alignments on byte-packed rows with the plain ring
-// and the banded store, every sequence in the launch's one width class (VcFwdArgs::all_hi; the backtrack reads the rows in that class,
-// VcTraceArgs::cpl_lo); a group with a sequence that cannot (a window with fewer sequences, one outside the envelope) goes through
-// vc_fwd_body in the same wave, one sequence after the other.
-// MEASURED (round 5, config C, 100 000 windows): bit-identical, and slower on the job -- 34.3 k (NS = 2) / 30.3 k (NS = 4) against 36.0 k
-// windows/s.  The re-alignment rounds are 12 % of the job's kernel time, so the scalar half saved is worth ~3 % at best; the one class for
-// the whole launch costs the 76 % of sequences that fit 512 columns a fifth more vector work; and with half the waves of twice the
-// registers the launch gets a smaller share of a machine it runs on beside the other streams' kernels.  Off by default (VC_MULTI).
-// ------------------------------------------------------------------------------------------------
-template <int CPL, int RING, int NS>
-__device__ __forceinline__ void vc_fwd_multi(const VcFwdArgs& a, uint32_t* ring_raw, const uint32_t slot, const uint32_t job0, const uint32_t k0) {
-    static_assert((RING & (RING - 1)) == 0 && CPL < 32, "plain ring, narrow classes");
-    constexpr int ND = CPL / 2, NDS = vc_nds(CPL);
-    constexpr uint32_t RS = RING * ND * 64;                   // dwords of one sequence's ring
-    const int lane = vc_lane();
-    const uint32_t w = a.w0 + slot;
-    const uint32_t s0 = a.b.win_seq_off[w];
-    const int m = a.m, n = a.n, g = a.g;
-    const uint32_t nrows = a.dp.nrows[slot];
-    const uint64_t nb = (uint64_t)slot * a.NC;
-    uint64_t so[NS]; uint32_t len[NS];
-    uint32_t lensum = 0;
-    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; { so[s] = a.b.seq_off[s0 + k0 + s]; len[s] = (uint32_t)(a.b.seq_off[s0 + k0 + s + 1] - so[s]); lensum += len[s]; } });
-    if (lane == 0) {
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; { a.job_type[job0 + s] = 1; a.tie_cnt[job0 + s] = 0; } });
-        unsigned long long* st = vc_stat_slot(a.stat);
-        atomicAdd(st + 0, (unsigned long long)nrows * lensum);
-        atomicAdd(st + 1, (unsigned long long)NS * nrows);
-    }
-    uint32_t pfA[NS][ND], pfC[NS][ND], pfG[NS][ND], pfT[NS][ND], sbp[NS][ND];
-    const int mt = m - g, nt = n - g;
-    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; {
-#pragma unroll
-        for (int q = 0; q < ND; ++q) {
-            const uint32_t i0 = lane * CPL + 2 * q, i1 = i0 + 1;
-            const uint32_t b0 = i0 < len[s] ? a.b.bases[so[s] + i0] : 0xFFu;
-            const uint32_t b1 = i1 < len[s] ? a.b.bases[so[s] + i1] : 0xFFu;
-            sbp[s][q] = b0 | (b1 << 16);
-            auto sc = [&](uint32_t x) { return ((uint32_t)((b0 == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)((b1 == x) ? mt : nt) << 16); };
-            pfA[s][q] = sc('A'); pfC[s][q] = sc('C'); pfG[s][q] = sc('G'); pfT[s][q] = sc('T');
-        }
-    } });
-    const uint32_t gg = pk_dup(g);
-    uint32_t band_ql[NS], lane_e[NS], c_e[NS];
-    int best[NS];
-    uint32_t best_row[NS];
-    const bool band = a.band != 0;
-    // the matrices, band rows and column 0 of the NS jobs lie one behind the other: job0 + s
-    uint32_t* const hrow00 = a.hmat + (uint64_t)job0 * a.hstride;
-    const uint64_t bstride = vc_band_job_dwords(a.hstride) * 4ull;      // bytes between the band rows of consecutive jobs
-    const char* const brow00 = reinterpret_cast<const char*>(a.bmat) + (uint64_t)job0 * bstride;
-    int16_t* const c0p_out0 = a.c0 + (uint64_t)job0 * a.NC;
-    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; {
-        band_ql[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_slope(len[s], nrows, CPL));
-        if (band && lane == 0) a.band_par[job0 + s] = band_ql[s];
-        lane_e[s] = (len[s] - 1) / CPL; c_e[s] = (len[s] - 1) % CPL;
-        best[s] = VC_INT_MIN; best_row[s] = 0;
-    } });
-    constexpr uint32_t TLB = NDS * 4u, TBB = VC_BAND_LANES * TLB;
-    static_assert(!VC_BAND_TILED, "row-major band rows");
-    uint32_t t_off = 0u - TBB;
-    unsigned long long t_mask[NS];
-    uint32_t t_lane[NS];
-    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; { t_mask[s] = 0; t_lane[s] = 0; } });
-    const uint32_t lane_tlb = (uint32_t)lane * TLB;
-    const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
-    uint32_t far_reads = 0;
-    // (one array per sequence, picked by the compile-time index: as one two-dimensional array the compiler kept the rows in scratch memory)
-    uint32_t acc0[ND], acc1[ND], acc2[ND], acc3[ND];
-#define VC_ACC_S (*(s == 0 ? &acc0 : s == 1 ? &acc1 : s == 2 ? &acc2 : &acc3))
-    int c0prev = 0, c0vec = 0;                                // column 0 depends on the graph only: one copy for all sequences
-    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S;
-#pragma unroll
-        for (int q = 0; q < ND; ++q) acc_s[q] = 0; });
-    uint4 myrec = make_uint4(0, 0, 0, 0), nextrec = make_uint4(0, 0, 0, 0);
-    if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
-    constexpr uint32_t rowdw = NDS * 64;
-    const uint32_t loff = (uint32_t)lane * NDS * 4u;
-    uint32_t srow = 0;
-
-    auto ring_slot_merge = [&](uint32_t rslot, uint32_t c0lane, int& c0m) __attribute__((always_inline)) {
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
-            const uint32_t* rp = ring_raw + s * RS + rslot * (ND * 64) + lane;
-            uint32_t hp[ND];
-#pragma unroll
-            for (int q = 0; q < ND; ++q) hp[q] = rp[q * 64];
-#pragma unroll
-            for (int q = 0; q < ND; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc_s[q]) : "v"(hp[q]));
-        } });
-        c0m = max(c0m, __builtin_amdgcn_readlane(c0vec, c0lane));
-    };
-    auto row_tail = [&](const uint32_t r0, const int c0m, const uint32_t i, const uint32_t ri) __attribute__((always_inline)) {
-        const uint32_t bi = (r0 >> 24) & 7u;
-        const int col0 = c0m + g;
-        uint32_t P[NS][ND];
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
-            const uint32_t left = (uint32_t)VC_DPP_SHR((int)acc_s[ND - 1], (int)((uint32_t)c0m << 16), 0x138, 0xF);
-#pragma unroll
-            for (int q = 0; q < ND; ++q) P[s][q] = __builtin_amdgcn_alignbit(acc_s[q], q == 0 ? left : acc_s[q - 1], 16);
-        } });
-        if (bi < 2) {
-            if (bi == 0) {
-                vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value;
-#pragma unroll
-                    for (int q = 0; q < ND; ++q) P[s][q] = pk_add(P[s][q], pfA[s][q]); });
-            } else {
-                vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value;
-#pragma unroll
-                    for (int q = 0; q < ND; ++q) P[s][q] = pk_add(P[s][q], pfC[s][q]); });
-            }
-        } else if (bi == 2) {
-            vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value;
-#pragma unroll
-                for (int q = 0; q < ND; ++q) P[s][q] = pk_add(P[s][q], pfG[s][q]); });
-        } else if (bi == 3) {
-            vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value;
-#pragma unroll
-                for (int q = 0; q < ND; ++q) P[s][q] = pk_add(P[s][q], pfT[s][q]); });
-        } else {
-            const uint32_t x = r0 & 0xFF;
-            vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value;
-#pragma unroll
-                for (int q = 0; q < ND; ++q)
-                    P[s][q] = pk_add(P[s][q], ((uint32_t)(((sbp[s][q] & 0xFFFFu) == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)(((sbp[s][q] >> 16) == x) ? mt : nt) << 16)); });
-        }
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
-#pragma unroll
-            for (int q = 0; q < ND; ++q) P[s][q] = pk_max(P[s][q], pk_add(acc_s[q], gg));
-            P[s][0] = pk_max_hi_with_lo(P[s][0]);
-#pragma unroll
-            for (int q = 1; q < ND; ++q) P[s][q] = pk_max_bcast_hi(pk_max_hi_with_lo(P[s][q]), P[s][q - 1]);
-        } });
-        // the lane scans of the sequences are independent: their DPP steps alternate, each filling the others' wait states
-        int sc[NS];
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = (int)P[s][ND - 1]; });
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x111, 0xF)); });
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x112, 0xF)); });
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x114, 0xF)); });
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x118, 0xF)); });
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x142, 0xA)); });
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; sc[s] = max(sc[s], VC_DPP_SHR(sc[s], VC_INT_MIN, 0x143, 0xC)); });
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
-            int carry = VC_DPP_SHR(sc[s], VC_INT_MIN, 0x138, 0xF);
-            carry = max(carry, (int)((uint32_t)col0 << 16));
-#pragma unroll
-            for (int q = 0; q < ND; ++q) acc_s[q] = pk_max_bcast_hi(P[s][q], (uint32_t)carry);
-        } });
-        // end cell (sisd :353-355): the first sink row with the best score
-        if (r0 & (VC_RF_SINK << 8)) {
-            vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
-                uint32_t hv = acc_s[0];
-#pragma unroll
-                for (int q = 1; q < ND; ++q) {               // (the copy through an empty asm keeps this a chain of selects: as plain code it was folded into one load at a
-                    uint32_t t = acc_s[q];                   //  run-time index, which put the whole row array into scratch memory)
-                    asm("" : "+v"(t));
-                    hv = (c_e[s] / 2 == (uint32_t)q) ? t : hv;
-                }
-                int v = (c_e[s] & 1) ? pk_hi(hv) : pk_lo(hv);
-                v = __builtin_amdgcn_readlane(v, lane_e[s]);
-                if (v > best[s]) { best[s] = v; best_row[s] = i; }
-            } });
-        }
-        c0prev = col0;
-        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(c0vec) : "s"(col0), "s"(ri) : "m0");
-        __builtin_amdgcn_wave_barrier();
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
-            uint32_t* wp = ring_raw + s * RS + (i & (RING - 1)) * (ND * 64) + lane;
-#pragma unroll
-            for (int q = 0; q < ND; ++q) wp[q * 64] = acc_s[q];
-        } });
-        // (from the row number, not from a counter carried round the loop: as a carried value the compiler took it for lane-dependent)
-        const bool newblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)((i - 1u) & (uint32_t)(VC_BAND_ROWS - 1))) == 0u;
-        t_off += TBB;
-        // (one instance per sequence with a compile-time index: as a loop the compiler left this part rolled -- it holds inline assembly --
-        // and then indexes acc / t_mask / t_lane at run time, i.e. keeps them in scratch memory)
-        auto store_seq = [&](auto S) __attribute__((always_inline)) {
-            constexpr int s = decltype(S)::value;
-            uint32_t (&acc_s)[ND] = VC_ACC_S;
-            uint32_t wv[NDS];
-            vc_pack_row<ND, NDS>(acc_s, wv);
-            if (!band || (r0 & (VC_RF_FULL << 8))) {
-                uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow00 + (uint64_t)s * a.hstride) + srow + loff);
-                if (NDS == 2) *reinterpret_cast<uint2*>(hr) = make_uint2(wv[0], wv[1]);
-                else if (NDS == 4) *reinterpret_cast<uint4*>(hr) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-                else if (NDS == 3) { struct __attribute__((packed, aligned(4))) u3 { uint32_t a, b, c; }; *reinterpret_cast<u3*>(hr) = u3{wv[0], wv[1], wv[2]}; }
-                else {
-#pragma unroll
-                    for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
-                }
-            }
-            if (band) {
-                if (newblock) {
-                    const uint32_t bt_ = ((i + VC_BAND_ROWS / 2u) * band_ql[s]) >> 16;
-                    constexpr uint32_t BLO = VC_BAND_LANES / 2 - 1, BHI = BLO + 64u - VC_BAND_LANES;
-                    uint32_t bs, bso;
-                    asm("s_max_u32 %0, %2, %3\n\ts_min_u32 %0, %0, %4\n\ts_sub_u32 %0, %0, %3\n\ts_mul_i32 %1, %0, %5"
-                        : "=&s"(bs), "=s"(bso) : "s"(bt_), "n"(BLO), "n"(BHI), "n"(TLB) : "scc");
-                    t_mask[s] = (unsigned long long)((1u << VC_BAND_LANES) - 1u) << bs;
-                    t_lane[s] = lane_tlb - bso;
-                }
-                const char* bp = brow00 + (uint64_t)s * bstride + t_off;
-                // (the exec mask of the store below must BE a scalar whatever the compiler thinks of it: an "s" operand is taken as it stands)
-                const unsigned long long tm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_mask[s] >> 32)) << 32) |
-                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t_mask[s]);
-                if (NDS == 3) {
-                    typedef uint32_t vc_u3 __attribute__((ext_vector_type(3)));
-                    const vc_u3 d = {wv[0], wv[1], wv[2]};
-                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx3 %1, %2, %3\n\ts_mov_b64 exec, -1\n\ts_nop 0" :: "s"(tm), "v"(t_lane[s]), "v"(d), "s"(bp) : "memory");
-                } else if (NDS == 2) {
-                    typedef uint32_t vc_u2 __attribute__((ext_vector_type(2)));
-                    const vc_u2 d = {wv[0], wv[1]};
-                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %1, %2, %3\n\ts_mov_b64 exec, -1" :: "s"(tm), "v"(t_lane[s]), "v"(d), "s"(bp) : "memory");
-                } else if (NDS == 4) {
-                    typedef uint32_t vc_u4 __attribute__((ext_vector_type(4)));
-                    const vc_u4 d = {wv[0], wv[1], wv[2], wv[3]};
-                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_mov_b64 exec, -1\n\ts_nop 0" :: "s"(tm), "v"(t_lane[s]), "v"(d), "s"(bp) : "memory");
-                } else {
-                    if ((t_mask[s] >> lane) & 1ull) {
-                        uint32_t* hr = reinterpret_cast<uint32_t*>(const_cast<char*>(bp) + t_lane[s]);
-#pragma unroll
-                        for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
-                    }
-                }
-            }
-        };
-        store_seq(std::integral_constant<int, 0>{});
-        if constexpr (NS > 1) store_seq(std::integral_constant<int, 1>{});
-        if constexpr (NS > 2) store_seq(std::integral_constant<int, 2>{});
-        if constexpr (NS > 3) store_seq(std::integral_constant<int, 3>{});
-        srow += rowdw * 4u;
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    for (uint32_t i0 = 1; i0 <= nrows; i0 += 64) {
-        myrec = nextrec;
-        {
-            const uint32_t r = i0 - 1 + 64 + lane;
-            if (r < nrows) nextrec = a.dp.frec[nb + r];
-        }
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, nrows - i0 + 1));
-        for (uint32_t ri = 0; ri < cnt; ++ri) {
-            const uint32_t i = i0 + ri;
-            const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
-            int c0m = c0prev;
-            if (!(r0 & (VC_RF_PLAIN << 8))) {
-                if (!(r0 & (VC_RF_PREV << 8))) {
-                    c0m = VC_INT_MIN;
-                    vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S;
-#pragma unroll
-                        for (int q = 0; q < ND; ++q) asm volatile("v_mov_b32 %0, %1" : "+v"(acc_s[q]) : "s"(0x80008000u)); });
-                }
-                const uint32_t fl = (r0 >> 8) & 0xFF, nq = (r0 >> 16) & 0xFF;
-                const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
-                const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
-                const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
-                const uint32_t nlist = (fl & VC_RF_OVF) ? r2 : nq;
-                for (uint32_t p = 0; p < nlist; ++p) {
-                    uint32_t delta;
-                    if (fl & VC_RF_OVF) {
-                        delta = ovfp[r1 + p];
-                        if ((fl & VC_RF_PREV) && delta == 1) continue;
-                    } else {
-                        const uint32_t wsel = p < 2 ? r1 : (p < 4 ? r2 : r3);
-                        delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
-                    }
-                    const uint32_t pr = i - delta;
-                    if (pr == 0) {                                             // the virtual row: H[0][j] = j*g, column 0: 0
-                        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S;
-#pragma unroll
-                            for (int q = 0; q < ND; ++q) { const uint32_t z = 0u; asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc_s[q]) : "v"(z)); } });
-                        c0m = max(c0m, 0);
-                    } else if (delta <= (uint32_t)RING) {
-                        ring_slot_merge((i - delta) & (RING - 1), (i - delta - 1u) & 63u, c0m);
-                    } else {
-                        __threadfence_block();                                  // my own earlier stores must have landed
-                        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; uint32_t (&acc_s)[ND] = VC_ACC_S; {
-                            const uint32_t* hr = hrow00 + (uint64_t)s * a.hstride + (uint64_t)(pr - 1) * (NDS * 64) + lane * NDS;
-                            uint32_t wv[NDS], hA[ND];
-#pragma unroll
-                            for (int t = 0; t < NDS; ++t) wv[t] = hr[t];
-                            vc_unpack_row<ND, NDS>(wv, hA);
-#pragma unroll
-                            for (int q = 0; q < ND; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc_s[q]) : "v"(hA[q]));
-                        } });
-                        far_reads += NS;
-                        int cA;
-                        if (delta <= 64) cA = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
-                        else cA = (int)__builtin_amdgcn_readfirstlane((int)c0p_out0[pr - 1]);
-                        c0m = max(c0m, cA);
-                    }
-                }
-            }
-            row_tail(r0, c0m, i, ri);
-        }
-        if ((uint32_t)lane < cnt) {
-            vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; c0p_out0[(uint64_t)s * a.NC + i0 - 1 + lane] = (int16_t)c0vec; });
-        }
-        __threadfence_block();
-    }
-    if (lane == 0 && far_reads) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
-    if (lane == 0) {
-        vc_static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int s = decltype(S_)::value; a.job_end[job0 + s] = (best_row[s] << 16) | len[s]; });
-    }
-}
-#undef VC_ACC_S
-
-// can sequence k of window slot take the multi-sequence body of class CPL?  (what vc_fwd_body's prologue asks, for a global alignment)
-template <int CPL>
-__device__ __forceinline__ bool vc_fwd_multi_ok(const VcFwdArgs& a, uint32_t slot, uint32_t k) {
-    const uint32_t w = a.w0 + slot;
-    if (a.b.status[w] != VC_WIN_OK) return false;
-    const uint32_t s0 = a.b.win_seq_off[w], ns = a.b.win_seq_off[w + 1] - s0;
-    if (k >= ns) return false;
-    const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k + 1] - a.b.seq_off[s0 + k]);
-    const uint32_t L = (uint32_t)(a.b.seq_off[s0 + 1] - a.b.seq_off[s0]);
-    if (!(k == 0 || vc_full_span(a.b.seq_begin[s0 + k], a.b.seq_end[s0 + k], L))) return false;
-    const uint32_t nrows = a.dp.nrows[slot];
-    return len > 0 && len <= 64u * CPL && nrows > 0 && !(a.dp.flags[slot] & 1u) && vc_int16_ok(a.m, a.n, a.g, nrows, CPL, true);
-}
-
-// wave p of a window takes its sequences k0 + NS p ... k0 + NS p + NS - 1, all in width class CPL (VcFwdArgs::all_hi)
-template <int CPL, int RING, int NS>
-VC_KL __global__ __launch_bounds__(64) void k_fwdn(VcFwdArgs a) {
-    __shared__ uint32_t ring_raw[NS * RING * (CPL / 2) * 64];
-    const uint32_t hp = (a.group + NS - 1u) / NS;
-    const uint32_t slot = blockIdx.x / hp, p = blockIdx.x % hp;
-    if (slot >= a.nslots) return;
-    const uint32_t job0 = slot * a.group + NS * p, k0 = a.k0 + NS * p;
-    const uint32_t have = min((uint32_t)NS, a.group - NS * p);           // sequences of the launch this wave is responsible for
-    bool all = have == (uint32_t)NS;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) all = all && vc_fwd_multi_ok<CPL>(a, slot, k0 + s);
-    if (all) { vc_fwd_multi<CPL, RING, NS>(a, ring_raw, slot, job0, k0); return; }
-    // one after the other, exactly as k_fwd would have run them
-#pragma unroll 1
-    for (uint32_t s = 0; s < have; ++s) {
-        VcJob jb; jb.job = job0 + s; jb.slot = slot; jb.k = k0 + s; jb.redo = false;
-        __syncthreads();
-        vc_fwd_any<CPL, RING, true, false, true>(a, ring_raw, jb);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_fwdh: the re-alignment rounds, TWO sequences of a window per wave, each on 32 lanes ("half geometry").  Where k_fwdn repeats the
-// vector half of a row per sequence, here every vector instruction serves both: lanes 0-31 hold sequence k, lanes 32-63 sequence k + 1,
-// a lane owns CPL columns of its own sequence (twice the columns per lane of the 64-lane class, so 7 instructions per pair of cells
-// as before), and what a row costs beyond its cells -- the lane scan, the shifts, the carry, the row's pack, the whole scalar half --
-// is paid once for the two.  The scan stops at the half boundary (no row_bcast:31 step) and lane 32 takes what lane 0 takes (column 0).
-// Stored rows: [32 lanes][NDS] whole, VC_BAND_LANES_H lanes around the diagonal banded; the job's type carries VC_JOB_HALF so that
-// the backtrack reads them in this geometry (vc_tracew_body).
-// MEASURED (round 5, config C): bit-identical; per sequence-row 54 vector instructions as before (the per-row overhead it shares is what
-// the doubled per-lane merges and the one width class for the launch cost) and 18 scalar ones instead of 50 -- and the same time: alone
-// on one stream k_fwd's launches take 348.6 against 345.8 ms per 16 384 windows, in the eight-stream job 35.1 against 36.1 k windows/s.
-// The re-alignment launches are bound by the VECTOR port; halving their scalar half buys nothing (as trimming the scalar side of k_fwd's
-// row tail bought nothing, NOTES.md).  Off by default (VC_MULTI=32).
-// ------------------------------------------------------------------------------------------------
-#define VC_BAND_LANES_H 8
-#define VC_JOB_HALF 4u          // job_type bit: rows stored in half geometry (32 lanes of 2 x the class's columns, VC_BAND_LANES_H band lanes)
-__device__ __forceinline__ uint32_t vc_band_start_g(uint32_t i, uint32_t ql, uint32_t bl, uint32_t ln) {      // vc_band_start for bl band lanes of ln
-    const uint32_t t = __umul24(i, ql) >> 16;
-    return min(max(t, bl / 2 - 1) - (bl / 2 - 1), ln - bl);
-}
-template <int CPL, int RING>
-__device__ __forceinline__ void vc_fwd_half(const VcFwdArgs& a, uint32_t* ring_raw, const uint32_t slot, const uint32_t job0, const uint32_t k0) {
-    static_assert((RING & (RING - 1)) == 0 && CPL < 32 && !VC_BAND_TILED, "plain ring, narrow classes, row-major band rows");
-    constexpr int ND = CPL / 2, NDS = vc_nds(CPL);
-    static_assert(NDS >= 4 && NDS <= 8, "stored row of 4..8 dwords per lane");
-    const int lane = vc_lane();
-    const uint32_t hs = (uint32_t)lane >> 5, hl = (uint32_t)lane & 31u;
-    const bool lane32 = lane == 32;
-    const uint32_t w = a.w0 + slot;
-    const uint32_t s0 = a.b.win_seq_off[w];
-    const int m = a.m, n = a.n, g = a.g;
-    const uint32_t nrows = a.dp.nrows[slot];
-    const uint64_t nb = (uint64_t)slot * a.NC;
-    const uint64_t so = a.b.seq_off[s0 + k0 + hs];                                   // my half's sequence
-    const uint32_t len = (uint32_t)(a.b.seq_off[s0 + k0 + hs + 1] - so);
-    const uint32_t len0 = (uint32_t)__builtin_amdgcn_readlane((int)len, 0), len1 = (uint32_t)__builtin_amdgcn_readlane((int)len, 32);
-    if (lane == 0) {
-        a.job_type[job0] = (uint8_t)(1u | VC_JOB_HALF); a.job_type[job0 + 1] = (uint8_t)(1u | VC_JOB_HALF);
-        a.tie_cnt[job0] = 0; a.tie_cnt[job0 + 1] = 0;
-        unsigned long long* st = vc_stat_slot(a.stat);
-        atomicAdd(st + 0, (unsigned long long)nrows * (len0 + len1));
-        atomicAdd(st + 1, 2ull * nrows);
-    }
-    uint32_t pfA[ND], pfC[ND], pfG[ND], pfT[ND], sbp[ND];
-    const int mt = m - g, nt = n - g;
-#pragma unroll
-    for (int q = 0; q < ND; ++q) {
-        const uint32_t i0 = hl * CPL + 2 * q, i1 = i0 + 1;
-        const uint32_t b0 = i0 < len ? a.b.bases[so + i0] : 0xFFu;
-        const uint32_t b1 = i1 < len ? a.b.bases[so + i1] : 0xFFu;
-        sbp[q] = b0 | (b1 << 16);
-        auto sc = [&](uint32_t x) { return ((uint32_t)((b0 == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)((b1 == x) ? mt : nt) << 16); };
-        pfA[q] = sc('A'); pfC[q] = sc('C'); pfG[q] = sc('G'); pfT[q] = sc('T');
-    }
-    const uint32_t gg = pk_dup(g);
-    const bool band = a.band != 0;
-    const uint32_t ql_v = vc_band_slope(len, nrows, CPL);
-    const uint32_t ql0 = (uint32_t)__builtin_amdgcn_readlane((int)ql_v, 0), ql1 = (uint32_t)__builtin_amdgcn_readlane((int)ql_v, 32);
-    if (band && hl == 0) a.band_par[job0 + hs] = ql_v;
-    const uint32_t le_v = (len - 1) / CPL, ce_v = (len - 1) % CPL;                   // end cell of my half: lane (inside the half) and column inside the lane
-    const uint32_t le0 = (uint32_t)__builtin_amdgcn_readlane((int)le_v, 0), le1 = 32u + (uint32_t)__builtin_amdgcn_readlane((int)le_v, 32);
-    int best0 = VC_INT_MIN, best1 = VC_INT_MIN;
-    uint32_t best_row0 = 0, best_row1 = 0;
-    // the matrices, band rows and column 0 of the two jobs lie one behind the other
-    const uint64_t bstride = vc_band_job_dwords(a.hstride) * 4ull;                    // bytes between the band rows of consecutive jobs
-    uint32_t* const hrow_l = a.hmat + (uint64_t)(job0 + hs) * a.hstride;             // (per lane: my half's job)
-    const char* const brow00 = reinterpret_cast<const char*>(a.bmat) + (uint64_t)job0 * bstride;
-    int16_t* const c0p_out0 = a.c0 + (uint64_t)job0 * a.NC;
-    constexpr uint32_t TLB = NDS * 4u, TBB = VC_BAND_LANES_H * TLB;
-    uint32_t t_off = 0u - TBB;
-    unsigned long long t_mask = 0;
-    uint32_t t_lane = 0;
-    const uint32_t lane_tlb = hl * TLB + hs * (uint32_t)bstride;
-    const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
-    uint32_t far_reads = 0;
-    uint32_t acc[ND];
-    int c0prev = 0, c0vec = 0;                                // column 0 depends on the graph only: one copy for both sequences
-#pragma unroll
-    for (int q = 0; q < ND; ++q) acc[q] = 0;
-    uint4 myrec = make_uint4(0, 0, 0, 0), nextrec = make_uint4(0, 0, 0, 0);
-    if ((uint32_t)lane < nrows) nextrec = a.dp.frec[nb + lane];
-    constexpr uint32_t rowdw = NDS * 32;                      // dwords of one sequence's whole row
-    const uint32_t loff = hl * NDS * 4u;
-    uint32_t srow = 0;
-
-    auto ring_slot_merge = [&](uint32_t rslot, uint32_t c0lane, int& c0m) __attribute__((always_inline)) {
-        const uint32_t* rp = ring_raw + rslot * (ND * 64) + lane;
-        uint32_t hp[ND];
-#pragma unroll
-        for (int q = 0; q < ND; ++q) hp[q] = rp[q * 64];
-#pragma unroll
-        for (int q = 0; q < ND; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc[q]) : "v"(hp[q]));
-        c0m = max(c0m, __builtin_amdgcn_readlane(c0vec, c0lane));
-    };
-    auto row_tail = [&](const uint32_t r0, const int c0m, const uint32_t i, const uint32_t ri) __attribute__((always_inline)) {
-        const uint32_t bi = (r0 >> 24) & 7u;
-        const int col0 = c0m + g;
-        uint32_t P[ND];
-        {
-            const uint32_t fill = (uint32_t)c0m << 16;
-            uint32_t left = (uint32_t)VC_DPP_SHR((int)acc[ND - 1], (int)fill, 0x138, 0xF);
-            left = lane32 ? fill : left;                                       // the first lane of the upper half starts a sequence, too
-#pragma unroll
-            for (int q = 0; q < ND; ++q) P[q] = __builtin_amdgcn_alignbit(acc[q], q == 0 ? left : acc[q - 1], 16);
-        }
-        if (bi < 2) {
-            if (bi == 0) {
-#pragma unroll
-                for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfA[q]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfC[q]);
-            }
-        } else if (bi == 2) {
-#pragma unroll
-            for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfG[q]);
-        } else if (bi == 3) {
-#pragma unroll
-            for (int q = 0; q < ND; ++q) P[q] = pk_add(P[q], pfT[q]);
-        } else {
-            const uint32_t x = r0 & 0xFF;
-#pragma unroll
-            for (int q = 0; q < ND; ++q)
-                P[q] = pk_add(P[q], ((uint32_t)(((sbp[q] & 0xFFFFu) == x) ? mt : nt) & 0xFFFFu) | ((uint32_t)(((sbp[q] >> 16) == x) ? mt : nt) << 16));
-        }
-#pragma unroll
-        for (int q = 0; q < ND; ++q) P[q] = pk_max(P[q], pk_add(acc[q], gg));
-        P[0] = pk_max_hi_with_lo(P[0]);
-#pragma unroll
-        for (int q = 1; q < ND; ++q) P[q] = pk_max_bcast_hi(pk_max_hi_with_lo(P[q]), P[q - 1]);
-        // the lane scan, inside each half: rows of 16 lanes, then row 0 -> row 1 and row 2 -> row 3; nothing crosses lane 31 | 32
-        int sc = (int)P[ND - 1];
-        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x111, 0xF));
-        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x112, 0xF));
-        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x114, 0xF));
-        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x118, 0xF));
-        sc = max(sc, VC_DPP_SHR(sc, VC_INT_MIN, 0x142, 0xA));
-        {
-            int carry = VC_DPP_SHR(sc, VC_INT_MIN, 0x138, 0xF);
-            carry = lane32 ? VC_INT_MIN : carry;
-            carry = max(carry, (int)((uint32_t)col0 << 16));
-#pragma unroll
-            for (int q = 0; q < ND; ++q) acc[q] = pk_max_bcast_hi(P[q], (uint32_t)carry);
-        }
-        // end cell (sisd :353-355): the first sink row with the best score, per half
-        if (r0 & (VC_RF_SINK << 8)) {
-            uint32_t hv = acc[0];
-#pragma unroll
-            for (int q = 1; q < ND; ++q) {                   // (a chain of selects; the empty asm keeps the compiler from folding it into one indexed load -> scratch)
-                uint32_t t = acc[q];
-                asm("" : "+v"(t));
-                hv = (ce_v / 2 == (uint32_t)q) ? t : hv;
-            }
-            const int v = (ce_v & 1) ? pk_hi(hv) : pk_lo(hv);
-            const int v0 = __builtin_amdgcn_readlane(v, le0), v1 = __builtin_amdgcn_readlane(v, le1);
-            if (v0 > best0) { best0 = v0; best_row0 = i; }
-            if (v1 > best1) { best1 = v1; best_row1 = i; }
-        }
-        c0prev = col0;
-        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(c0vec) : "s"(col0), "s"(ri) : "m0");
-        __builtin_amdgcn_wave_barrier();
-        {
-            uint32_t* wp = ring_raw + (i & (RING - 1)) * (ND * 64) + lane;
-#pragma unroll
-            for (int q = 0; q < ND; ++q) wp[q * 64] = acc[q];
-        }
-        const bool newblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)((i - 1u) & (uint32_t)(VC_BAND_ROWS - 1))) == 0u;
-        t_off += TBB;
-        uint32_t wv[NDS];
-        vc_pack_row<ND, NDS>(acc, wv);
-        if (!band || (r0 & (VC_RF_FULL << 8))) {
-            uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow_l) + srow + loff);
-#pragma unroll
-            for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
-        }
-        if (band) {
-            if (newblock) {                                   // the two bands of the next VC_BAND_ROWS rows, on the scalar side
-                constexpr uint32_t BLO = VC_BAND_LANES_H / 2 - 1, BHI = BLO + 32u - VC_BAND_LANES_H;
-                const uint32_t bt0 = ((i + VC_BAND_ROWS / 2u) * ql0) >> 16, bt1 = ((i + VC_BAND_ROWS / 2u) * ql1) >> 16;
-                uint32_t bs0, bso0, bs1, bso1;
-                asm("s_max_u32 %0, %2, %3\n\ts_min_u32 %0, %0, %4\n\ts_sub_u32 %0, %0, %3\n\ts_mul_i32 %1, %0, %5"
-                    : "=&s"(bs0), "=s"(bso0) : "s"(bt0), "n"(BLO), "n"(BHI), "n"(TLB) : "scc");
-                asm("s_max_u32 %0, %2, %3\n\ts_min_u32 %0, %0, %4\n\ts_sub_u32 %0, %0, %3\n\ts_mul_i32 %1, %0, %5"
-                    : "=&s"(bs1), "=s"(bso1) : "s"(bt1), "n"(BLO), "n"(BHI), "n"(TLB) : "scc");
-                t_mask = ((unsigned long long)((1u << VC_BAND_LANES_H) - 1u) << bs0) | ((unsigned long long)((1u << VC_BAND_LANES_H) - 1u) << (32u + bs1));
-                t_lane = lane_tlb - (hs ? bso1 : bso0);
-            }
-            const char* bp = brow00 + t_off;
-            // (the exec mask of the store below must BE a scalar whatever the compiler thinks of it: an "s" operand is taken as it stands)
-            const unsigned long long tm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_mask >> 32)) << 32) |
-                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t_mask);
-            typedef uint32_t vc_u4 __attribute__((ext_vector_type(4)));
-            const vc_u4 d = {wv[0], wv[1], wv[2], wv[3]};
-            // (two wait states between a store of more than 64 bits and a VALU write of its data registers: the s_nop)
-            if (NDS == 4) {
-                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_mov_b64 exec, -1\n\ts_nop 0" :: "s"(tm), "v"(t_lane), "v"(d), "s"(bp) : "memory");
-            } else if (NDS == 5) {
-                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %4\n\tglobal_store_dword %1, %3, %4 offset:16\n\ts_mov_b64 exec, -1\n\ts_nop 0"
-                             :: "s"(tm), "v"(t_lane), "v"(d), "v"(wv[NDS - 1]), "s"(bp) : "memory");
-            } else if (NDS == 6) {
-                typedef uint32_t vc_u2 __attribute__((ext_vector_type(2)));
-                const vc_u2 e = {wv[4], wv[NDS - 1]};
-                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %4\n\tglobal_store_dwordx2 %1, %3, %4 offset:16\n\ts_mov_b64 exec, -1\n\ts_nop 0"
-                             :: "s"(tm), "v"(t_lane), "v"(d), "v"(e), "s"(bp) : "memory");
-            } else {
-                if ((t_mask >> lane) & 1ull) {
-                    uint32_t* hr = reinterpret_cast<uint32_t*>(const_cast<char*>(bp) + t_lane);
-#pragma unroll
-                    for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
-                }
-            }
-        }
-        srow += rowdw * 4u;
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    for (uint32_t i0 = 1; i0 <= nrows; i0 += 64) {
-        myrec = nextrec;
-        {
-            const uint32_t r = i0 - 1 + 64 + lane;
-            if (r < nrows) nextrec = a.dp.frec[nb + r];
-        }
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, nrows - i0 + 1));
-        for (uint32_t ri = 0; ri < cnt; ++ri) {
-            const uint32_t i = i0 + ri;
-            const uint32_t r0 = __builtin_amdgcn_readlane(myrec.x, ri);
-            int c0m = c0prev;
-            if (!(r0 & (VC_RF_PLAIN << 8))) {
-                if (!(r0 & (VC_RF_PREV << 8))) {
-                    c0m = VC_INT_MIN;
-#pragma unroll
-                    for (int q = 0; q < ND; ++q) asm volatile("v_mov_b32 %0, %1" : "+v"(acc[q]) : "s"(0x80008000u));
-                }
-                const uint32_t fl = (r0 >> 8) & 0xFF, nq = (r0 >> 16) & 0xFF;
-                const uint32_t r1 = __builtin_amdgcn_readlane(myrec.y, ri);
-                const uint32_t r2 = __builtin_amdgcn_readlane(myrec.z, ri);
-                const uint32_t r3 = __builtin_amdgcn_readlane(myrec.w, ri);
-                const uint32_t nlist = (fl & VC_RF_OVF) ? r2 : nq;
-                for (uint32_t p = 0; p < nlist; ++p) {
-                    uint32_t delta;
-                    if (fl & VC_RF_OVF) {
-                        delta = ovfp[r1 + p];
-                        if ((fl & VC_RF_PREV) && delta == 1) continue;
-                    } else {
-                        const uint32_t wsel = p < 2 ? r1 : (p < 4 ? r2 : r3);
-                        delta = (p & 1) ? (wsel >> 16) : (wsel & 0xFFFF);
-                    }
-                    const uint32_t pr = i - delta;
-                    if (pr == 0) {                                             // the virtual row: H[0][j] = j*g, column 0: 0
-#pragma unroll
-                        for (int q = 0; q < ND; ++q) { const uint32_t z = 0u; asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc[q]) : "v"(z)); }
-                        c0m = max(c0m, 0);
-                    } else if (delta <= (uint32_t)RING) {
-                        ring_slot_merge((i - delta) & (RING - 1), (i - delta - 1u) & 63u, c0m);
-                    } else {
-                        __threadfence_block();                                  // my own earlier stores must have landed
-                        const uint32_t* hr = hrow_l + (uint64_t)(pr - 1) * rowdw + hl * NDS;
-                        uint32_t fw[NDS], hA[ND];
-#pragma unroll
-                        for (int t = 0; t < NDS; ++t) fw[t] = hr[t];
-                        vc_unpack_row<ND, NDS>(fw, hA);
-#pragma unroll
-                        for (int q = 0; q < ND; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(acc[q]) : "v"(hA[q]));
-                        far_reads += 2;
-                        int cA;
-                        if (delta <= 64) cA = __builtin_amdgcn_readlane(c0vec, (pr - 1) & 63);
-                        else cA = (int)__builtin_amdgcn_readfirstlane((int)c0p_out0[pr - 1]);
-                        c0m = max(c0m, cA);
-                    }
-                }
-            }
-            row_tail(r0, c0m, i, ri);
-        }
-        if ((uint32_t)lane < cnt) {
-            c0p_out0[i0 - 1 + lane] = (int16_t)c0vec;
-            c0p_out0[(uint64_t)a.NC + i0 - 1 + lane] = (int16_t)c0vec;
-        }
-        __threadfence_block();
-    }
-    if (lane == 0 && far_reads) atomicAdd(vc_stat_slot(a.stat) + 3, (unsigned long long)far_reads);
-    if (lane == 0) {
-        a.job_end[job0] = (best_row0 << 16) | len0;
-        a.job_end[job0 + 1] = (best_row1 << 16) | len1;
-    }
-}
-
-// wave p of a window takes its sequences k0 + 2p and k0 + 2p + 1, both in the 32-lane class of 2 x CPL columns per lane (VcFwdArgs::all_hi:
-// CPL is the launch's widest 64-lane class); a pair that cannot -- an odd one out, a sequence outside the envelope -- goes through vc_fwd_body
-// in the same wave, one after the other, in class CPL (its rows then carry no VC_JOB_HALF)
-template <int CPL, int RING>
-VC_KL __global__ __launch_bounds__(64) void k_fwdh(VcFwdArgs a) {
-    __shared__ uint32_t ring_raw[RING * CPL * 64];
-    const uint32_t hp = (a.group + 1u) / 2u;
-    const uint32_t slot = blockIdx.x / hp, p = blockIdx.x % hp;
-    if (slot >= a.nslots) return;
-    const uint32_t job0 = slot * a.group + 2u * p, k0 = a.k0 + 2u * p;
-    const uint32_t have = min(2u, a.group - 2u * p);
-    if (have == 2u && vc_fwd_multi_ok<CPL>(a, slot, k0) && vc_fwd_multi_ok<CPL>(a, slot, k0 + 1u)) { vc_fwd_half<2 * CPL, RING>(a, ring_raw, slot, job0, k0); return; }
-#pragma unroll 1
-    for (uint32_t s = 0; s < have; ++s) {
-        VcJob jb; jb.job = job0 + s; jb.slot = slot; jb.k = k0 + s; jb.redo = false;
-        __syncthreads();
-        vc_fwd_any<CPL, RING, true, false, true>(a, ring_raw, jb);
-    }
-}
+#include "vc_fwd_dt.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_fwd_wide: the general forward pass for alignments the packed-int16 kernel declines -- score range beyond int16
@@ -2864,9 +2207,11 @@ VC_KL __global__ void k_trace(VcTraceArgs a) {
     const uint32_t slot = job / a.group, k = a.cursor ? (a.cursor[slot] & 0xFFFFu) : a.k0 + job % a.group;
     const uint32_t w = a.w0 + slot;
     const uint64_t pj = a.cursor ? (uint64_t)slot : (uint64_t)slot * a.pair_group + (k - a.pair_k0);
-    const uint8_t type = a.job_type[job];
-    if (type == 255) return;
-    const bool wide = type == 2 || type == 3;                 // (4 and up: VC_JOB_HALF rows, k_tracew's)
+    const uint8_t type_raw = a.job_type[job];
+    if (type_raw == 255) return;
+    const bool dtj = (type_raw & VC_JOB_DT) != 0;             // doubly tilted rows (k_fwd_dt): see vc_dt_cell
+    const uint8_t type = (uint8_t)(type_raw & ~VC_JOB_DT);
+    const bool wide = type == 2 || type == 3;                 // (VC_JOB_DT rows: k_tracew's, or converted below)
     if (a.only_wide && !wide) return;
     if (a.b.status[w] != VC_WIN_OK) return;
     uint32_t* out = a.pairs + pj * a.PC;
@@ -2890,7 +2235,7 @@ VC_KL __global__ void k_trace(VcTraceArgs a) {
         if (wide) return col == 0 ? (nw ? wc0[r - 1] : 0) : wm[(uint64_t)(r - 1) * a.wcols + col - 1];
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
-        if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl);
+        if (packed) { const int v = vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl); return dtj ? vc_dt_cell(v, r, g) : v; }
         return (int)(short)hm[((uint64_t)(r - 1) * nd * 64 + (cc >> 1) * 64 + lc) * 2 + (cc & 1)];
     };
     uint32_t nout = 0;
@@ -2924,7 +2269,7 @@ VC_KL __global__ void k_trace(VcTraceArgs a) {
                                              : (int)(short)hm[((uint64_t)(rr - 1) * nd * 64 + (cw >> 1) * 64 + lc) * 2 + (cw & 1)];
                     const uint32_t bs = a.b.bases[so + j - 1];
                     const uint4 q0 = a.dp.rec[nb + rr - 1];
-                    int v0 = v0raw;
+                    int v0 = (dtj && packed) ? vc_dt_cell(v0raw, rr, g) : v0raw;
                     if (pr0 == 0 || j == 1 || wide) v0 = Hat(pr0, j - 1);
                     const int sc = ((bs == (rec.x & 0xFF)) ? m : n) - g;
                     if (Hij == v0 + sc) { pi_ = pr0; pj_ = j - 1; hv = v0; nrec = pr0 ? q0 : zero4; have_nrec = true; found = true; }
@@ -3015,9 +2360,10 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     auto tab_at = [&](uint32_t r) __attribute__((always_inline)) -> uint32_t { return ((uint32_t)tab[r >> 1] >> ((r & 1u) * 4u)) & 15u; };
     const uint32_t w = a.w0 + slot;
     const uint8_t type_raw = valid ? a.job_type[job] : (uint8_t)255;
-    // rows stored by k_fwdh: 32 lanes of twice the columns, VC_BAND_LANES_H band lanes (a redo pass stores 64-lane rows again)
-    const bool half = type_raw != 255 && (type_raw & VC_JOB_HALF) != 0 && !redo;
-    const uint8_t type = type_raw == 255 ? type_raw : (uint8_t)(type_raw & ~VC_JOB_HALF);
+    // VC_JOB_DT: the rows of this job are doubly tilted (k_fwd_dt, vc_fwd_dt.h) -- a cell read back is T'' = H - (row + col) * g as an unsigned
+    // 16-bit number; Tat() below hands out T = T'' + row * g, so everything behind it is the same walk
+    const bool dtj = type_raw != 255 && (type_raw & VC_JOB_DT) != 0;
+    const uint8_t type = type_raw == 255 ? type_raw : (uint8_t)(type_raw & ~VC_JOB_DT);
     valid = valid && type < 2;                                // 255: nothing to walk; 2, 3: k_fwd_wide's, walked by k_trace
     if (valid && a.b.status[w] != VC_WIN_OK) valid = false;
     if (!__any(valid)) return false;
@@ -3031,15 +2377,15 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     const uint32_t* hm32 = a.hmat + (uint64_t)(valid ? job : 0) * a.hstride;
     const uint16_t* hm = (const uint16_t*)hm32;
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
-    const uint32_t cpl = max(vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), a.cpl_lo) << (half ? 1 : 0), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
+    const uint32_t cpl = max(vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), a.cpl_lo), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
     const bool packed = a.packed != 0;
-    const uint32_t band_lanes = half ? (uint32_t)VC_BAND_LANES_H : (uint32_t)VC_BAND_LANES, row_lanes = half ? 32u : 64u;
+    constexpr uint32_t band_lanes = VC_BAND_LANES;
     // banded store: global alignments of a banded launch keep VC_BAND_LANES lanes per row around the rank diagonal
     const bool band = a.band != 0 && !redo && valid && type == 1;
     const uint32_t* bm32 = a.bmat + (uint64_t)(valid ? job : 0) * vc_band_job_dwords(a.hstride);
     const uint32_t band_ql = band ? a.band_par[job] : 0u;
     const uint32_t tile_rows = vc_band_tile_rows(nds ? nds : 3u), tile_magic = tile_rows > 1 ? 0xFFFFFFFFu / tile_rows + 1u : 0u;     // rows < 65536: the multiply-high divides exactly
-    const uint32_t blk_dw = (half ? (uint32_t)VC_BAND_LANES_H * nds * 4u : vc_band_block_bytes(nds ? nds : 3u)) / 4u, tile_dw = vc_band_tile_bytes(nds ? nds : 3u) / 4u;
+    const uint32_t blk_dw = vc_band_block_bytes(nds ? nds : 3u) / 4u, tile_dw = vc_band_tile_bytes(nds ? nds : 3u) / 4u;
     bool oob = false;                                          // this lane asked for a cell outside the band (its value is then meaningless)
     const uint32_t nrows = valid ? min(a.dp.nrows[slot], a.tab_rows) : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
@@ -3053,11 +2399,12 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
         if (band) {
             const uint32_t tb = vc_band_tile_of_row(r - 1, tile_rows, tile_magic), rin = r - 1 - tb * tile_rows;
             const uint32_t bl = lc - (VC_BAND_TILED ? vc_band_block_start(tb, tile_rows, band_ql)
-                                                    : vc_band_start_g(((r - 1) & ~(uint32_t)(VC_BAND_ROWS - 1)) + 1u + VC_BAND_ROWS / 2u, band_ql, band_lanes, row_lanes));
+                                                    : vc_band_row_start(r - 1, band_ql));
             if (bl >= band_lanes) { oob = true; return 0; }
-            return vc_packed_cell(bm32 + tb * blk_dw + bl * tile_dw + rin * nds, cc, cpl);
+            const int v = vc_packed_cell(bm32 + tb * blk_dw + bl * tile_dw + rin * nds, cc, cpl);
+            return dtj ? vc_dt_cell(v, r, g) : v;
         }
-        if (packed) return vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl);
+        if (packed) { const int v = vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl); return dtj ? vc_dt_cell(v, r, g) : v; }
         return (int)(short)hm[((uint64_t)(r - 1) * nd * 64 + (cc >> 1) * 64 + lc) * 2 + (cc & 1)];
     };
     const uint4 zero4 = make_uint4(0, 0, 0, 0);

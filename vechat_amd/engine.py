@@ -57,6 +57,10 @@ class HipContext:
         """vc_reserve: the workspaces' memory in one piece, now (0 = the default budget)."""
         self._chk(self.lib.vc_reserve(self.h, int(nbytes)), "vc_reserve")
 
+    def release(self):
+        """vc_release: workspaces (and a reservation) back to the device.  A staged batch that has not run can no longer be run -- submit it again."""
+        self._chk(self.lib.vc_release(self.h), "vc_release")
+
     def set_window_type(self, window_type):
         self.params.window_type = int(window_type)
         self._chk(self.lib.vc_set_window_type(self.h, int(window_type)), "vc_set_window_type")
