@@ -107,14 +107,14 @@ def valu_peak_now(device):
 
 def mix_peak(classes, khash):
     """The issue rate of k_fwd's own instruction mix: sum(n_i) / sum(n_i / rate_i) over the opcode classes of its row loop
-    (profiles/r5_valu_mix.json: histogram of the commonest row from the device ISA, tools/valu_mix.py), every class's rate measured
+    (profiles/r6_valu_mix.json: histogram of the commonest row from the device ISA, tools/valu_mix.py), every class's rate measured
     in this run.  -> (rate or None, detail)"""
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r5_valu_mix.json")))
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r6_valu_mix.json")))
     except Exception as e:
         return None, {"note": repr(e)}
     if mix.get("kernel_hash") != khash:
-        return None, {"note": f"profiles/r5_valu_mix.json was made for kernels {mix.get('kernel_hash')}, these are {khash}: not used"}
+        return None, {"note": f"profiles/r6_valu_mix.json was made for kernels {mix.get('kernel_hash')}, these are {khash}: not used"}
     n = mix["representative_row"]
     missing = [k for k in n if k not in classes]
     if missing:
@@ -419,7 +419,7 @@ def main():
         cal = valu_peak_now(local)
         peak_pk16, peak_src = cal["pk16"], cal["source"]
         peak_mix, mix_detail = mix_peak(cal["classes"], khash)
-        peak_now = peak_mix or peak_pk16
+        peak_now = peak_pk16                 # ONE denominator, always -- the packed-int16 issue rate measured in this run (rounds 2-4's); the mix-weighted view is frac_vs_mix
         # The forward DP keeps its predecessor rows in registers / LDS and stores a byte-packed band: it moves ~0.5 B per cell, an
         # eighth of SURVEY 8(d)'s 4 B/cell model, so the bound that holds is the instruction stream ("then the VALU
         # issue bound is the honest limiter and must be stated").  achieved = VALU wave-instructions of ALL kernels of a step
@@ -445,11 +445,11 @@ def main():
               "timing": "HIP events around every k_fwd launch on its own stream, inside the timed region (vc_params.profile = 2); the chunk streams "
                         "overlap, so launches run beside each other: busy_ms = time during which at least one k_fwd launch was running"}
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r5_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r6_hbm_traffic.json")))
             if tj.get("kernel_hash") != khash:
-                roof["counts_note"] = f"profiles/r5_hbm_traffic.json was measured for kernels {tj.get('kernel_hash')}, these are {khash}: not used"
+                roof["counts_note"] = f"profiles/r6_hbm_traffic.json was measured for kernels {tj.get('kernel_hash')}, these are {khash}: not used"
             else:
-                roof["counts_source"] = ("rocprofv3 --pmc passes over the same kernel sources (profiles/r5_hbm_traffic.json from profiles/r5*_pmc_counters.txt: "
+                roof["counts_source"] = ("rocprofv3 --pmc passes over the same kernel sources (profiles/r6_hbm_traffic.json from profiles/r6_pmc_counters.txt: "
                                          "SQ_INSTS_VALU, FETCH_SIZE, WRITE_SIZE, one counter group per pass) scaled by this run's windows / DP rows / cells")
                 wps = a.windows * world                                             # windows per step
                 job_valu = tj["valu_insts_per_window_all_kernels"] * wps
@@ -457,8 +457,9 @@ def main():
                 if peak_now:
                     roof["achieved"] = job_valu / (wall_s * 1e6 * simds)
                     roof["frac"] = roof["achieved"] / peak_now
-                    if peak_pk16:
-                        roof["frac_vs_pk16"] = roof["achieved"] / peak_pk16
+                    roof["frac_vs_pk16"] = roof["frac"]
+                    if peak_mix:
+                        roof["frac_vs_mix"] = roof["achieved"] / peak_mix
                 roof["_valu_per_window_by_config"] = tj.get("valu_insts_per_window_by_config", {})
                 # Second view, the one that explains why nothing moves this design by much any more: EVERY instruction the SQ counts (vector,
                 # scalar, branch, LDS, memory) of a step over the same time, against what a SIMD issues when vector and scalar instructions
@@ -544,7 +545,7 @@ def main():
                            "D_shard": short_config(local, 1002, 500, 64, 125000, capi.PACBIO, first=3 * 125000, check=256),
                            "E_shard": short_config(local, 1005, 1000, 128, 6250, capi.ONT, first=5 * 6250, check=256)}
         # the same roofline for the other shapes: VALU wave-instructions per window of configs E and W by their own PMC passes
-        # (profiles/r5_hbm_traffic.json), priced against the same peak (the mix is config C's: the wider classes spend a larger share
+        # (profiles/r6_hbm_traffic.json), priced against the same peak (the mix is config C's: the wider classes spend a larger share
         # of a row in the packed-int16 class, whose rate is the highest -- the fraction is, if anything, flattered by a few percent)
         pc = {}
         for name, v in (line["roofline"].get("_valu_per_window_by_config") or {}).items():

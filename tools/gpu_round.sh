@@ -2,7 +2,7 @@
 # One GPU-box call per measurement round: gpu tests, PMC passes (own runs, kernel-trace only) + VALU calibration -> traffic / count
 # files, THEN the bench line (its roofline reads those counts), then rocprofv3 kernel stats of the same command.
 # Everything lands in gpurun_out/$TAG/.   usage: tools/gpu_round.sh TAG [skip-tests]
-TAG=${1:-r5}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
+TAG=${1:-r6}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 if [ "$2" != "skip-tests" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
@@ -22,7 +22,7 @@ VC_PROFILE=ont VC_SEED=1005 VC_STATS_JSON=$O/pmc_stats_E.json timeout 900 rocpro
 VC_SEED=1007 VC_STATS_JSON=$O/pmc_stats_W.json timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pmcW -- python $R/tools/gpu_scale.py 512 12 3000 > $O/pmcW.log 2>&1
 $R/vechat_amd/lib/valu_peak.bin > $O/valu_peak.txt
 python $R/tools/make_traffic_json.py /tmp/pmc $O/pmc_stats.json $O/valu_peak.txt $O E=/tmp/pmcE:$O/pmc_stats_E.json W=/tmp/pmcW:$O/pmc_stats_W.json
-cp $O/r5_hbm_traffic.json $R/profiles/r5_hbm_traffic.json      # (on this box: the bench below prices its step against these counts)
+cp $O/r6_hbm_traffic.json $R/profiles/r6_hbm_traffic.json      # (on this box: the bench below prices its step against these counts)
 cd $R
 timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; tail -c 1500 $O/bench.json
 cd /tmp

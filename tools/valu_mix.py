@@ -4,7 +4,7 @@
   python tools/valu_mix.py [out.json]      (build container: needs hipcc; ~30 s)
 
 Compiles vc_api.hip for the device only (-S, the flags of __graft_entry__.build(), width classes 8 / 10 = config C), finds the
-dominant instantiation k_fwd<8, 10, 6, true, true, true>, takes its two row loops (one per width class: the region from the
+dominant instantiation k_fwd_dt<8, 10, 6, true>, takes its two row loops (one per width class: the region from the
 loop's header label to its last backward branch, inside the 64-row block loop) and classifies every vector-ALU instruction:
   pk16_max / pk16_add   v_pk_max_i16 / v_pk_add_u16 ... (the DP itself)     perm / alignbit   v_perm_b32 / v_alignbit_b32 (cell shift, row packing)
   dpp    any instruction with a DPP modifier (lane scan, shift)             lane   v_readlane / v_writelane / v_readfirstlane
@@ -17,7 +17,7 @@ with; the PMC count of VALU instructions per DP row scales it to the job."""
 import json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_Z5k_fwdILi8ELi10ELi6ELb1ELb1ELb1EEv9VcFwdArgs"
+KERNEL = "_Z8k_fwd_dtILi8ELi10ELi6ELb1EEv9VcFwdArgs"        # the build phase's forward kernel (round 6: doubly tilted rows, vc_fwd_dt.h)
 
 
 def cls(op, rest):
@@ -39,7 +39,7 @@ def cls(op, rest):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r5_valu_mix.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r6_valu_mix.json")
     with tempfile.TemporaryDirectory() as d:
         asm = os.path.join(d, "vc_api.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I", os.path.join(ROOT, "include"),
@@ -66,9 +66,17 @@ def main():
             outer.append((a, b))
         if len(outer) == 2:
             break
+    # the row loop of a body: the largest loop inside it whose header fetches the row's record word (v_readlane_b32 of the prefetched records) --
+    # round 6's kernel has one more level between the 64-row block loop and the rows (the band block of 8 rows)
+    def first_op(a):              # (the loop is rotated: its back edges go to the latch block that sits in front of the header)
+        for i in range(a, min(a + 12, len(body))):
+            m = re.match(r"\s+([a-z]\S+)", body[i])
+            if m and m.group(1).startswith("v_readlane"):
+                return m.group(1)
+        return ""
     rows = []
     for oa, ob in outer:
-        inner = [(a, b) for a, b in loops if oa < a and b <= ob]
+        inner = [(a, b) for a, b in loops if oa < a and b <= ob and first_op(a).startswith("v_readlane")]
         rows.append(max(inner, key=lambda x: x[1] - x[0]))
     static, rep = {}, {}
     n_blocks = 0
@@ -106,29 +114,36 @@ def main():
             if not last[0].startswith("s_branch") and k + 1 < len(blocks):
                 succ.append(k + 1)
             blk["succ"], blk["latch"] = succ, latch
-        # the cheapest way round the loop (by instruction count): the row whose only predecessor is the row above, with nothing extra to do
+        # the cheapest way round the loop (by instruction count) THAT RUNS THE DP: header -> the block with the last step of the lane scan
+        # (row_bcast:31) -> back to the header.  That is the row whose only predecessor is the row above, with nothing extra to do.  (The
+        # rotated loop also has trivial ways round that skip the row body: exits and error arms.)
         import heapq
-        dist, prev = {0: len(blocks[0]["ins"])}, {}
-        pq = [(dist[0], 0)]
-        best = None
-        while pq:
-            dcur, k = heapq.heappop(pq)
-            if dcur > dist.get(k, 1 << 30):
-                continue
-            if blocks[k]["latch"]:
-                best = k
-                break
-            for t in blocks[k]["succ"]:
-                nd = dcur + len(blocks[t]["ins"])
-                if nd < dist.get(t, 1 << 30):
-                    dist[t] = nd; prev[t] = k
-                    heapq.heappush(pq, (nd, t))
-        path = []
-        k = best
-        while k is not None:
-            path.append(k)
-            k = prev.get(k)
-        path.reverse()
+
+        def shortest(src, is_target):
+            dist, prev = {src: len(blocks[src]["ins"])}, {}
+            pq = [(dist[src], src)]
+            while pq:
+                dcur, k = heapq.heappop(pq)
+                if dcur > dist.get(k, 1 << 30):
+                    continue
+                if is_target(k) and k != src:
+                    p_, kk = [], k
+                    while kk is not None:
+                        p_.append(kk); kk = prev.get(kk)
+                    return p_[::-1]
+                for t in blocks[k]["succ"]:
+                    nd = dcur + len(blocks[t]["ins"])
+                    if nd < dist.get(t, 1 << 30):
+                        dist[t] = nd; prev[t] = k
+                        heapq.heappush(pq, (nd, t))
+            return None
+
+        scan = lambda k: any("row_bcast:31" in rest for _, rest in blocks[k]["ins"])
+        p1 = shortest(0, scan)
+        p2 = shortest(p1[-1], lambda k: blocks[k]["latch"]) if p1 else None
+        if not p1 or not p2:
+            raise SystemExit("valu_mix: no path through the lane scan found in the row loop")
+        path = p1 + p2[1:]
         h = {}
         for k in path:
             for op, rest in blocks[k]["ins"]:
@@ -139,7 +154,7 @@ def main():
     sys.path.insert(0, ROOT)
     from bench import kernel_hash
     tot = sum(rep.values())
-    res = {"kernel": "k_fwd<8, 10, 6, true, true, true>", "kernel_hash": kernel_hash(), "row_loops_lines": rows, "basic_blocks": n_blocks,
+    res = {"kernel": "k_fwd_dt<8, 10, 6, true>", "kernel_hash": kernel_hash(), "row_loops_lines": rows, "basic_blocks": n_blocks,
            "plain_row_paths": paths, "static": static, "representative_row": rep, "fractions": {k: v / tot for k, v in sorted(rep.items())},
            "classes": "each class is priced by the test class_<name> of tools/valu_peak.hip",
            "source": "tools/valu_mix.py (device ISA of vc_api.hip built with the product's flags, width classes 8 / 10)"}

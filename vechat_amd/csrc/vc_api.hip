@@ -392,7 +392,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
     if ((rc = dalloc(c, c->chunk_allocs, &wk->dp.nrows, CW)) || (rc = dalloc(c, c->chunk_allocs, &wk->dp.flags, CW)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rec, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.frec, CW * NC)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->dp.fie, CW * (NC + 4))) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->dp.fie, CW * (NC + 4) + 64)) ||      // (+ 64: k_tracew reads whole 8-byte chunks of a window's entries)
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||

@@ -223,9 +223,12 @@ __device__ __forceinline__ uint32_t vc_fwd_dt(const VcFwdArgs& a, uint32_t* ring
         for (int q = 0; q < ND; ++q) acc[q] = pku_max_bcast_hi(P[q], carry);
 
         if (!FAST && (r0 & (VC_RF_SINK << 8))) {                 // sisd:353-355
+            // (the empty asm keeps this a chain of selects: left to itself the compiler folds it into ONE indexed load of acc[c_e / 2], and an
+            // array that is indexed by a register lives in scratch memory -- every write of acc then became a scratch store, at 16 / 20 columns
+            // per lane, and config E ran 14 % slower than on k_fwd)
             uint32_t hv = acc[0];
 #pragma unroll
-            for (int q = 1; q < ND; ++q) hv = (c_e / 2 == (uint32_t)q) ? acc[q] : hv;
+            for (int q = 1; q < ND; ++q) { uint32_t t = acc[q]; asm("" : "+v"(t)); hv = (c_e / 2 == (uint32_t)q) ? t : hv; }
             uint32_t vv = (c_e & 1) ? (hv >> 16) : (hv & 0xFFFFu);
             vv = (uint32_t)__builtin_amdgcn_readlane((int)vv, (int)lane_e);
             const int v = (int)vv + (int)i * g;

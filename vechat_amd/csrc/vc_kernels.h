@@ -1479,6 +1479,14 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     // banded store: global alignments only (a local alignment may end and start anywhere), byte-packed rows only
     const bool band = NWT && PACKED && a.band && !redo;
     const char* const brow0 = reinterpret_cast<const char*>(a.bmat + (uint64_t)job * vc_band_job_dwords(a.hstride));
+    __amdgpu_buffer_rsrc_t brs;                                // the job's band rows behind a buffer descriptor (wave-uniform by construction)
+    {
+        const uintptr_t bb = reinterpret_cast<uintptr_t>(brow0);
+        const uint64_t bjb = vc_band_job_dwords(a.hstride) * 4ull;
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bb), hi_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bb >> 32));
+        brs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi_ << 32) | lo_), 0,
+                                                (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bjb < 0xFFFFF000ull ? bjb : 0xFFFFF000ull)), 0x00020000);
+    }
     const uint32_t band_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_slope(len, nrows, CPL));   // a scalar: the band of a row is worked out on the scalar side
     if (band && lane == 0) a.band_par[job] = band_ql;
     constexpr uint32_t TR = vc_band_tile_rows(NDS);
@@ -1631,7 +1639,13 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
 
         // ---- keep the row: registers (acc), LDS ring, HBM
         c0prev = col0;
-        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(c0vec) : "s"(col0), "s"(ri) : "m0");      // lane ri keeps this row's column 0
+        // lane ri keeps this row's column 0.  v_writelane_b32 takes ONE scalar register (constant bus), and both the value and the lane are
+        // scalars: the lane goes through m0, which the clobber list tells the compiler (this clang has no __builtin_amdgcn_writelane, and
+        // warns that m0 is "reserved" -- it is, the compiler keeps nothing there across an asm that names it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(c0vec) : "s"(col0), "s"(ri) : "m0");
+#pragma clang diagnostic pop
         // one wave per workgroup: LDS operations of a wave retire in order, so no s_barrier (and no
         // vmcnt(0) drain of the H stores) is needed -- only keep the compiler from reordering
         __builtin_amdgcn_wave_barrier();
@@ -1646,9 +1660,9 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
             uint32_t wv[NDS];
             vc_pack_row<ND, NDS>(acc, wv);
             auto put = [&](uint32_t* hr) __attribute__((always_inline)) {
-                if (NDS == 2) *reinterpret_cast<uint2*>(hr) = make_uint2(wv[0], wv[1]);
-                else if (NDS == 4) *reinterpret_cast<uint4*>(hr) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-                else if (NDS == 3) { struct __attribute__((packed, aligned(4))) u3 { uint32_t a, b, c; }; *reinterpret_cast<u3*>(hr) = u3{wv[0], wv[1], wv[2]}; }
+                if constexpr (NDS == 2) *reinterpret_cast<uint2*>(hr) = make_uint2(wv[0], wv[1]);
+                else if constexpr (NDS == 4) *reinterpret_cast<uint4*>(hr) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                else if constexpr (NDS == 3) { struct __attribute__((packed, aligned(4))) u3 { uint32_t a, b, c; }; *reinterpret_cast<u3*>(hr) = u3{wv[0], wv[1], wv[2]}; }
                 else {
 #pragma unroll
                     for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
@@ -1675,29 +1689,21 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
                     t_mask = (unsigned long long)((1u << VC_BAND_LANES) - 1u) << bs;
                     t_lane = lane_tlb - bso;
                 }
-                // the band lanes store under their own exec mask (all 64 lanes are active here: one wave, uniform control flow);
-                // the store is not visible to the compiler's vmcnt bookkeeping, which only makes its waits longer, never shorter
-                const char* bp = brow0 + t_off + t_rin * (NDS * 4u);
-                // (the s_nop: gfx950 wants two wait states between a store of more than 64 bits and a VALU write of its data registers; the
-                // compiler's hazard pass cannot see a store inside an asm block, and the instruction after it may well be the next row's pack)
-                if (NDS == 3) {
-                    typedef uint32_t vc_u3 __attribute__((ext_vector_type(3)));
-                    const vc_u3 d = {wv[0], wv[1], wv[2]};
-                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx3 %1, %2, %3\n\ts_mov_b64 exec, -1\n\ts_nop 0" :: "s"(t_mask), "v"(t_lane), "v"(d), "s"(bp) : "memory");
-                } else if (NDS == 2) {
-                    typedef uint32_t vc_u2 __attribute__((ext_vector_type(2)));
-                    const vc_u2 d = {wv[0], wv[1]};
-                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %1, %2, %3\n\ts_mov_b64 exec, -1" :: "s"(t_mask), "v"(t_lane), "v"(d), "s"(bp) : "memory");
-                } else if (NDS == 4) {
-                    typedef uint32_t vc_u4 __attribute__((ext_vector_type(4)));
+                // the band lanes store through a raw buffer descriptor over the job's band rows: a lane outside the band carries an offset beyond
+                // every range and the hardware drops it (tools/buffer_probe.hip).  (Until round 6: exec-mask writes around a store inside an asm
+                // block -- invisible to the compiler's hazard pass; a gfx950 store-data hazard there cost round 5 a day, NOTES.md.)
+                const uint32_t soff = t_off + t_rin * (NDS * 4u);
+                const uint32_t voff = ((t_mask >> lane) & 1ull) ? t_lane : 0x80000000u;
+                typedef uint32_t vc_u2 __attribute__((ext_vector_type(2)));
+                typedef uint32_t vc_u3 __attribute__((ext_vector_type(3)));
+                typedef uint32_t vc_u4 __attribute__((ext_vector_type(4)));
+                if constexpr (NDS == 2) { const vc_u2 d = {wv[0], wv[1]}; __builtin_amdgcn_raw_buffer_store_b64(d, brs, voff, soff, 0); }
+                else if constexpr (NDS == 3) { const vc_u3 d = {wv[0], wv[1], wv[2]}; __builtin_amdgcn_raw_buffer_store_b96(d, brs, voff, soff, 0); }
+                else {
                     const vc_u4 d = {wv[0], wv[1], wv[2], wv[3]};
-                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_mov_b64 exec, -1\n\ts_nop 0" :: "s"(t_mask), "v"(t_lane), "v"(d), "s"(bp) : "memory");
-                } else {
-                    if ((t_mask >> lane) & 1ull) {
-                        uint32_t* hr = reinterpret_cast<uint32_t*>(const_cast<char*>(bp) + t_lane);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, brs, voff, soff, 0);
 #pragma unroll
-                        for (int t = 0; t < NDS; ++t) hr[t] = wv[t];
-                    }
+                    for (int t = 4; t < NDS; ++t) __builtin_amdgcn_raw_buffer_store_b32(wv[t], brs, voff + 4u * t, soff, 0);
                 }
                 t_rin++;
             }
@@ -2331,7 +2337,12 @@ VC_KL __global__ void k_trace(VcTraceArgs a) {
 // short of is LDS x time (k_fwd alone fills the LDS of every CU; a backtrack wave that waits on memory with 9 KB of tables
 // keeps a forward wave out), and distances beyond 15 are rare
 __host__ __device__ inline uint32_t vc_tracew_tab_len(uint32_t max_rows) { return (max_rows + 2 + 7) & ~7u; }     // entries per table
-__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table, uint32_t tg = VC_TG) { return (shared_table ? 1u : tg) * vc_tracew_tab_len(max_rows) / 2u; }
+// Shared table (the alignments of a wave belong to one window: re-alignment rounds): the whole graph, 4 bits per row.  Otherwise (build phase:
+// every alignment of a wave walks a window of its own) each group keeps a SLIDING window of VC_TW_WIN rows around its position -- 128 bytes
+// instead of a table of the graph's height (1.1 KB at 2 240 rows; 9 KB per wave of eight alignments, which is what kept a second
+// backtrack wave off a CU whose LDS five forward waves per SIMD fill to 10 KB): the walk only ever looks at the rows just below it.
+#define VC_TW_WIN 256u       // rows of the sliding window (four blocks of 64; a power of two)
+__host__ __device__ inline uint32_t vc_tracew_lds_bytes(uint32_t max_rows, bool shared_table, uint32_t tg = VC_TG) { return shared_table ? vc_tracew_tab_len(max_rows) / 2u : tg * (VC_TW_WIN / 2u); }
 __device__ __forceinline__ int vc_row_shr1(int v, int first) {          // value of the lane to the left inside a 16-lane row
     return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false);
 }
@@ -2356,8 +2367,13 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     // first in-edge distance of row r (0: do not speculate).  In the re-alignment rounds the alignments of a
     // wave belong to one window (group % TG == 0) and share one table: a quarter of the LDS, more waves
     const bool shared_tab = a.shared_table != 0;
-    uint8_t* tab = smem + (shared_tab ? 0u : grp) * (vc_tracew_tab_len(a.tab_rows) / 2u);       // two entries per byte
-    auto tab_at = [&](uint32_t r) __attribute__((always_inline)) -> uint32_t { return ((uint32_t)tab[r >> 1] >> ((r & 1u) * 4u)) & 15u; };
+    uint8_t* tab = smem + (shared_tab ? 0u : grp * (VC_TW_WIN / 2u));                           // two entries per byte
+    uint32_t* const tab32 = reinterpret_cast<uint32_t*>(tab);
+    uint32_t wlo = 0;                                          // sliding window: its lowest row (a multiple of 64); rows [wlo, wlo + VC_TW_WIN) sit at row % VC_TW_WIN
+    auto tab_at = [&](uint32_t r) __attribute__((always_inline)) -> uint32_t {
+        if (shared_tab) return r <= a.tab_rows ? ((uint32_t)tab[r >> 1] >> ((r & 1u) * 4u)) & 15u : 0u;
+        return r >= wlo ? (tab32[(r & (VC_TW_WIN - 1u)) >> 3] >> ((r & 7u) * 4u)) & 15u : 0u;      // below the window: not speculated (the window follows)
+    };
     const uint32_t w = a.w0 + slot;
     const uint8_t type_raw = valid ? a.job_type[job] : (uint8_t)255;
     // VC_JOB_DT: the rows of this job are doubly tilted (k_fwd_dt, vc_fwd_dt.h) -- a cell read back is T'' = H - (row + col) * g as an unsigned
@@ -2445,22 +2461,37 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
             tab[k0] = (uint8_t)p0;
             if (2 * k1 <= nr) tab[k1] = (uint8_t)p1;
         }
-    } else {
-        const uint8_t* fie = a.dp.fie + (uint64_t)slot * VC_FIE_STRIDE(a.NC);
-        auto pair = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t {
-            if (2 * k > nrows) return 0u;
-            const uint32_t v = *reinterpret_cast<const uint16_t*>(fie + 2 * k);
-            return (v & 0xFu) | ((2 * k + 1 <= nrows ? (v >> 8) & 0xFu : 0u) << 4);
-        };
-        // (four blocks of entries per pass: the loads of a pass are in flight together)
-        for (uint32_t k0 = gl; walking && 2 * k0 <= nrows; k0 += 4 * TL) {
-            uint32_t e[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) e[u] = pair(k0 + u * TL);
-#pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) { const uint32_t k2 = k0 + u * TL; if (2 * k2 <= nrows) tab[k2] = (uint8_t)e[u]; }
-        }
     }
+    // sliding window (not shared): lane gl of the group fetches entries 8 gl .. 8 gl + 7 of a block of 64 rows (VcDp::fie, one byte per row
+    // number) and squeezes them into eight nibbles = the block's dword gl
+    // (the address is worked out where it is needed -- once per 64 rows walked: k_tracew sits at 110 VGPRs, and 112 is what fits beside five forward waves)
+    auto blk_fetch = [&](uint32_t b, uint32_t& lo, uint32_t& hi) __attribute__((always_inline)) {
+        const uint32_t r = 64u * b + 8u * gl;
+        lo = 0; hi = 0;
+        if (gl < 8u && r <= nrows) {                            // (eight lanes fill a block, whatever the group's width; the array is padded: the eight bytes of the last chunk exist)
+            const uint8_t* const fp = a.dp.fie + (uint64_t)slot * VC_FIE_STRIDE(a.NC) + r;
+            lo = *reinterpret_cast<const uint32_t*>(fp);
+            hi = *reinterpret_cast<const uint32_t*>(fp + 4);
+        }
+    };
+    auto blk_store = [&](uint32_t b, uint32_t lo, uint32_t hi) __attribute__((always_inline)) {
+        auto sq = [](uint32_t x) { x = (x | (x >> 4)) & 0x00FF00FFu; return (x | (x >> 8)) & 0xFFFFu; };     // four bytes (each < 16) -> four nibbles
+        const uint32_t r = 64u * b + 8u * gl;
+        // rows beyond the graph: 0 (never looked up)
+        uint32_t v = sq(lo) | (sq(hi) << 16);
+        if (r + 7u > nrows) v &= (r > nrows) ? 0u : (0xFFFFFFFFu >> ((7u - (nrows - r)) * 4u));
+        if (gl < 8u) tab32[(b & (VC_TW_WIN / 64u - 1u)) * 8u + gl] = v;
+    };
+    auto win_init = [&](uint32_t top) __attribute__((always_inline)) {           // the window ends at the block of row `top`
+        const uint32_t bt = top >> 6, b0 = bt >= 3u ? bt - 3u : 0u;
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) { lo[u] = hi[u] = 0; if (b0 + u <= bt) blk_fetch(b0 + u, lo[u], hi[u]); }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) if (b0 + u <= bt) blk_store(b0 + u, lo[u], hi[u]);
+        wlo = b0 * 64u;
+    };
+    if (!shared_tab && walking) win_init(end >> 16);
     __syncthreads();
     uint32_t gi = end >> 16, gj = end & 0xFFFF, gnout = 0, nspec_ok = 0, nrounds = 0;
     bool govf = false, gbroken = false;
@@ -2474,6 +2505,13 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     for (;;) {
         if (walking && (nw ? (gi == 0 && gj == 0) : (gT == -(int)gj * g))) walking = false;
         if (!__any(walking)) break;
+        // sliding window of first-in-edge entries: a position below it (a general step may jump any distance) starts it over there; a position
+        // in its lower half asks for the next block of 64 rows now -- the request travels with this round's loads and is stored behind them
+        uint32_t pf_lo = 0, pf_hi = 0;                                  // (an entry is < 16: bit 31 of pf_hi says "a block is on its way")
+        if (!shared_tab) {
+            if (walking && gi < wlo) win_init(gi);
+            if (walking && wlo > 0 && gi < wlo + VC_TW_WIN / 2u) { blk_fetch((wlo >> 6) - 1u, pf_lo, pf_hi); pf_hi |= 0x80000000u; }
+        }
         // ---- A: speculated positions (row my_i, column gj - gl), next row my_in
         uint32_t my_i = 0, my_in = 0, nspec = 0;
         {
@@ -2526,6 +2564,7 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
             if (f && gnout + f > a.PC) { govf = true; walking = false; f = 0; }
         }
         if (gl < f) out[gnout + gl] = (my_i << 16) | jk;
+        if (pf_hi >> 31) { blk_store((wlo >> 6) - 1u, pf_lo, pf_hi & 0x7FFFFFFFu); wlo -= 64u; }      // (this round's cells are in: the block asked for in front of them is, too)
         bool cont = false;
         {
             const uint32_t src = gbase + (f ? f - 1 : 0);
@@ -2627,8 +2666,9 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     return valid && gredo;
 }
 
+// (112 VGPRs: what is left on a SIMD beside five forward waves of 80)
 template <int TL>
-VC_KL __global__ __launch_bounds__(64) void k_tracew(VcTraceArgs a) {
+VC_KL __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(112))) void k_tracew(VcTraceArgs a) {
     VC_LATENCY_KERNEL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int TG = 64 / TL;
