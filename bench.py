@@ -233,6 +233,21 @@ def short_config(device, seed, L, D, n, profile, frac_partial=0.0, n_haplotypes=
     return out
 
 
+def files_to_fasta_large():
+    """The same path on a LARGE input (51 200 windows: 20 renamed copies of 128 simulated targets of 10 kb x 64 reads, 4 GB of files): the
+    device phase runs the slices of the batch queued behind each other in one context (HipContext.consensus_batched), and the host
+    phases in front of it -- parse, load, window assembly -- are what a command line adds to the device's own rate."""
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("gpu_files_e2e", os.path.join(ROOT, "tools", "gpu_files_e2e.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    with tempfile.TemporaryDirectory(prefix="vc_files_large_", dir="/tmp") as d:
+        res = mod.main(nt=128, tl=10000, depth=64, out=d, python_too=True, quiet=True, copies=20)
+    for k in ("batch", "text", "_keep"):
+        res.pop(k, None)
+    return res
+
+
 def files_to_fasta(params):
     """The path a user runs, from files: FASTQ + SAM on disk -> corrected FASTA text through the C++ readers (vc_io_*), the window
     builder, the device and the stitcher (tools/gpu_files_e2e.py), with the Python readers beside it (must give the same text) and
@@ -558,6 +573,8 @@ def main():
         line["roofline"].pop("_valu_per_window_by_config", None)
     if rank == 0 and world == 1 and not a.no_extras and not a.ab and cfg_name == "C":
         line["files_to_fasta"] = files_to_fasta(ctx_params)
+        if os.environ.get("VC_BENCH_LARGE_FILES", "1") != "0":
+            line["files_to_fasta_large"] = files_to_fasta_large()
     if rank == 0 and world == 1 and not a.no_cpu:
         cb, ref_out = cpu_baseline(batch, ctx_params, a.cpu_seconds)
         cons_np = cons_all.cpu().numpy()

@@ -171,6 +171,12 @@ int   vc_has_experiments(void);
  * allocations.  The counterpart of createCUDABatch sizing a batch's device memory at construction (mem_per_batch, src/cuda/cudapolisher.cpp:229-243):
  * a caller does it while its input is still being parsed.  Optional; without it vc_submit allocates what a batch needs. */
 int   vc_reserve(vc_ctx* ctx, uint64_t bytes);
+/* Changes the polishing parameters of a live context -- overload (mode), thresholds, prune rounds, trim, window type, scores: what differs
+ * between the two rounds of the driver (scripts/vechat:59-93: round 1 `vechat_racon -f -p -d D -s S`, round 2 `-f [-u]`).  Device,
+ * capacities, scratch budget and streams stay as created, workspaces stay where they are: one warm context serves both rounds and every
+ * --split chunk, where a process per invocation (scripts/vechat:371-393) pays the start-up each time.  A batch staged before the call
+ * must be submitted again. */
+int   vc_set_polish_params(vc_ctx* ctx, const vc_params* params);
 /* Gives the workspaces (and a reservation) back to the device; batch buffers and results stay.  The next vc_submit lays them out again.
  * For a caller that needs the memory for something else in between -- e.g. a second context for windows that overflowed. */
 int   vc_release(vc_ctx* ctx);

@@ -46,8 +46,10 @@ def noisy_copy(rng, t, sub=0.05, ins=0.05, dele=0.05):
     return out, cigar
 
 
-def main(nt=None, tl=None, depth=None, out=None, python_too=True, quiet=False):
-    """-> dict(windows_per_s, ...) of the C++-reader path (and the Python-reader path beside it)"""
+def main(nt=None, tl=None, depth=None, out=None, python_too=True, quiet=False, copies=1):
+    """-> dict(windows_per_s, ...) of the C++-reader path (and the Python-reader path beside it).
+    copies > 1: the files hold that many renamed copies of the nt simulated targets and their reads (a large input without simulating
+    every read: the work per window is what it is for distinct reads, the simulation is what would take minutes)."""
     nt = nt or (int(sys.argv[1]) if len(sys.argv) > 1 else 200)
     tl = tl or (int(sys.argv[2]) if len(sys.argv) > 2 else 10000)
     depth = depth or (int(sys.argv[3]) if len(sys.argv) > 3 else 64)
@@ -57,19 +59,27 @@ def main(nt=None, tl=None, depth=None, out=None, python_too=True, quiet=False):
     rng = np.random.default_rng(7)
     t0 = time.time()
     fq, sam, tg = os.path.join(out, "reads.fastq"), os.path.join(out, "ovl.sam"), os.path.join(out, "targets.fastq")
+    sim = []
+    for t in range(nt):
+        tseq = NT[rng.integers(0, 4, tl)]
+        rs = []
+        for d in range(depth):
+            r, cg = noisy_copy(rng, tseq)
+            rs.append((r.tobytes(), (rng.integers(8, 30, len(r)) + 33).astype(np.uint8).tobytes(), cg))
+        sim.append((tseq.tobytes(), rs))
     with open(fq, "wb") as f_r, open(sam, "w") as f_s, open(tg, "wb") as f_t:
-        for t in range(nt):
-            tseq = NT[rng.integers(0, 4, tl)]
-            tname = f"t{t}"
-            f_t.write(b"@" + tname.encode() + b"\n" + tseq.tobytes() + b"\n+\n" + b"5" * tl + b"\n")
-            for d in range(depth):
-                r, cg = noisy_copy(rng, tseq)
-                q = (rng.integers(8, 30, len(r)) + 33).astype(np.uint8).tobytes()
-                rn = f"r{t}_{d}"
-                f_r.write(b"@" + rn.encode() + b"\n" + r.tobytes() + b"\n+\n" + q + b"\n")
-                f_s.write(f"{rn}\t0\t{tname}\t1\t60\t{cg}\t*\t0\t0\t*\t*\n")
+        for c in range(copies):
+            sfx = f"x{c}" if copies > 1 else ""
+            for t, (tseq, rs) in enumerate(sim):
+                tname = f"t{t}{sfx}"
+                f_t.write(b"@" + tname.encode() + b"\n" + tseq + b"\n+\n" + b"5" * tl + b"\n")
+                for d, (r, q, cg) in enumerate(rs):
+                    rn = f"r{t}_{d}{sfx}"
+                    f_r.write(b"@" + rn.encode() + b"\n" + r + b"\n+\n" + q + b"\n")
+                    f_s.write(f"{rn}\t0\t{tname}\t1\t60\t{cg}\t*\t0\t0\t*\t*\n")
+    del sim
     mb = (os.path.getsize(fq) + os.path.getsize(sam) + os.path.getsize(tg)) / 1e6
-    say(f"generated {nt} targets x {tl} bp x {depth} reads: {mb:.0f} MB of files in {time.time() - t0:.1f} s", flush=True)
+    say(f"generated {nt} targets x {tl} bp x {depth} reads x {copies} copies: {mb:.0f} MB of files in {time.time() - t0:.1f} s", flush=True)
 
     keep = []
 
@@ -90,7 +100,7 @@ def main(nt=None, tl=None, depth=None, out=None, python_too=True, quiet=False):
         nw = batch.n_windows
         text = b""
         if dev:
-            t0 = time.time(); cons, status = ctx.consensus(batch); T["device (submit + run + collect)"] = time.time() - t0
+            t0 = time.time(); cons, status = ctx.consensus_batched(batch); T["device (submit + run + collect, slices queued behind each other)"] = time.time() - t0
             t0 = time.time()
             text = b"".join(b">" + n.encode() + b"\n" + d + b"\n" for n, d in wb.stitch(cons, status, drop_unpolished=True, fragment_correction=True))
             T["stitch"] = time.time() - t0
@@ -111,7 +121,7 @@ def main(nt=None, tl=None, depth=None, out=None, python_too=True, quiet=False):
         ctx.consensus(capi.synth_batch(capi.synth_cfg(1, 200, 8), 0, 64))
     t_nat, b_nat, rate_nat, T_nat = run(True, dev)
     res = {"windows_per_s": rate_nat, "windows": int(b_nat.n_windows), "input_mb": mb, "seconds_by_phase": {k: round(v, 4) for k, v in T_nat.items()},
-           "workload": f"{nt} targets x {tl} bp x {depth} reads as FASTQ + SAM files -> corrected FASTA text (C++ readers vc_io_*, window builder, device, stitching; "
+           "workload": f"{nt * copies} targets x {tl} bp x {depth} reads{' (' + str(copies) + ' renamed copies of ' + str(nt) + ' simulated ones)' if copies > 1 else ''} as FASTQ + SAM files -> corrected FASTA text (C++ readers vc_io_*, window builder, device, stitching; "
                        "one process, phases in series)", "batch": b_nat, "text": t_nat}
     if python_too:
         t_py, b_py, rate_py, _ = run(False, dev)

@@ -303,6 +303,11 @@ def load_hip():
         lib.vc_set_profile.restype = C.c_int
         lib.vc_set_pipeline.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
         lib.vc_set_pipeline.restype = C.c_int
+        try:                                  # (development: an A/B variant library built before an entry point was added still loads)
+            lib.vc_set_polish_params.argtypes = [vp, C.POINTER(VcParams)]
+            lib.vc_set_polish_params.restype = C.c_int
+        except AttributeError:
+            pass
         lib.vc_has_experiments.argtypes = []
         lib.vc_has_experiments.restype = C.c_int
         lib.vc_reserve.argtypes = [vp, C.c_uint64]; lib.vc_reserve.restype = C.c_int

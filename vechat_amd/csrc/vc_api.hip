@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <deque>
@@ -64,6 +65,7 @@ constexpr int kRingPruned = VC_RING_PRUNED;
 // (re-alignment rounds and the final alignment: a pruned graph is nearly a chain, four rows hold its non-adjacent predecessors, and the
 // smaller ring lets a fifth / sixth wave onto each SIMD)
 constexpr int kMaxStreams = 16;
+constexpr uint32_t kArenaSegs = 4;         // segments of the workspace arena (vc_ctx::arena): each a quarter of the budget, 24 GiB by default
 constexpr uint32_t kAutoStreamsMany = 8, kAutoStreamsFew = 4, kAutoStreamsFrom = 12288;   // windows from which a batch runs on the larger number of chunk streams
 constexpr uint32_t kTraceTabRows = 8188;           // rows covered by k_tracew's first-in-edge table (4 tables x 2 B x 8192 = 64 KB); later rows are walked without speculation
 constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may ask for (160 KB per CU minus room for static __shared__)
@@ -157,11 +159,18 @@ struct vc_ctx {
     std::vector<void*> allocs;          // lifetime of the context
     std::vector<void*> chunk_allocs;    // workspaces (re-created when capacities change)
     uint64_t chunk_bytes = 0;           // what they hold: counts as available when the next batch is planned
-    char* arena = nullptr;              // vc_reserve: one allocation the workspaces are carved from (a change of shape then costs no hipFree / hipMalloc)
-    size_t arena_bytes = 0, arena_used = 0;
+    // The arena: memory the workspaces are carved from, so that a batch of another shape costs no hipFree / hipMalloc.  Giving ~90 GiB back
+    // and asking for it again is what made a growing stream of batches stall for seconds (round 6, profiles/r6_cold_start.txt: hipMalloc
+    // 4.7 s behind a hipFree of 86 GiB -- the driver scrubs what it takes back; one hipMalloc of 96 GiB: 3.2 s, of 32 GiB: 0.000 s).  One
+    // in kArenaSegs SEGMENTS (each far below the size where hipMalloc turns slow); made by vc_reserve, or by the first large vc_submit.
+    struct ArenaSeg { char* p; size_t bytes, used; };
+    std::vector<ArenaSeg> arena;
+    size_t arena_bytes = 0;             // sum over the segments
+    uint32_t arena_cur = 0;             // segment the next workspace pieces come from (alloc_work of stream s: s % segments)
     bool ws_packed = false;             // the workspaces hold band space (the batch they were made for stores byte-packed rows)
     bool auto_streams = false;          // vc_params.n_streams was 0: vc_submit picks the chunk streams per batch
     uint32_t streams_made = 0;          // streams created (>= n_streams)
+    bool auto_arena = true;             // vc_submit makes the arena itself for the first large batch (development: VC_AUTO_ARENA=0)
     bool have_ws = false;               // workspaces exist (out of the arena or allocated piece by piece)
 
     Batch bt[2];
@@ -270,9 +279,13 @@ template <typename T>
 int dalloc(vc_ctx* c, std::vector<void*>& list, T** out, size_t n) {
     void* p = nullptr;
     size_t bytes = std::max<size_t>(n * sizeof(T), 256);
-    if (&list == &c->chunk_allocs && c->arena) {          // workspaces come out of the reserved arena while it lasts
-        const size_t at = (c->arena_used + 255) & ~(size_t)255;
-        if (at + bytes <= c->arena_bytes) { c->arena_used = at + bytes; *out = reinterpret_cast<T*>(c->arena + at); return VC_OK; }
+    if (&list == &c->chunk_allocs && !c->arena.empty()) { // workspaces come out of the arena while it lasts: the stream's own segment first
+        const size_t ns_ = c->arena.size();
+        for (size_t k = 0; k < ns_; ++k) {
+            vc_ctx::ArenaSeg& sg = c->arena[(c->arena_cur + k) % ns_];
+            const size_t at = (sg.used + 255) & ~(size_t)255;
+            if (at + bytes <= sg.bytes) { sg.used = at + bytes; *out = reinterpret_cast<T*>(sg.p + at); return VC_OK; }
+        }
     }
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return fail(c, VC_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -357,9 +370,45 @@ void unstage(vc_ctx* c) {
 }
 void free_workspaces(vc_ctx* c) {         // the chunk workspaces: what was allocated piece by piece, and the arena's bump pointer
     free_list(c->chunk_allocs);
-    c->arena_used = 0;
+    for (auto& sg : c->arena) sg.used = 0;
     c->chunk_bytes = 0;
     c->have_ws = false;
+}
+
+void free_arena(vc_ctx* c) {
+    for (auto& sg : c->arena) (void)hipFree(sg.p);
+    c->arena.clear();
+    c->arena_bytes = 0; c->arena_cur = 0;
+}
+// bytes = 0: the default budget (vc_params.scratch_bytes, or 60 % of the free memory up to 96 GiB).  One segment per chunk stream.
+int make_arena(vc_ctx* c, uint64_t bytes) {
+    free_arena(c);
+    if (!bytes) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        bytes = c->prm.scratch_bytes ? c->prm.scratch_bytes : std::min<uint64_t>((uint64_t)(free_b * 0.6), 96ull << 30);
+    }
+    const bool tm = getenv("VC_TIME_SUBMIT") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = now();
+    // four segments whatever the streams: a batch on four chunk streams lays a workspace into each, one on eight two, on sixteen four --
+    // a segment per stream of EIGHT halved what a four-stream batch (config E: 4 096 windows of 1 kb x 128) could use, and its rate with it
+    const uint32_t nseg = kArenaSegs;
+    const size_t each = std::max<size_t>((size_t)(bytes / nseg) & ~(size_t)0xFFFFF, (size_t)1 << 20);
+    for (uint32_t k = 0; k < nseg; ++k) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, each);
+        if (e != hipSuccess) { free_arena(c); return fail(c, VC_ERR_HIP, "hipMalloc(%zu) failed: %s", each, hipGetErrorString(e)); }
+        c->arena.push_back({(char*)p, each, 0});
+        c->arena_bytes += each;
+        // first touch now, not under the first batch (the driver hands out cleared memory and clears it when it has to): 17 ms per 96 GiB
+        if ((e = hipMemsetAsync(p, 0, each, c->stream)) != hipSuccess) { free_arena(c); return fail(c, VC_ERR_HIP, "clearing the reserved workspace failed: %s", hipGetErrorString(e)); }
+    }
+    const double t_1 = now();
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { free_arena(c); return fail(c, VC_ERR_HIP, "clearing the reserved workspace failed: %s", hipGetErrorString(e)); }
+    if (tm) fprintf(stderr, "make_arena: %u segments of %.1f GiB: hipMalloc + fill queued %.3f s, fills done %.3f s\n", nseg, each / 1073741824.0, t_1 - t_0, now() - t_1);
+    return VC_OK;
 }
 
 int alloc_graph(vc_ctx* c, VcGraph* g) {
@@ -396,7 +445,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, (c->ws_packed ? c->hmat_dwords / 4 + (VC_BAND_TILED ? c->hmat_dwords / 16 : 0) + (size_t)c->jobs_cap * VC_BAND_JOB_PAD_DWORDS : 0) + 64)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, (c->ws_packed ? c->hmat_dwords / 4 + (size_t)c->jobs_cap * VC_BAND_JOB_PAD_DWORDS : 0) + 64)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_band_par, (size_t)c->jobs_cap * 2)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_list, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_n, 4)) ||
@@ -1109,6 +1158,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
     if (const char* d = getenv("VC_DT")) c->dt = std::atoi(d) != 0;
+    if (const char* d = getenv("VC_AUTO_ARENA")) c->auto_arena = std::atoi(d) != 0;
 #ifdef VC_EXPERIMENTS
     if (const char* d = getenv("VC_PIPE")) c->pipe = std::atoi(d) != 0;
 #endif
@@ -1175,7 +1225,8 @@ void vc_destroy(vc_ctx* c) {
     c->qcv.notify_all();
     for (uint32_t s = 0; s < c->workers_made; ++s) if (c->workers[s].joinable()) c->workers[s].join();
     free_workspaces(c);
-    if (c->arena) (void)hipFree(c->arena);
+    for (auto& sg : c->arena) (void)hipFree(sg.p);
+    c->arena.clear();
     for (Batch& bt : c->bt) {
         for (auto& sl : bt.slots) if (sl.p) (void)hipFree(sl.p);
         for (hipEvent_t e : bt.done_ev) if (e) (void)hipEventDestroy(e);
@@ -1225,21 +1276,7 @@ int vc_reserve(vc_ctx* c, uint64_t bytes) {
     drain(c);
     free_workspaces(c);
     unstage(c);
-    if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
-    if (!bytes) {                                         // the default budget of vc_submit
-        size_t free_b = 0, total_b = 0;
-        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-        bytes = c->prm.scratch_bytes ? c->prm.scratch_bytes : std::min<uint64_t>((uint64_t)(free_b * 0.6), 96ull << 30);
-    }
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return fail(c, VC_ERR_HIP, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
-    // first touch now, not under the first batch: the driver hands out cleared memory and clears it when it has to
-    e = hipMemsetAsync(p, 0, bytes, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { (void)hipFree(p); return fail(c, VC_ERR_HIP, "clearing the reserved workspace failed: %s", hipGetErrorString(e)); }
-    c->arena = (char*)p; c->arena_bytes = bytes; c->arena_used = 0;
-    return VC_OK;
+    return make_arena(c, bytes);
 }
 
 int vc_release(vc_ctx* c) {
@@ -1248,7 +1285,26 @@ int vc_release(vc_ctx* c) {
     drain(c);
     free_workspaces(c);
     unstage(c);
-    if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+    free_arena(c);
+    return VC_OK;
+}
+
+// The polishing parameters of a live context: what differs between the rounds of a driver run (scripts/vechat:59-93: round 1 `-f -p -d D -s S`,
+// round 2 `-f [-u]`) -- overload, thresholds, prune rounds, trim, window type, scores.  Device, capacities, budget and streams stay as
+// created; workspaces and arena stay where they are (that is the point: one warm context for both rounds and every --split chunk).
+int vc_set_polish_params(vc_ctx* c, const vc_params* p) {
+    if (!c || !p) return VC_ERR_ARG;
+    if (p->mode != 0 && p->mode != 1) return fail(c, VC_ERR_ARG, "mode %d unknown (0 haplotype overload, 1 racon-linear overload)", p->mode);
+    if (p->num_prune == 0) return fail(c, VC_ERR_ARG, "num_prune must be >= 1");
+    if (p->gap >= 0 || p->sw_gap >= 0) return fail(c, VC_ERR_ARG, "gap penalties must be negative");
+    if (p->window_type != 0 && p->window_type != 1) return fail(c, VC_ERR_ARG, "window_type %d unknown", p->window_type);
+    drain(c);
+    for (Batch& b : c->bt) if (!b.ran || b.collected) b.have = false;       // (a batch staged under the old scores was planned for them)
+    if (c->cur && !c->cur->have) c->cur = nullptr;
+    c->prm.match = p->match; c->prm.mismatch = p->mismatch; c->prm.gap = p->gap;
+    c->prm.sw_match = p->sw_match; c->prm.sw_mismatch = p->sw_mismatch; c->prm.sw_gap = p->sw_gap;
+    c->prm.min_confidence = p->min_confidence; c->prm.min_support = p->min_support; c->prm.num_prune = p->num_prune;
+    c->prm.mode = p->mode; c->prm.trim = p->trim; c->prm.window_type = p->window_type;
     return VC_OK;
 }
 
@@ -1344,6 +1400,9 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     VcBatchDev& b = bt->b;
     b = VcBatchDev{};
     b.n_windows = nw;
+    const bool tm_s = getenv("VC_TIME_SUBMIT") != nullptr;          // development: phases of a submit on stderr
+    auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double ts_0 = now_s();
     uint32_t* d_wso; uint64_t* d_so; uint32_t *d_sb, *d_se; uint8_t *d_hq, *d_ba, *d_qu, *d_wf;
     if ((rc = salloc(c, bt, 0, &d_wso, nw + 1)) || (rc = salloc(c, bt, 1, &d_so, nseq + 1)) ||
         (rc = salloc(c, bt, 2, &d_sb, nseq)) || (rc = salloc(c, bt, 3, &d_se, nseq)) ||
@@ -1352,6 +1411,7 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         (rc = salloc(c, bt, 8, &b.win_avg, nw)) || (rc = salloc(c, bt, 9, &b.status, nw)) ||
         (rc = salloc(c, bt, 10, &b.cons_len, nw)) || (rc = salloc(c, bt, 11, &b.errinfo, nw)))
         return rc;
+    const double ts_1 = now_s();
     HIPCHK(c, hipMemcpyAsync(d_wso, hb->win_seq_off, (nw + 1) * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_so, hb->seq_off, (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_sb, hb->seq_begin, nseq * 4, hipMemcpyHostToDevice, c->stream));
@@ -1391,6 +1451,18 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         bt->lean = (pure && c->prm.mismatch - c->prm.gap == -1 ? 1u : 0u) | (pure && c->prm.sw_mismatch - c->prm.sw_gap == -1 ? 2u : 0u);
     }
 
+    if (tm_s) fprintf(stderr, "vc_submit(%u windows): batch buffers %.3f s, copies in + byte census %.3f s\n", nw, ts_1 - ts_0, now_s() - ts_1);
+    // A large batch of ordinary windows with no arena yet: make it now, once (vc_reserve's work; a caller that knows what is coming calls
+    // that while it still parses).  Every later batch, whatever its shape, is then laid out inside it -- a stream of batches that grows
+    // (the host-to-host loop starts small so that the device starts early) re-created ~90 GiB of workspaces twice on the way, seconds each.
+    // Small batches (tests, single targets) and windows beyond 2 kb (their chunk size IS the memory: section "big alignments" below)
+    // keep the piece-by-piece workspaces.
+    if (c->arena.empty() && c->auto_arena && nw >= 4096 && max_len <= 2048) {
+        drain(c);
+        free_workspaces(c);
+        for (Batch& ob : c->bt) if (&ob != bt && (!ob.ran || ob.collected)) ob.have = false;      // (a batch staged on the old workspaces cannot run on the new ones)
+        if ((rc = make_arena(c, 0))) return rc;
+    }
     // capacities
     uint32_t NC = c->prm.max_nodes ? c->prm.max_nodes : (uint32_t)std::min<uint64_t>(need_nodes, 59968);
     NC = (NC + 63) & ~63u;
@@ -1440,7 +1512,11 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     // (chunks of 4 096 windows) and at 86 % with 32 GiB (2 048), so holding more than that buys nothing (profiles/r3c_footprint.txt)
     uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : std::min<uint64_t>((uint64_t)(free_b * 0.6), 96ull << 30)) / S;
     const uint64_t budget_default = budget;
-    if (c->arena) budget = (c->arena_bytes - std::min<size_t>(c->arena_bytes, 1u << 20)) / S;      // vc_reserve: the arena IS the budget (less the padding between its pieces)
+    if (!c->arena.empty()) {                             // the arena IS the budget: a segment per stream (less the padding between its pieces)
+        const uint64_t per_seg = (S + c->arena.size() - 1) / c->arena.size();          // workspaces that share a segment
+        const uint64_t seg = c->arena[0].bytes - std::min<size_t>(c->arena[0].bytes, (size_t)per_seg << 20);
+        budget = seg / per_seg;
+    }
     const uint64_t rowd = 64ull * (bt->packed ? (uint64_t)vc_nds((int)cpl) : cpl / 2);      // dwords per stored row: byte-packed (NDS per lane) or raw int16 pairs
     const uint64_t per_slot_fixed = 2ull * (NC * (1 + 8 + 1 + 2ull * MA + 6 + 16) + EC * 12ull + 8) + (NC * (16ull + 16 + 2 + 2 + 16 + 2 + 1) + EC * 2ull + 36) +
                                     PC * 4ull + 4 + (uint64_t)max_nseq * (PC * 4ull + 4) + big;
@@ -1455,13 +1531,13 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const uint64_t per_job = NC * rowd * (bt->packed ? 5 : 4) + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
     // big alignments (3 kb reads: 58 MB of raw rows each; the int32 matrices of k_fwd_wide: 86 MB more): there the chunk size IS the
     // budget, and the 96-GiB cap would leave a few hundred alignments per stream -- take the 60 % whole
-    if (!c->prm.scratch_bytes && !c->arena && (per_slot_fixed + per_job) * 1024ull > budget) budget = std::max<uint64_t>(budget, (uint64_t)(free_b * 0.6) / S);
+    if (!c->prm.scratch_bytes && c->arena.empty() && (per_slot_fixed + per_job) * 1024ull > budget) budget = std::max<uint64_t>(budget, (uint64_t)(free_b * 0.6) / S);
     uint32_t CW = c->prm.chunk_windows ? c->prm.chunk_windows : 8192;
     CW = std::min(CW, (nw + S - 1) / S);
     if (CW == 0) CW = 1;
     // a reservation that cannot hold a sensible chunk of this batch does not bind the plan: the usual budget applies and what does
     // not fit the arena is allocated piece by piece
-    if (c->arena && (per_slot_fixed + per_job) * std::min(CW, 64u) > budget) budget = std::max(budget, budget_default);
+    if (!c->arena.empty() && (per_slot_fixed + per_job) * std::min(CW, 64u) > budget) budget = std::max(budget, budget_default);
     if ((per_slot_fixed + per_job) * CW > budget) {          // as many windows per chunk as the budget holds (whole waves of 64 where it can)
         CW = (uint32_t)std::max<uint64_t>(budget / (per_slot_fixed + per_job), 1);
         if (CW > 64) CW &= ~63u;
@@ -1475,8 +1551,13 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const bool same = have_ws && S == c->n_streams && c->ws_packed == bt->packed && c->wcols == wcols && c->MA == MA && c->NC == NC && c->EC == EC && c->CW >= CW && c->ws_cpl == cpl && c->PC == PC &&
                       c->big_ws_stride == big && c->max_nseq == max_nseq;
     if (!same) {
+        const bool tm = getenv("VC_TIME_SUBMIT") != nullptr;          // development: where a submit that re-creates the workspaces spends its time
+        auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_0 = now();
         drain(c);                           // the other batch may be running on the workspaces that go
+        const double t_1 = now();
         free_workspaces(c);
+        const double t_2 = now();
         c->n_streams = S;
         c->ws_packed = bt->packed; c->wcols = wcols; c->MA = MA; c->NC = NC; c->EC = EC; c->CW = CW; c->ws_cpl = cpl; c->PC = PC; c->group_max = group_max; c->max_nseq = max_nseq;
         c->ws_max_len = ws_max_len;
@@ -1488,11 +1569,15 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         c->hmat_dwords = (uint64_t)CW * group_max * NC * rowd;
         size_t f0 = 0, f1 = 0, tt = 0;
         (void)hipMemGetInfo(&f0, &tt);
-        for (uint32_t s = 0; s < S; ++s)
+        for (uint32_t s = 0; s < S; ++s) {
+            c->arena_cur = c->arena.empty() ? 0u : s % (uint32_t)c->arena.size();
             if ((rc = alloc_work(c, &c->works[s]))) return rc;
+        }
         (void)hipMemGetInfo(&f1, &tt);
         c->chunk_bytes = f0 > f1 ? f0 - f1 : 0;
         c->have_ws = true;
+        if (tm) fprintf(stderr, "vc_submit: workspaces re-created for %u windows: drain %.3f s, free %.3f s, allocate %.3f s (%.1f GiB on %u streams, CW %u)\n",
+                        nw, t_1 - t_0, t_2 - t_1, now() - t_2, c->chunk_bytes / 1073741824.0, S, CW);
     }
     b.cons_cap = NC;
     const bool wide_cls = bt->cpl >= 32;                 // (launch_fwd_t instantiates the forward kernel with the same numbers)

@@ -15,7 +15,9 @@
 
 #define VC_NONE16   0xFFFFu
 #define VC_INLINE_PRED 6       // predecessors stored inline in a row record
+#ifndef VC_BAND_LANES
 #define VC_BAND_LANES 16       // banded matrix store: lanes of a DP row that are written (around the rank diagonal); see vc_band_start
+#endif
 #define VC_MAXTIE   16         // NW end-cell ties remembered for the exact-rank resolver
 
 // row record flags

@@ -119,7 +119,7 @@ __device__ __forceinline__ uint32_t vc_fwd_dt(const VcFwdArgs& a, uint32_t* ring
 
     uint32_t* const hrow0 = a.hmat + (uint64_t)job * a.hstride;
     const bool band = uni((a.band && !redo) ? 1u : 0u) != 0;
-    // the job's band rows behind a buffer descriptor: [row][VC_BAND_LANES][NDS dwords]
+    // the job's band rows behind a buffer descriptor: [row][vc_band_lanes(CPL)][NDS dwords]
     const uint64_t bjd = vc_band_job_dwords(a.hstride);
     const uintptr_t bbase = reinterpret_cast<uintptr_t>(a.bmat + (uint64_t)job * bjd);
     const uint32_t bb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bbase), bb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bbase >> 32));
@@ -127,8 +127,8 @@ __device__ __forceinline__ uint32_t vc_fwd_dt(const VcFwdArgs& a, uint32_t* ring
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)bb_hi << 32) | bb_lo), 0, (int)bbytes, 0x00020000);
     const uint32_t band_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_slope(len, nrows, CPL));
     if (band && lane == 0) a.band_par[job] = band_ql;
-    constexpr uint32_t TLB = NDS * 4u, TBB = VC_BAND_LANES * TLB;           // a lane's bytes in a band row, a band row
-    static_assert(!VC_BAND_TILED, "row-major band rows");
+    constexpr uint32_t BL = vc_band_lanes(CPL);                                 // lanes of a band row in this width class (80 columns, at least 8 lanes)
+    constexpr uint32_t TLB = NDS * 4u, TBB = BL * TLB;                          // a lane's bytes in a band row, a band row
     const uint32_t lane_tlb = (uint32_t)lane * TLB;
     int16_t* const c0p_out = a.c0 + (uint64_t)job * a.NC;
     const uint16_t* const ovfp = a.dp.ovf + (uint64_t)slot * a.EC;
@@ -396,9 +396,9 @@ __device__ __forceinline__ uint32_t vc_fwd_dt(const VcFwdArgs& a, uint32_t* ring
         const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, nrows - i0 + 1));
         for (uint32_t rb = 0; rb < cnt; rb += VC_BAND_ROWS) {   // the band moves every VC_BAND_ROWS rows (vc_band_row_start)
             if (band) {
-                const uint32_t bs = vc_band_row_start(i0 - 1u + rb, band_ql);      // (scalar: row and slope are uniform)
+                const uint32_t bs = vc_band_row_start(i0 - 1u + rb, band_ql, BL);      // (scalar: row and slope are uniform)
                 const uint32_t bl = (uint32_t)lane - bs;
-                vband = bl < (uint32_t)VC_BAND_LANES ? lane_tlb - bs * TLB : 0x80000000u;
+                vband = bl < BL ? lane_tlb - bs * TLB : 0x80000000u;
             }
             const uint32_t re = min(rb + (uint32_t)VC_BAND_ROWS, cnt);
             for (uint32_t ri = rb; ri < re; ++ri) {

@@ -1195,45 +1195,40 @@ VC_KL __global__ __launch_bounds__(64) VC_RESOLVE_OCC void k_resolve(VcBatchDev 
 // backtrack that needs a cell outside the band gives up and puts its alignment on a redo list: k_fwd runs again for those
 // (whole rows), and the backtrack walks them from there.
 // Layout: [row][VC_BAND_LANES][NDS dwords]; the band lanes store under their own exec mask, worked out on the scalar side
-// (no per-row vector arithmetic for the band).  A TILED layout for the reader (-DVC_BAND_TILED=1: one 128-byte line holds the
-// stored form of ONE lane for 32 / NDS consecutive rows, so that a backtrack finds its next moves in the line it already
-// has) was built and measured in round 3: bytes fetched per move fall as intended, the backtrack gains 3 % and k_fwd loses
-// 5 % to the sixteen partial lines a row then writes -- the job is 1.5 % slower, so rows stay row-major.
+// (no per-row vector arithmetic for the band).  (A TILED layout for the reader -- one 128-byte line holding ONE lane's stored form for ten
+// consecutive rows -- was built and measured twice, rounds 3 and 4: the backtrack gains 3 %, k_fwd loses 5 - 12 % to the sixteen partial lines
+// a row then writes; the code is gone, NOTES.md has the numbers.)
 // Both kernels take the band of a row from the same number per alignment (VcFwdArgs::band_par): the slope of the diagonal.
 __device__ __forceinline__ uint32_t vc_band_slope(uint32_t len, uint32_t nrows, uint32_t cpl) {   // lanes per row, 16.16 fixed point
     return min((uint32_t)((((unsigned long long)len << 16) / nrows) / cpl), 0xFFFFFFu);
 }
-__device__ __forceinline__ uint32_t vc_band_start(uint32_t i, uint32_t ql) {
+// Width of the band, in lanes, for a width class: 80 columns, at least 8 lanes.  Round 6 (profiles/r6_ab_band_width.txt): rounds 3-5 kept 16
+// lanes and only ever tried MORE (24: - 5 %); fewer are faster -- config C 37.5 k (16) / 38.5 (12) / 39.2 (10) / 40.0 (8) / 38.2 (6) / 29.0 k
+// (4 lanes) windows/s: a row of 8 lanes is 96 bytes instead of 192 (k_fwd stores half, the backtrack finds 1.3 rows per 128-byte line
+// instead of 0.7), and the alignments that leave the band go from 0.14 % to 0.19 % (at 6 lanes: 0.6 %, and the catch-up rounds eat the
+// gain).  What the walk needs is a width in COLUMNS: config E (20 columns per lane) leaves 8 lanes as rarely as 16.
+__host__ __device__ constexpr uint32_t vc_band_lanes(uint32_t cpl) {
+    return cpl >= 10u ? 8u : (cpl >= 8u ? 10u : (cpl >= 6u ? 14u : (uint32_t)VC_BAND_LANES));
+}
+__device__ __forceinline__ uint32_t vc_band_start(uint32_t i, uint32_t ql, uint32_t bl) {
     // lane of the diagonal at row i (i <= rows, so i * ql < 2^22 * ... fits 32 bits; the 24-bit multiply is the fast one).  Any
     // function would do as long as k_fwd and the backtrack use the same: a band that misses the path only costs a redo
     const uint32_t t = __umul24(i, ql) >> 16;
-    return min(max(t, (uint32_t)(VC_BAND_LANES / 2 - 1)) - (VC_BAND_LANES / 2 - 1), 64u - VC_BAND_LANES);
+    return min(max(t, bl / 2u - 1u) - (bl / 2u - 1u), 64u - bl);
 }
-#ifndef VC_BAND_TILED
-#define VC_BAND_TILED 0        // development: 0 = row-major band rows [row][VC_BAND_LANES][NDS] (one row per block, a lane's NDS dwords per "tile")
-#endif
-__host__ __device__ constexpr uint32_t vc_band_tile_rows(uint32_t nds) { return VC_BAND_TILED ? 32u / nds : 1u; }      // rows per tile
-__host__ __device__ constexpr uint32_t vc_band_tile_bytes(uint32_t nds) { return VC_BAND_TILED ? 128u : nds * 4u; }   // one lane's tile
-__host__ __device__ constexpr uint32_t vc_band_block_bytes(uint32_t nds) { return VC_BAND_LANES * vc_band_tile_bytes(nds); }   // a row block: a tile per band lane
 #define VC_BAND_JOB_PAD_DWORDS (VC_BAND_LANES * 128u / 4u)
-__host__ __device__ inline uint64_t vc_band_job_dwords(uint64_t hstride) {       // a quarter of the whole rows (16 of 64 lanes), + the last, partial block
-    return hstride / 4 + (VC_BAND_TILED ? hstride / 16 : 0) + VC_BAND_JOB_PAD_DWORDS;                                // (tiles pad their rows to 128-byte lines)
+__host__ __device__ inline uint64_t vc_band_job_dwords(uint64_t hstride) {       // a quarter of the whole rows (room for 16 of 64 lanes), + padding
+    return hstride / 4 + VC_BAND_JOB_PAD_DWORDS;
 }
-__device__ __forceinline__ uint32_t vc_band_tile_of_row(uint32_t r1, uint32_t tile_rows, uint32_t tile_magic) {       // r1 = row - 1 < 65536
-    (void)tile_rows;
-    return VC_BAND_TILED ? __umulhi(r1, tile_magic) : r1;
-}
-// first band lane of row block tb (rows tb * TR + 1 ...): the diagonal at the block's middle
-__device__ __forceinline__ uint32_t vc_band_block_start(uint32_t tb, uint32_t tr, uint32_t ql) { return vc_band_start(tb * tr + 1u + tr / 2u, ql); }
-// Row-major band rows: the band MOVES only every VC_BAND_ROWS rows (a power of two) -- rows (b * VC_BAND_ROWS + 1 ...) share the lanes of the
-// diagonal at the block's middle.  The diagonal advances ~0.04 lanes per row, so a block of 8 rows shifts the band by a third of a lane at
-// most, and k_fwd works out a band (scalar multiply, clamps, exec mask, lane offsets) once per 8 rows instead of once per row.
+// The band MOVES only every VC_BAND_ROWS rows (a power of two) -- rows (b * VC_BAND_ROWS + 1 ...) share the lanes of the diagonal at the
+// block's middle.  The diagonal advances ~0.04 lanes per row, so a block of 8 rows shifts the band by a third of a lane at most, and
+// k_fwd works out a band (scalar multiply, clamps, lane offsets) once per 8 rows instead of once per row.
 #ifndef VC_BAND_ROWS
 #define VC_BAND_ROWS 8
 #endif
 static_assert(VC_BAND_ROWS >= 1 && (VC_BAND_ROWS & (VC_BAND_ROWS - 1)) == 0, "rows per band block: a power of two");
-__device__ __forceinline__ uint32_t vc_band_row_start(uint32_t r1, uint32_t ql) {        // r1 = row - 1
-    return vc_band_start((r1 & ~(uint32_t)(VC_BAND_ROWS - 1)) + 1u + VC_BAND_ROWS / 2u, ql);
+__device__ __forceinline__ uint32_t vc_band_row_start(uint32_t r1, uint32_t ql, uint32_t bl) {        // r1 = row - 1
+    return vc_band_start((r1 & ~(uint32_t)(VC_BAND_ROWS - 1)) + 1u + VC_BAND_ROWS / 2u, ql, bl);
 }
 
 struct VcFwdArgs {
@@ -1489,10 +1484,10 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     }
     const uint32_t band_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_slope(len, nrows, CPL));   // a scalar: the band of a row is worked out on the scalar side
     if (band && lane == 0) a.band_par[job] = band_ql;
-    constexpr uint32_t TR = vc_band_tile_rows(NDS);
-    constexpr uint32_t TBB = vc_band_block_bytes(NDS), TLB = vc_band_tile_bytes(NDS);
-    uint32_t t_rin = TR, t_off = 0u - TBB;                     // row inside the current block, byte offset of the block (scalars)
-    uint32_t b_rin = 0;                                        // row-major layout: rows left in the current band block (vc_band_row_start)
+    constexpr uint32_t BL = vc_band_lanes(CPL);                 // lanes of a band row in this width class
+    constexpr uint32_t TLB = NDS * 4u, TBB = BL * TLB;          // a lane's bytes in a band row, a band row
+    uint32_t t_off = 0u - TBB;                                 // byte offset of the band row in work (scalar)
+    uint32_t b_rin = 0;                                        // rows left in the current band block (vc_band_row_start)
     unsigned long long t_mask = 0;                             // lanes of the block's band
     uint32_t t_lane = 0;                                       // my byte offset inside a block: (lane - first band lane) * TLB
     const uint32_t lane_tlb = (uint32_t)lane * TLB;
@@ -1671,28 +1666,29 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
             // whole row: always without the band; with it only where a later row reads the row back (VC_RF_FULL)
             if (!band || (r0 & (VC_RF_FULL << 8))) put(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + srow + loff));
             if (band) {
-                bool newblock = t_rin == TR;             // tiled layout (development): a block of TR rows shares a band
-                if (newblock) { t_rin = 0; t_off += TBB; }
-                if (!VC_BAND_TILED) { newblock = b_rin == 0; if (newblock) b_rin = VC_BAND_ROWS; b_rin--; }      // row-major: the band moves every VC_BAND_ROWS rows
+                t_off += TBB;
+                const bool newblock = b_rin == 0;         // the band moves every VC_BAND_ROWS rows
+                if (newblock) b_rin = VC_BAND_ROWS;
+                b_rin--;
                 if (newblock) {                           // next row block: its band, on the scalar side
                     // vc_band_start of the block's middle row in scalar arithmetic (row and slope are uniform; the product stays below 2^23,
                     // so the plain multiply equals the 24-bit one the backtrack uses).  As vector code, once per row -- v_mul_u32_u24, a
                     // clamped subtract, a minimum, v_readfirstlane and a quarter-rate v_mul_lo_u32 for the lane offset -- this was 5 of a
                     // row's ~59 vector instructions
-                    const uint32_t bt_ = ((i + (VC_BAND_TILED ? TR / 2u : VC_BAND_ROWS / 2u)) * band_ql) >> 16;
+                    const uint32_t bt_ = ((i + VC_BAND_ROWS / 2u) * band_ql) >> 16;
                     // (in assembly: left to itself the compiler clamps with v_med3_u32 / a saturating v_sub -- only the vector ALU has those --
                     // and multiplies the lane offset with a quarter-rate v_mad_u64_u32)
-                    constexpr uint32_t BLO = VC_BAND_LANES / 2 - 1, BHI = BLO + 64u - VC_BAND_LANES;
+                    constexpr uint32_t BLO = BL / 2 - 1, BHI = BLO + 64u - BL;
                     uint32_t bs, bso;
                     asm("s_max_u32 %0, %2, %3\n\ts_min_u32 %0, %0, %4\n\ts_sub_u32 %0, %0, %3\n\ts_mul_i32 %1, %0, %5"
                         : "=&s"(bs), "=s"(bso) : "s"(bt_), "n"(BLO), "n"(BHI), "n"(TLB) : "scc");
-                    t_mask = (unsigned long long)((1u << VC_BAND_LANES) - 1u) << bs;
+                    t_mask = (unsigned long long)((1u << BL) - 1u) << bs;
                     t_lane = lane_tlb - bso;
                 }
                 // the band lanes store through a raw buffer descriptor over the job's band rows: a lane outside the band carries an offset beyond
                 // every range and the hardware drops it (tools/buffer_probe.hip).  (Until round 6: exec-mask writes around a store inside an asm
                 // block -- invisible to the compiler's hazard pass; a gfx950 store-data hazard there cost round 5 a day, NOTES.md.)
-                const uint32_t soff = t_off + t_rin * (NDS * 4u);
+                const uint32_t soff = t_off;
                 const uint32_t voff = ((t_mask >> lane) & 1ull) ? t_lane : 0x80000000u;
                 typedef uint32_t vc_u2 __attribute__((ext_vector_type(2)));
                 typedef uint32_t vc_u3 __attribute__((ext_vector_type(3)));
@@ -1705,7 +1701,6 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
 #pragma unroll
                     for (int t = 4; t < NDS; ++t) __builtin_amdgcn_raw_buffer_store_b32(wv[t], brs, voff + 4u * t, soff, 0);
                 }
-                t_rin++;
             }
         } else {
             // full 256-B rows on purpose: masking the lanes past the sequence end was measured SLOWER
@@ -2395,13 +2390,12 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
     const uint32_t cpl = max(vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), a.cpl_lo), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
     const bool packed = a.packed != 0;
-    constexpr uint32_t band_lanes = VC_BAND_LANES;
+    const uint32_t band_lanes = vc_band_lanes(cpl);             // (the width class decides: 80 columns, at least 8 lanes)
     // banded store: global alignments of a banded launch keep VC_BAND_LANES lanes per row around the rank diagonal
     const bool band = a.band != 0 && !redo && valid && type == 1;
     const uint32_t* bm32 = a.bmat + (uint64_t)(valid ? job : 0) * vc_band_job_dwords(a.hstride);
     const uint32_t band_ql = band ? a.band_par[job] : 0u;
-    const uint32_t tile_rows = vc_band_tile_rows(nds ? nds : 3u), tile_magic = tile_rows > 1 ? 0xFFFFFFFFu / tile_rows + 1u : 0u;     // rows < 65536: the multiply-high divides exactly
-    const uint32_t blk_dw = vc_band_block_bytes(nds ? nds : 3u) / 4u, tile_dw = vc_band_tile_bytes(nds ? nds : 3u) / 4u;
+    const uint32_t blk_dw = band_lanes * nds;                  // dwords of a band row
     bool oob = false;                                          // this lane asked for a cell outside the band (its value is then meaningless)
     const uint32_t nrows = valid ? min(a.dp.nrows[slot], a.tab_rows) : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
@@ -2413,11 +2407,9 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
         if (col == 0) return nw ? (int)c0[r - 1] : 0;
         const uint32_t ci = col - 1, lc = ci / cpl, cc = ci % cpl;
         if (band) {
-            const uint32_t tb = vc_band_tile_of_row(r - 1, tile_rows, tile_magic), rin = r - 1 - tb * tile_rows;
-            const uint32_t bl = lc - (VC_BAND_TILED ? vc_band_block_start(tb, tile_rows, band_ql)
-                                                    : vc_band_row_start(r - 1, band_ql));
+            const uint32_t bl = lc - vc_band_row_start(r - 1, band_ql, band_lanes);
             if (bl >= band_lanes) { oob = true; return 0; }
-            const int v = vc_packed_cell(bm32 + tb * blk_dw + bl * tile_dw + rin * nds, cc, cpl);
+            const int v = vc_packed_cell(bm32 + (r - 1) * blk_dw + bl * nds, cc, cpl);
             return dtj ? vc_dt_cell(v, r, g) : v;
         }
         if (packed) { const int v = vc_packed_cell(hm32 + (uint64_t)(r - 1) * nds * 64 + lc * nds, cc, cpl); return dtj ? vc_dt_cell(v, r, g) : v; }

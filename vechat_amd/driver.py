@@ -123,6 +123,16 @@ _FLOAT = re.compile(r"[0-9]+(\.[0-9]*)?([eE][-+]?[0-9]+)?|\.[0-9]+([eE][-+]?[0-9
 _INT = re.compile(r"[0-9]+")
 
 
+_SHARED = {}             # --in-process: the polisher's context, kept from one invocation to the next (vechat_amd.polish.main(shared=...))
+
+
+def close_shared():
+    ctx = _SHARED.pop("ctx", None)
+    if ctx is not None:
+        ctx.close()
+    _SHARED.clear()
+
+
 def polisher_command(a):
     if a.polisher:
         return a.polisher
@@ -159,7 +169,27 @@ def run_error_correction(a, sequences, chunk_targets, corrected_file, iteration,
         flags += f" -b --cudaaligner-batches {a.cudaaligner_batches} -c {a.cudapoa_batches}"
     if getattr(a, "keep_going", False) and not a.polisher:
         flags += " --keep-going"                               # (only our own polisher knows the switch)
-    _sh(f"{pol} {flags} {shlex.quote(sub_reads)} {shlex.quote(overlap)} {shlex.quote(chunk_targets)} >{shlex.quote(corrected_file)}", workdir)
+    if getattr(a, "in_process", False) and not a.polisher and a.gpus <= 1:
+        # the polisher inside this process, on ONE context that stays warm from invocation to invocation (vc_set_polish_params switches
+        # the round's parameters in place): scripts/vechat:371-393 starts a process per round and per --split chunk, and each start pays
+        # the device start-up and the workspaces again -- seconds that a small input consists of
+        import contextlib
+        from . import polish
+        argv = shlex.split(flags) + [sub_reads, overlap, chunk_targets]
+        print(f"[vechat_amd.driver] (in process) python -m vechat_amd.polish {' '.join(shlex.quote(x) for x in argv)} >{corrected_file}", file=sys.stderr)
+        if COMMAND_LOG is not None:
+            COMMAND_LOG.append(f"(in process) {flags} {sub_reads} {overlap} {chunk_targets} >{corrected_file}")
+        cwd = os.getcwd()
+        os.chdir(workdir)
+        try:
+            with open(corrected_file, "w") as fw, contextlib.redirect_stdout(fw):
+                rc = polish.main(argv, shared=_SHARED)
+        finally:
+            os.chdir(cwd)
+        if rc != 0:
+            raise RuntimeError(f"polisher failed ({rc}) in process: {flags}")
+    else:
+        _sh(f"{pol} {flags} {shlex.quote(sub_reads)} {shlex.quote(overlap)} {shlex.quote(chunk_targets)} >{shlex.quote(corrected_file)}", workdir)
     for f in os.listdir(workdir):
         if f.startswith("query_sequences.tmp."):
             os.remove(os.path.join(workdir, f))
@@ -216,6 +246,8 @@ def main(argv=None):
     ap.add_argument("--overlapper-r1", default=None, help="command template replacing the minimap2|awk|fpa pipeline of round 1")
     ap.add_argument("--overlapper-r2", default=None, help="... of round 2")
     ap.add_argument("--polisher", default=None, help="command replacing `python -m vechat_amd.polish`")
+    ap.add_argument("--in-process", action="store_true", help="run this package's polisher inside the driver process, on one device context that "
+                    "stays warm across the rounds and --split chunks (default: a process per invocation, as the reference's wrapper does)")
     ap.add_argument("--keep-going", action="store_true", help="handed to the polisher: a window the device cannot hold keeps its backbone "
                     "(unpolished) instead of ending the run with exit status 3; VC_KEEP_GOING=1 in the environment does the same")
     a = ap.parse_args(argv)
@@ -260,6 +292,7 @@ def main(argv=None):
                 os.remove(pth)
         for chunk in chunks:
             os.remove(chunk)
+    close_shared()
     shutil.move(corrected, a.outfile if os.path.isabs(a.outfile) else os.path.join(os.getcwd(), a.outfile))
     for f in os.listdir(workdir):                             # scripts/vechat:371-373, 395-396
         if (f.startswith("reads.corrected.tmp") and f.endswith(".fa")) or f.startswith("reads_chunk"):

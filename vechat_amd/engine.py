@@ -57,6 +57,18 @@ class HipContext:
         """vc_reserve: the workspaces' memory in one piece, now (0 = the default budget)."""
         self._chk(self.lib.vc_reserve(self.h, int(nbytes)), "vc_reserve")
 
+    def set_polish_params(self, **kw):
+        """vc_set_polish_params: overload (mode), thresholds, prune rounds, trim, window type and scores of this live context -- what
+        differs between the driver's rounds; device, capacities and streams stay as created, the workspaces stay warm."""
+        p = capi.VcParams.from_buffer_copy(self.params)
+        for k, v in kw.items():
+            if k not in ("mode", "min_confidence", "min_support", "num_prune", "trim", "window_type", "match", "mismatch", "gap",
+                         "sw_match", "sw_mismatch", "sw_gap"):
+                raise ValueError(f"{k} is fixed at vc_create")
+            setattr(p, k, v)
+        self._chk(self.lib.vc_set_polish_params(self.h, C.byref(p)), "vc_set_polish_params")
+        self.params = p
+
     def release(self):
         """vc_release: workspaces (and a reservation) back to the device.  A staged batch that has not run can no longer be run -- submit it again."""
         self._chk(self.lib.vc_release(self.h), "vc_release")
@@ -136,6 +148,38 @@ class HipContext:
         for i in range(s.n_classes):
             d["kernels"][s.names[i].value.decode()] = dict(ms=float(s.ms[i]), launches=int(s.launches[i]), busy_ms=float(s.busy_ms[i]))
         return d
+
+    def consensus_batched(self, batch: capi.Batch, batch_windows=32768, first=8192, retry_overflow=True):
+        """The loop of include/vechat_hip.h over one large batch: slices are queued behind each other in this context -- the copy-in of slice
+        i + 1 and the copy-out of slice i - 1 run while slice i computes (the reference's accelerated polisher fills the next batch while one
+        computes, src/cuda/cudapolisher.cpp:246-277).  A small first slice starts the device early.  Same bytes as consensus(); windows
+        that outgrow the capacity estimate are retried the same way."""
+        n = batch.n_windows
+        if n <= first + batch_windows // 2:
+            return self.consensus(batch, retry_overflow=retry_overflow)
+        sizes = [first]
+        rem = (n - first) % batch_windows
+        if rem:
+            sizes.append(rem)                   # the odd remainder early (it runs beside full slices), full slices to the end
+        sizes += [batch_windows] * ((n - sum(sizes)) // batch_windows)
+        cuts = [0]
+        for k in sizes:
+            cuts.append(cuts[-1] + k)
+        parts = [batch.slice(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        outs = []
+        self.submit(parts[0]); self.run()
+        for i in range(1, len(parts)):
+            self.submit(parts[i]); self.run()
+            outs.append(self.collect())
+        outs.append(self.collect())
+        cons = [x for o in outs for x in o[0]]
+        status = np.concatenate([o[1] for o in outs])
+        over = [w for w in range(n) if int(status[w]) == capi.VC_WIN_OVERFLOW]
+        if retry_overflow and over:
+            c2, s2 = self.consensus(batch.select(over), retry_overflow=True)
+            for k, w in enumerate(over):
+                cons[w], status[w] = c2[k], s2[k]
+        return cons, status
 
     def consensus(self, batch: capi.Batch, retry_overflow=True):
         """submit + run + collect.  Windows whose graph outgrew the capacity estimate come back as

@@ -40,7 +40,7 @@ def target_cost(index, overlaps):
     return cost
 
 
-def main(argv=None):
+def main(argv=None, shared=None):
     ap = argparse.ArgumentParser(prog="python -m vechat_amd.polish", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("sequences"); ap.add_argument("overlaps"); ap.add_argument("targets")
     ap.add_argument("-p", "--haplotype", action="store_true", help="haplotype-aware (variation graph) correction")
@@ -79,17 +79,28 @@ def main(argv=None):
     # (vc_io_target_cost / vc_io_rank_names) and then loads only its own targets and the reads their overlaps mention.  The Python
     # readers (VC_PY_PARSERS=1; MHAP in a multi-GPU run: its records name sequences by file position) give the same records
     # (tests/test_seqio.py) and remain as the second restatement.
-    native = native_parsers() and not (distributed and str(a.overlaps).split(".gz")[0].endswith(".mhap"))
+    native = native_parsers() and not (distributed and str(a.overlaps).endswith((".mhap", ".mhap.gz")))      # (the readers' own test of the format, vc_io.cpp / seqio.py)
     native_targets = None
     ctx_kw = dict(device=device, mode=0 if a.haplotype else 1, min_confidence=a.min_confidence, min_support=a.min_support,
                   num_prune=a.num_prune, match=a.match, mismatch=a.mismatch, gap=a.gap, trim=0 if a.no_trimming else 1,
                   max_nodes=a.max_nodes, n_streams=a.streams)
+    # shared: the driver's --in-process mode keeps ONE context for every invocation of a run (both rounds, every --split chunk); its
+    # polishing parameters are switched in place (vc_set_polish_params) where they differ, creation-time settings must agree
+    fixed_kw = dict(device=device, max_nodes=a.max_nodes, n_streams=a.streams)
+    soft_kw = {k: v for k, v in ctx_kw.items() if k not in fixed_kw}
+    reuse = None
+    if shared is not None and not distributed and shared.get("ctx") is not None:
+        if shared.get("fixed") == fixed_kw:
+            reuse = shared["ctx"]
+        else:
+            shared["ctx"].close(); shared["ctx"] = None
     ctx_future = None
     all_reads = None
     r_idx = t_idx = None
     if native and not distributed:
         # the device starts up while the files are parsed (the workspaces are reserved below, once the aligner is done with the memory)
-        ctx_future = HipContext.in_background(**ctx_kw)
+        if reuse is None:
+            ctx_future = HipContext.in_background(**ctx_kw)
         native_reads, overlaps, native_targets = read_inputs_native(a.sequences, a.overlaps, a.targets)
         all_reads = native_reads
         lengths = all_reads.lengths
@@ -177,11 +188,16 @@ def main(argv=None):
                 target_name = lambda t: targets[t][0]
             if kept or a.include_unpolished:
                 batch, ids = wb.build(copy=False)              # (the builder lives until the text is stitched)
-                if ctx_future is not None:
+                if reuse is not None:
+                    ctx = reuse
+                    ctx.set_polish_params(window_type=window_type, **soft_kw)
+                elif ctx_future is not None:
                     ctx, ctx_future = ctx_future.result(), None
                     ctx.set_window_type(window_type)
                 else:
                     ctx = HipContext(window_type=window_type, **ctx_kw)
+                if shared is not None and not distributed:
+                    shared["ctx"], shared["fixed"] = ctx, fixed_kw
                 if n_aligned:
                     from .align import release as release_aligner
                     release_aligner()                       # the overlap aligner's matrix buffer goes back before the workspaces are laid out
@@ -193,8 +209,10 @@ def main(argv=None):
                         ctx.reserve(0)
                     except Exception:                       # noqa: BLE001
                         pass
-                cons, status = ctx.consensus(batch, retry_overflow=not a.no_capacity_retry)
-                ctx.close()
+                # (a large input goes through the context in slices queued behind each other: copies in and out run beside the kernels)
+                cons, status = ctx.consensus_batched(batch, retry_overflow=not a.no_capacity_retry)
+                if shared is None or distributed:
+                    ctx.close()
                 # Every valid window is computed on the device.  What can remain is a graph beyond the 16-bit id space after the
                 # capacity retries (VC_WIN_OVERFLOW) or input the reference would throw on (VC_WIN_INVALID).  The reference's
                 # accelerated polisher re-runs such windows on the CPU (cudapolisher.cpp:355-379); this command has no CPU path,
