@@ -246,6 +246,12 @@ void        vc_wb_breaking_points(const vc_wb* b, uint32_t overlap, uint32_t* t_
 /* fills `out` with arrays owned by the builder (valid until the next build / destroy): every window of every
  * target in order, layers in the reference's rank order */
 int         vc_wb_build(vc_wb* b, vc_batch* out);
+/* The same in two steps, for a caller that hands a large input to the device in slices (vc_submit of slice i + 1 while slice i runs): _begin
+ * lays the whole batch out (every offset and buffer of `out` is final, the windows' bytes are not written yet), _fill writes the windows
+ * [w_lo, w_hi).  A slice may be submitted once its windows are filled; filling the next one overlaps the device, as the reference's
+ * accelerated polisher fills its next batch while one computes (src/cuda/cudapolisher.cpp:246-277). */
+int         vc_wb_build_begin(vc_wb* b, vc_batch* out);
+int         vc_wb_build_fill(vc_wb* b, uint32_t w_lo, uint32_t w_hi);
 /* add_layer() index (0 = backbone) of every stored sequence of the last build, i.e. the rank permutation */
 const uint32_t* vc_wb_seq_orig(const vc_wb* b);
 uint32_t    vc_wb_n_windows(const vc_wb* b);

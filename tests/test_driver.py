@@ -261,6 +261,13 @@ def test_two_rounds_on_the_device_match_the_reference(built, tmp_path):
                       "--overlapper-r1", f"cp {tmp_path / 'round1_paf.paf'} {{out}}", "--overlapper-r2", f"cp {tmp_path / 'round2_paf.paf'} {{out}}"])
     assert rc == 0
     assert open(out).read() == fx["round2_fasta"]
+    # the same two rounds inside ONE process on ONE context (--in-process: vc_set_polish_params switches the overload between the rounds)
+    out2 = tmp_path / "out_in_process.fa"
+    rc = driver.main([str(reads), "-o", str(out2), "--workdir", str(tmp_path / "work2"), "--in-process",
+                      "--overlapper-r1", f"cp {tmp_path / 'round1_paf.paf'} {{out}}", "--overlapper-r2", f"cp {tmp_path / 'round2_paf.paf'} {{out}}"])
+    assert rc == 0
+    assert open(out2).read() == fx["round2_fasta"]
+    assert not driver._SHARED                        # the shared context went with the run
     # and the haplotype-aware round alone (--linear would be the other overload; here: one explicit polisher call on round 1)
     from vechat_amd import polish
     import io

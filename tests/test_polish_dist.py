@@ -40,6 +40,11 @@ class OracleContext:
         cons, pol, _ = oa.oracle_run(batch, self.params)
         return cons, np.array([capi.VC_WIN_OK if p else capi.VC_WIN_UNPOLISHED for p in pol], dtype=np.uint8)
 
+    def consensus_batched(self, batch, retry_overflow=True, fill=None, **kw):      # (the command line hands the batch over laid out, not yet written)
+        if fill is not None:
+            fill(0, batch.n_windows)
+        return self.consensus(batch, retry_overflow=retry_overflow)
+
     def close(self):
         pass
 

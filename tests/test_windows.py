@@ -102,6 +102,17 @@ def test_builder_matches_the_python_restatement(built, seed, W):
         for k in range(len(s)):
             assert s[k] == exp[k][0] and q[k] == exp[k][1] and (b[k], e[k]) == (exp[k][2], exp[k][3])
         assert [int(x) for x in batch.seq_orig[batch.win_seq_off[w]:batch.win_seq_off[w + 1]]] == ref["order"]
+    # the same build in two steps (vc_wb_build_begin + vc_wb_build_fill in ragged pieces): every slice complete once its windows are filled
+    sb, sids, fill = wb.build_streaming()
+    assert sids == ids and sb.n_windows == batch.n_windows
+    cuts = sorted({0, batch.n_windows} | {random.Random(seed + 99).randrange(0, batch.n_windows + 1) for _ in range(3)})
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        fill(lo, hi)
+        got, want = sb.slice(lo, hi), batch.slice(lo, hi)
+        for k in ("win_seq_off", "seq_off", "seq_begin", "seq_end", "seq_has_qual", "bases", "quals", "win_fasta"):
+            assert np.array_equal(getattr(got, k), getattr(want, k)), (k, lo, hi)
+    for k in ("win_seq_off", "seq_off", "seq_begin", "seq_end", "seq_has_qual", "bases", "quals", "win_fasta", "seq_orig"):
+        assert np.array_equal(getattr(sb, k), getattr(batch, k)), k
     # stitching with made-up window results
     rng = random.Random(seed)
     cons = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 9))) for _ in wins]

@@ -95,12 +95,16 @@ def main(nt=None, tl=None, depth=None, out=None, python_too=True, quiet=False, c
         kept, _ = (load_polisher_input_native if native else load_polisher_input)(wb, targets, reads, overlaps, 0.3)
         T["load (records -> window builder)"] = time.time() - t0
         t0 = time.time()
-        batch, ids = wb.build(copy=not native)
-        T["window assembly (vc_wb_build)"] = time.time() - t0
+        fill = None
+        if native and dev and os.environ.get("VC_FILES_STREAM", "1") != "0":
+            batch, ids, fill = wb.build_streaming()           # laid out now; written slice by slice while the device runs (the command line's way)
+        else:
+            batch, ids = wb.build(copy=not native)
+        T["window assembly (vc_wb_build)" if fill is None else "window layout (vc_wb_build_begin; the bytes are written beside the device, vc_wb_build_fill)"] = time.time() - t0
         nw = batch.n_windows
         text = b""
         if dev:
-            t0 = time.time(); cons, status = ctx.consensus_batched(batch); T["device (submit + run + collect, slices queued behind each other)"] = time.time() - t0
+            t0 = time.time(); cons, status = ctx.consensus_batched(batch, fill=fill); T["device (submit + run + collect, slices queued behind each other)"] = time.time() - t0
             t0 = time.time()
             text = b"".join(b">" + n.encode() + b"\n" + d + b"\n" for n, d in wb.stitch(cons, status, drop_unpolished=True, fragment_correction=True))
             T["stitch"] = time.time() - t0

@@ -209,6 +209,8 @@ def _declare_host(lib):
     lib.vc_wb_n_breaking_points.argtypes = [vp, u32]; lib.vc_wb_n_breaking_points.restype = u32
     lib.vc_wb_breaking_points.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32)]; lib.vc_wb_breaking_points.restype = None
     lib.vc_wb_build.argtypes = [vp, C.POINTER(VcBatch)]; lib.vc_wb_build.restype = C.c_int
+    lib.vc_wb_build_begin.argtypes = [vp, C.POINTER(VcBatch)]; lib.vc_wb_build_begin.restype = C.c_int
+    lib.vc_wb_build_fill.argtypes = [vp, C.c_uint32, C.c_uint32]; lib.vc_wb_build_fill.restype = C.c_int
     lib.vc_wb_seq_orig.argtypes = [vp]; lib.vc_wb_seq_orig.restype = C.POINTER(u32)
     lib.vc_wb_n_windows.argtypes = [vp]; lib.vc_wb_n_windows.restype = u32
     lib.vc_wb_window_target.argtypes = [vp, u32]; lib.vc_wb_window_target.restype = u32

@@ -366,7 +366,7 @@ void free_list(std::vector<void*>& l) {
 // vc_submit.
 void unstage(vc_ctx* c) {
     for (Batch& b : c->bt) if (!b.ran || b.collected) b.have = false;       // (a finished run that nobody has collected keeps its results)
-    if (c->cur && !c->cur->have) c->cur = nullptr;
+    // (c->cur stays: the batch's own buffers -- statuses, diagnostics -- are not workspaces and can still be read: vc_debug_errinfo)
 }
 void free_workspaces(vc_ctx* c) {         // the chunk workspaces: what was allocated piece by piece, and the arena's bump pointer
     free_list(c->chunk_allocs);
@@ -1300,7 +1300,6 @@ int vc_set_polish_params(vc_ctx* c, const vc_params* p) {
     if (p->window_type != 0 && p->window_type != 1) return fail(c, VC_ERR_ARG, "window_type %d unknown", p->window_type);
     drain(c);
     for (Batch& b : c->bt) if (!b.ran || b.collected) b.have = false;       // (a batch staged under the old scores was planned for them)
-    if (c->cur && !c->cur->have) c->cur = nullptr;
     c->prm.match = p->match; c->prm.mismatch = p->mismatch; c->prm.gap = p->gap;
     c->prm.sw_match = p->sw_match; c->prm.sw_mismatch = p->sw_mismatch; c->prm.sw_gap = p->sw_gap;
     c->prm.min_confidence = p->min_confidence; c->prm.min_support = p->min_support; c->prm.num_prune = p->num_prune;
@@ -1850,7 +1849,7 @@ int vc_collect(vc_ctx* c, vc_result* r) {
 }
 
 int vc_debug_errinfo(vc_ctx* c, uint32_t* out) {
-    if (!c || !out || !(c->cur && c->cur->have)) return VC_ERR_ARG;
+    if (!c || !out || !(c->cur && c->cur->b.errinfo)) return VC_ERR_ARG;      // (the last batch submitted: its diagnostics outlive vc_release)
     HIPCHK(c, hipSetDevice(c->device));
     sync_all(c);
     HIPCHK(c, hipMemcpy(out, c->cur->b.errinfo, (size_t)c->cur->b.n_windows * 4, hipMemcpyDeviceToHost));

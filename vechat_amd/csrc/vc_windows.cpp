@@ -57,6 +57,7 @@ struct vc_wb {
     std::vector<Ovl> ovls;
     std::vector<Win> wins;
     std::vector<uint32_t> coverage;                 // targets_coverages_
+    std::vector<uint64_t> wbytes, wseqs;            // layout of the last build: first byte / first sequence of every window (vc_wb_build_begin / _fill)
     std::string err;
     // flattened batch (owned here, handed out through vc_batch)
     std::vector<uint32_t> win_seq_off, seq_begin, seq_end;
@@ -251,7 +252,21 @@ void vc_wb_breaking_points(const vc_wb* b, uint32_t overlap, uint32_t* t_pos, ui
     for (size_t i = 0; i < bp.size(); ++i) { t_pos[i] = bp[i].first; q_pos[i] = bp[i].second; }
 }
 
-int vc_wb_build(vc_wb* b, vc_batch* out) {
+// vc_wb_build in two steps, for a caller that hands the windows to the device in slices ("files in, FASTA out"): _begin lays
+// the batch out -- every offset, every buffer -- and _fill writes the bytes of the windows [w_lo, w_hi); slice i + 1 is filled while the
+// device works on slice i, as the reference's accelerated polisher fills its next batch while one computes (src/cuda/cudapolisher.cpp:246-277).
+static int wb_build_impl(vc_wb* b, vc_batch* out, bool fill_all);
+int vc_wb_build(vc_wb* b, vc_batch* out) { return wb_build_impl(b, out, true); }
+int vc_wb_build_begin(vc_wb* b, vc_batch* out) { return wb_build_impl(b, out, false); }
+
+static void wb_fill(vc_wb* b, size_t w_lo, size_t w_hi);
+int vc_wb_build_fill(vc_wb* b, uint32_t w_lo, uint32_t w_hi) {
+    if (!b || w_lo > w_hi || w_hi > b->wins.size() || b->wbytes.size() != b->wins.size() + 1) return VC_ERR_ARG;
+    wb_fill(b, w_lo, w_hi);
+    return VC_OK;
+}
+
+static int wb_build_impl(vc_wb* b, vc_batch* out, bool fill_all) {
     if (!b || !out) return VC_ERR_ARG;
     const uint32_t W = b->window_length;
     b->wins.clear();
@@ -309,7 +324,8 @@ int vc_wb_build(vc_wb* b, vc_batch* out) {
     // windows side by side
     auto& B = *b;
     const size_t nw = b->wins.size();
-    std::vector<uint64_t> wbytes(nw + 1, 0), wseqs(nw + 1, 0);
+    std::vector<uint64_t>& wbytes = b->wbytes; std::vector<uint64_t>& wseqs = b->wseqs;
+    wbytes.assign(nw + 1, 0); wseqs.assign(nw + 1, 0);
     for (size_t w = 0; w < nw; ++w) {
         const Win& win = b->wins[w];
         uint64_t by = win.length;
@@ -323,7 +339,24 @@ int vc_wb_build(vc_wb* b, vc_batch* out) {
     B.bases.alloc(nb); B.quals.alloc(nb); B.win_fasta.assign(nw, 0);
     for (size_t w = 0; w <= nw; ++w) B.win_seq_off[w] = (uint32_t)wseqs[w];
     B.seq_off[ns] = nb;
-    parallel_for(nw, 8, [&](size_t w) {
+    // (sequence offsets of every window now, so that a slice of the batch is complete as soon as its own windows are filled)
+    // (the order of the layers inside a window is settled in wb_fill, and the offsets of its sequences with it; here only every window's
+    // FIRST offset, which is what the slice in front of it ends on)
+    for (size_t w = 0; w < nw; ++w) B.seq_off[wseqs[w]] = wbytes[w];
+    if (fill_all) wb_fill(b, 0, nw);
+    out->n_windows = (uint32_t)nw;
+    out->win_seq_off = B.win_seq_off.data(); out->seq_off = B.seq_off.data();
+    out->seq_begin = B.seq_begin.data(); out->seq_end = B.seq_end.data(); out->seq_has_qual = B.seq_has_qual.data();
+    out->bases = (const uint8_t*)B.bases.data(); out->quals = (const uint8_t*)B.quals.data(); out->win_fasta = B.win_fasta.data();
+    return VC_OK;
+}
+
+static void wb_fill(vc_wb* b, size_t w_lo, size_t w_hi) {
+    auto& B = *b;
+    const uint32_t W = b->window_length;
+    const std::vector<uint64_t>& wbytes = b->wbytes; const std::vector<uint64_t>& wseqs = b->wseqs;
+    parallel_for(w_hi - w_lo, 8, [&](size_t wi) {
+        const size_t w = w_lo + wi;
         const Win& win = b->wins[w];
         const Seq& t = b->seqs[win.target];
         const uint32_t n = (uint32_t)win.layers.size() + 1;
@@ -363,11 +396,6 @@ int vc_wb_build(vc_wb* b, vc_batch* out) {
             }
         }
     });
-    out->n_windows = (uint32_t)nw;
-    out->win_seq_off = B.win_seq_off.data(); out->seq_off = B.seq_off.data();
-    out->seq_begin = B.seq_begin.data(); out->seq_end = B.seq_end.data(); out->seq_has_qual = B.seq_has_qual.data();
-    out->bases = (const uint8_t*)B.bases.data(); out->quals = (const uint8_t*)B.quals.data(); out->win_fasta = B.win_fasta.data();
-    return VC_OK;
 }
 
 const uint32_t* vc_wb_seq_orig(const vc_wb* b) { return b ? b->seq_orig.data() : nullptr; }

@@ -149,13 +149,17 @@ class HipContext:
             d["kernels"][s.names[i].value.decode()] = dict(ms=float(s.ms[i]), launches=int(s.launches[i]), busy_ms=float(s.busy_ms[i]))
         return d
 
-    def consensus_batched(self, batch: capi.Batch, batch_windows=32768, first=8192, retry_overflow=True):
+    def consensus_batched(self, batch: capi.Batch, batch_windows=32768, first=8192, retry_overflow=True, fill=None):
         """The loop of include/vechat_hip.h over one large batch: slices are queued behind each other in this context -- the copy-in of slice
         i + 1 and the copy-out of slice i - 1 run while slice i computes (the reference's accelerated polisher fills the next batch while one
         computes, src/cuda/cudapolisher.cpp:246-277).  A small first slice starts the device early.  Same bytes as consensus(); windows
-        that outgrow the capacity estimate are retried the same way."""
+        that outgrow the capacity estimate are retried the same way.
+        fill(lo, hi): the batch is laid out but its windows are not written yet (WindowBuilder.build_streaming): the windows of a slice
+        are written right before the slice is submitted, i.e. while the slices in front of it run."""
         n = batch.n_windows
         if n <= first + batch_windows // 2:
+            if fill is not None:
+                fill(0, n)
             return self.consensus(batch, retry_overflow=retry_overflow)
         sizes = [first]
         rem = (n - first) % batch_windows
@@ -165,11 +169,14 @@ class HipContext:
         cuts = [0]
         for k in sizes:
             cuts.append(cuts[-1] + k)
-        parts = [batch.slice(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        def part(i):
+            if fill is not None:
+                fill(cuts[i], cuts[i + 1])
+            return batch.slice(cuts[i], cuts[i + 1])              # (offsets are rebased here: after the fill)
         outs = []
-        self.submit(parts[0]); self.run()
-        for i in range(1, len(parts)):
-            self.submit(parts[i]); self.run()
+        self.submit(part(0)); self.run()
+        for i in range(1, len(sizes)):
+            self.submit(part(i)); self.run()
             outs.append(self.collect())
         outs.append(self.collect())
         cons = [x for o in outs for x in o[0]]

@@ -187,7 +187,8 @@ def main(argv=None, shared=None):
                 kept, _ = load_polisher_input(wb, targets, reads, overlaps, a.error_threshold, allow_empty=distributed)
                 target_name = lambda t: targets[t][0]
             if kept or a.include_unpolished:
-                batch, ids = wb.build(copy=False)              # (the builder lives until the text is stitched)
+                # (laid out now, written slice by slice while the slices in front run on the device; the builder lives until the text is stitched)
+                batch, ids, fill_windows = wb.build_streaming()
                 if reuse is not None:
                     ctx = reuse
                     ctx.set_polish_params(window_type=window_type, **soft_kw)
@@ -210,7 +211,7 @@ def main(argv=None, shared=None):
                     except Exception:                       # noqa: BLE001
                         pass
                 # (a large input goes through the context in slices queued behind each other: copies in and out run beside the kernels)
-                cons, status = ctx.consensus_batched(batch, retry_overflow=not a.no_capacity_retry)
+                cons, status = ctx.consensus_batched(batch, retry_overflow=not a.no_capacity_retry, fill=fill_windows)
                 if shared is None or distributed:
                     ctx.close()
                 # Every valid window is computed on the device.  What can remain is a graph beyond the 16-bit id space after the

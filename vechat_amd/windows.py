@@ -51,11 +51,18 @@ class WindowBuilder:
         self.lib.vc_wb_breaking_points(self.h, overlap, t, q)
         return [(int(t[i]), int(q[i])) for i in range(n)]
 
-    def build(self, copy=True):
+    def build_streaming(self):
+        """-> (batch, ids, fill): the batch laid out but not yet written (vc_wb_build_begin; arrays are views of the builder's buffers),
+        and fill(lo, hi), which writes the windows [lo, hi) (vc_wb_build_fill).  A slice may be taken and submitted once its windows are
+        filled -- HipContext.consensus_batched(batch, fill=fill) fills slice i + 1 while the device works on slice i."""
+        batch, ids = self.build(copy=False, _begin_only=True)
+        return batch, ids, lambda lo, hi: self._check(self.lib.vc_wb_build_fill(self.h, int(lo), int(hi)))
+
+    def build(self, copy=True, _begin_only=False):
         """-> capi.Batch of every window of every target, plus (target, rank) per window.  copy=False: the batch's arrays are
         views of the builder's buffers (valid until the next build / close) -- half a gigabyte not copied for a large input."""
         vb = capi.VcBatch()
-        self._check(self.lib.vc_wb_build(self.h, C.byref(vb)))
+        self._check((self.lib.vc_wb_build_begin if _begin_only else self.lib.vc_wb_build)(self.h, C.byref(vb)))
         n = int(vb.n_windows)
 
         def arr(p, k, dt):
