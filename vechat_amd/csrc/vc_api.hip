@@ -192,6 +192,7 @@ struct vc_ctx {
     bool topo_hbm = false;          // k_topo of the pruned graphs from the HBM workspace
     uint32_t dbg_stop_kind = 0, dbg_stop_index = 0;   // vc_debug_stop_after: leave the chunk's graphs as they are after that stage
     bool force_dfs = false;       // test knob: settle every end-cell tie with the exact DFS as well
+    bool trace_block = false;     // VC_EXPERIMENTS builds, VC_TRACEB=1: k_traceb (the walk out of LDS, vc_traceb.h) for byte-packed rows
     uint32_t trace_tl = 8;        // lanes per alignment of the lock-step k_tracew (development: VC_TRACE_TL=16)
     bool dt = true;               // global alignments on byte-packed rows run on k_fwd_dt (development: VC_DT=0 keeps them on k_fwd)
     bool fold = true;             // launch_fwd: more than two width classes in one launch (development: VC_NO_FOLD=1 launches once per class)
@@ -444,7 +445,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.fie, CW * (NC + 4) + 64)) ||      // (+ 64: k_tracew reads whole 8-byte chunks of a window's entries)
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords + 64)) ||      // (+ 64: k_traceb reads whole 48-byte windows of a row)
         (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, (c->ws_packed ? c->hmat_dwords / 4 + (size_t)c->jobs_cap * VC_BAND_JOB_PAD_DWORDS : 0) + 64)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_band_par, (size_t)c->jobs_cap * 2)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_list, c->jobs_cap)) ||
@@ -751,6 +752,14 @@ struct Plan {
             return;
         }
         // eight alignments per wave, eight lanes each (development: VC_TRACE_TL=16 -- four alignments of sixteen lanes, the form the pipeline uses)
+#ifdef VC_EXPERIMENTS
+        if (c->trace_block && ta.packed) {
+            // the walk out of LDS (vc_traceb.h; VC_TRACEB=1): bit-identical and a quarter SLOWER than k_tracew (profiles/r6_ab_traceb.txt) -- an experiment
+            hipLaunchKernelGGL(k_traceb, dim3((njobs + 7) / 8), dim3(64), vc_traceb_lds_bytes(), wk.stream, ta);
+            if (c->wcols) { ta.only_wide = 1; hipLaunchKernelGGL(k_trace, dim3((njobs + VC_TRACE_LANES - 1) / VC_TRACE_LANES), dim3(64), 0, wk.stream, ta); ta.only_wide = 0; }
+            return;
+        }
+#endif
         const uint32_t tg = c->trace_tl == 16 ? 4u : 8u;
         ta.shared_table = gsz % tg == 0; ta.tab_rows = std::min(max_rows, kTraceTabRows);
         const uint32_t lds = vc_tracew_lds_bytes(ta.tab_rows, ta.shared_table != 0, tg);
@@ -1155,6 +1164,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     c->fold = getenv("VC_NO_FOLD") == nullptr;
     if (const char* d = getenv("VC_TRACE_TL")) c->trace_tl = std::atoi(d) == 16 ? 16u : 8u;
+    if (const char* d = getenv("VC_TRACEB")) c->trace_block = std::atoi(d) != 0;
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
     c->trace_wave = getenv("VC_TRACE_THREAD") == nullptr;      // development switch: the thread-per-alignment backtrack
     if (const char* d = getenv("VC_DT")) c->dt = std::atoi(d) != 0;

@@ -2687,6 +2687,10 @@ VC_KL __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(112))) voi
     (void)vc_tracew_body<false, TL>(a, smem, job, slot, k, pj, valid, whole);
 }
 
+#ifdef VC_EXPERIMENTS
+#include "vc_traceb.h"     // k_traceb: the backtrack walked out of LDS -- measured slower than k_tracew, kept as an experiment
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // k_addaln: Graph::AddAlignment (graph.cpp:182-299) for the layer just aligned, wave-parallel.
 // The reference walks the alignment serially; every decision it takes depends only on the graph
