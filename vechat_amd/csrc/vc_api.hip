@@ -195,6 +195,7 @@ struct vc_ctx {
     bool trace_block = false;     // VC_EXPERIMENTS builds, VC_TRACEB=1: k_traceb (the walk out of LDS, vc_traceb.h) for byte-packed rows
     uint32_t trace_tl = 8;        // lanes per alignment of the lock-step k_tracew (development: VC_TRACE_TL=16)
     bool dt = true;               // global alignments on byte-packed rows run on k_fwd_dt (development: VC_DT=0 keeps them on k_fwd)
+    bool inline_redo = false;     // development (VC_INLINE_REDO=1, read once at vc_create): the redo pair inside every build round instead of catch-up rounds
     bool fold = true;             // launch_fwd: more than two width classes in one launch (development: VC_NO_FOLD=1 launches once per class)
     uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
     Work works[kMaxStreams];
@@ -849,8 +850,7 @@ struct Plan {
     // every layer of every window of the chunk: `layers` rounds, then as many catch-up rounds as the slowest window is behind
     int build_loop(Work& wk) {
         int rc;
-        const char* ir = getenv("VC_INLINE_REDO");                       // (development: VC_INLINE_REDO=1 keeps the redo pair in every round)
-        const bool defer = bt->band && !(ir && std::atoi(ir) != 0);
+        const bool defer = bt->band && !c->inline_redo;                 // (development: VC_INLINE_REDO=1 keeps the redo pair in every round)
         for (uint32_t j = 1; j <= wk.layers; ++j) if ((rc = build_layer(wk, j, !defer))) return rc;
         if (!defer) return VC_OK;
         // (the one host wait of the build phase; the re-alignment rounds have theirs: Plan::realign)
@@ -1163,6 +1163,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     c->force_dfs = getenv("VC_RESOLVE_FORCE_DFS") != nullptr;
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     c->fold = getenv("VC_NO_FOLD") == nullptr;
+    if (const char* d = getenv("VC_INLINE_REDO")) c->inline_redo = std::atoi(d) != 0;
     if (const char* d = getenv("VC_TRACE_TL")) c->trace_tl = std::atoi(d) == 16 ? 16u : 8u;
     if (const char* d = getenv("VC_TRACEB")) c->trace_block = std::atoi(d) != 0;
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
