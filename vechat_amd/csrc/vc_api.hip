@@ -1016,7 +1016,7 @@ struct Plan {
             ta.cpl_lo = fold_lo(c, bt);
             int rc = launch_fwd(c, bt, wk.stream, fa, ns * gsz, &wk, nwonly);
             if (rc) return rc;
-            ta.group = gsz; ta.k0 = k0; ta.hstride = stride;
+            ta.group = gsz; ta.k0 = k0; ta.hstride = stride; ta.band_chain = 1;      // (mode 1 launches run the forward kernels with KEPT = false)
             ta.pairs = wk.d_rpairs; ta.npairs = wk.d_rnpairs; ta.pair_group = c->max_nseq; ta.pair_k0 = 0;
             launch_trace(wk, ta, ns * gsz, gsz, maxn);
             if ((rc = redo(wk, fa, ta, ns * gsz, maxn, nwonly))) return rc;

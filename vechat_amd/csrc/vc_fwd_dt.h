@@ -127,7 +127,7 @@ __device__ __forceinline__ uint32_t vc_fwd_dt(const VcFwdArgs& a, uint32_t* ring
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)bb_hi << 32) | bb_lo), 0, (int)bbytes, 0x00020000);
     const uint32_t band_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_slope(len, nrows, CPL));
     if (band && lane == 0) a.band_par[job] = band_ql;
-    constexpr uint32_t BL = vc_band_lanes(CPL);                                 // lanes of a band row in this width class (80 columns, at least 8 lanes)
+    constexpr uint32_t BL = vc_band_lanes(CPL, !KEPT);                          // lanes of a band row in this width class and phase (build: 80 columns, at least 8 lanes)
     constexpr uint32_t TLB = NDS * 4u, TBB = BL * TLB;                          // a lane's bytes in a band row, a band row
     const uint32_t lane_tlb = (uint32_t)lane * TLB;
     int16_t* const c0p_out = a.c0 + (uint64_t)job * a.NC;

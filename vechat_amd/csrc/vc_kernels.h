@@ -1207,8 +1207,18 @@ __device__ __forceinline__ uint32_t vc_band_slope(uint32_t len, uint32_t nrows, 
 // (4 lanes) windows/s: a row of 8 lanes is 96 bytes instead of 192 (k_fwd stores half, the backtrack finds 1.3 rows per 128-byte line
 // instead of 0.7), and the alignments that leave the band go from 0.14 % to 0.19 % (at 6 lanes: 0.6 %, and the catch-up rounds eat the
 // gain).  What the walk needs is a width in COLUMNS: config E (20 columns per lane) leaves 8 lanes as rarely as 16.
-__host__ __device__ constexpr uint32_t vc_band_lanes(uint32_t cpl) {
-    return cpl >= 10u ? 8u : (cpl >= 8u ? 10u : (cpl >= 6u ? 14u : (uint32_t)VC_BAND_LANES));
+// `chain` (development, -DVC_BAND_CHAIN_COLS=n: a narrower band for the re-alignment rounds, whose graphs are little more than a chain of the
+// backbone's length): n columns, at least 4 lanes.  The forward kernels take it from their KEPT parameter (with the band on, KEPT <=> build
+// phase), the backtrack from VcTraceArgs::band_chain.  Measured and left off: the exact DFS order of a pruned graph puts rows of distant
+// backbone coordinates side by side often enough that 40 columns send 10 % of the re-alignments through the redo pass.
+#ifndef VC_BAND_CHAIN_COLS
+#define VC_BAND_CHAIN_COLS 0       // 0 = off (the product): 40 columns lose 10 % of the re-alignments to the redo pass, profiles/r6_ab_chain_band.txt
+#endif
+__host__ __device__ constexpr uint32_t vc_band_lanes(uint32_t cpl, bool chain = false) {
+    const uint32_t full = cpl >= 10u ? 8u : (cpl >= 8u ? 10u : (cpl >= 6u ? 14u : (uint32_t)VC_BAND_LANES));
+    if (!chain || VC_BAND_CHAIN_COLS == 0) return full;
+    const uint32_t c = ((uint32_t)VC_BAND_CHAIN_COLS + cpl - 1u) / cpl;
+    return c < 4u ? 4u : (c > full ? full : c);
 }
 __device__ __forceinline__ uint32_t vc_band_start(uint32_t i, uint32_t ql, uint32_t bl) {
     // lane of the diagonal at row i (i <= rows, so i * ql < 2^22 * ... fits 32 bits; the 24-bit multiply is the fast one).  Any
@@ -1484,7 +1494,7 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     }
     const uint32_t band_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_slope(len, nrows, CPL));   // a scalar: the band of a row is worked out on the scalar side
     if (band && lane == 0) a.band_par[job] = band_ql;
-    constexpr uint32_t BL = vc_band_lanes(CPL);                 // lanes of a band row in this width class
+    constexpr uint32_t BL = vc_band_lanes(CPL, !KEPT);          // lanes of a band row in this width class and phase
     constexpr uint32_t TLB = NDS * 4u, TBB = BL * TLB;          // a lane's bytes in a band row, a band row
     uint32_t t_off = 0u - TBB;                                 // byte offset of the band row in work (scalar)
     uint32_t b_rin = 0;                                        // rows left in the current band block (vc_band_row_start)
@@ -2191,6 +2201,7 @@ struct VcTraceArgs {
     int shared_table;           // k_tracew: the VC_TG alignments of a wave share a window (group % VC_TG == 0)
     uint32_t tab_rows;          // k_tracew: rows the LDS table is sized for (>= every graph's height in this launch)
     uint32_t cpl_lo;            // narrowest width class the forward pass of this launch used (0: every sequence in its own class)
+    int band_chain;             // the forward pass of this launch stored the narrow band of the re-alignment rounds (vc_band_lanes(cpl, true))
     uint32_t* cursor;           // build phase, != nullptr: [nslots] layer of every window | "left the band" << 31 (VcFwdArgs::cursor); the walk
                                 //   sets / clears the flag, the pair list of a window is pairs + slot * PC
 };
@@ -2390,7 +2401,7 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     const int16_t* c0 = a.c0 + (uint64_t)(valid ? job : 0) * a.NC;
     const uint32_t cpl = max(vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), a.cpl_lo), nd = cpl / 2, nds = (uint32_t)vc_nds((int)cpl);
     const bool packed = a.packed != 0;
-    const uint32_t band_lanes = vc_band_lanes(cpl);             // (the width class decides: 80 columns, at least 8 lanes)
+    const uint32_t band_lanes = vc_band_lanes(cpl, a.band_chain != 0);   // (the width class and the phase decide: 80 columns, at least 8 lanes; re-alignment rounds: 40, at least 4)
     // banded store: global alignments of a banded launch keep VC_BAND_LANES lanes per row around the rank diagonal
     const bool band = a.band != 0 && !redo && valid && type == 1;
     const uint32_t* bm32 = a.bmat + (uint64_t)(valid ? job : 0) * vc_band_job_dwords(a.hstride);

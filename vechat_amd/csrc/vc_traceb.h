@@ -62,7 +62,7 @@ __device__ __forceinline__ bool vc_traceb_body(const VcTraceArgs& a, uint8_t* sm
     const uint32_t sq = a.b.win_seq_off[w] + (valid ? k : 0);
     const uint64_t so = a.b.seq_off[sq];
     const uint32_t cpl = max(vc_cpl_for((uint32_t)(a.b.seq_off[sq + 1] - so)), a.cpl_lo), nds = (uint32_t)vc_nds((int)cpl);
-    const uint32_t band_lanes = vc_band_lanes(cpl);
+    const uint32_t band_lanes = vc_band_lanes(cpl, a.band_chain != 0);
     const bool band = a.band != 0 && !redo && valid && type == 1;
     const uint32_t band_ql = band ? a.band_par[job] : 0u;
     // stored rows of this job: row r (1-based) at rows32 + (r - 1) * rstride, its first stored lane first (band: vc_band_row_start; whole rows: lane 0)
