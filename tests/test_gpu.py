@@ -184,6 +184,31 @@ def test_tie_resolution_by_exact_dfs(built, monkeypatch):
     c.close()
 
 
+def test_lds_row_backtrack_agrees_with_the_speculative_one(built, monkeypatch):
+    """k_traceb (vc_traceb.h): the backtrack walked out of LDS-resident blocks of stored rows, an experiment of round 6 (bit-identical, slower;
+    profiles/r6_ab_traceb.txt) that only VC_EXPERIMENTS=1 builds carry.  Same pairs -> same bytes, statuses and work counters as k_tracew, on
+    build-phase bands, re-alignment bands, whole rows of the redo pass, partial-span (local) layers and both overloads."""
+    if not capi.load_hip().vc_has_experiments():
+        pytest.skip("library built without VC_EXPERIMENTS")
+    cases = [(capi.synth_cfg(1002, 500, 24), 16, {}),
+             (capi.synth_cfg(13, 400, 20, n_haplotypes=2, snp_rate=0.02, frac_partial=0.3), 24, dict(chunk_windows=16, n_streams=2)),
+             (capi.synth_cfg(77, 250, 12, frac_partial=0.5, fastq=0, backbone_fastq=0), 16, dict(mode=1)),
+             (capi.synth_cfg(1005, 1000, 40, profile=capi.ONT), 6, {})]
+    for cfg, n, kw in cases:
+        batch = capi.synth_batch(cfg, 0, n)
+        out = []
+        for tb in ("0", "1"):
+            monkeypatch.setenv("VC_TRACEB", tb)               # (read by vc_create)
+            c = HipContext(device=0, **kw)
+            cons, status = c.consensus(batch)
+            st = c.stats()
+            out.append((cons, [int(x) for x in status], st["cells"], st["dp_rows"], st["band_redo"], st["trace_steps"], st["trace_spec"]))
+            c.close()
+        assert out[0][6] > 0 and out[1][6] == 0               # the walks really were different ones: only k_tracew speculates
+        assert out[0][:6] == out[1][:6], (kw, [o[1:] for o in out])
+    _check(HipContext(device=0), capi.synth_batch(capi.synth_cfg(4242, 200, 12, frac_partial=0.25), 0, 8), "k_traceb against the oracle")
+
+
 def test_persistent_build_pipeline_agrees_with_the_lock_step_plan(built):
     """The two execution plans of the build loop (vc_set_pipeline): lock-step launches per layer, and the persistent pipeline of
     resident forward / backtrack waves handing windows over through device-side queues.  Same bytes, same statuses, same work
