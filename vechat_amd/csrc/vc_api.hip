@@ -688,7 +688,8 @@ bool pipe_classes(const Batch* bt, uint32_t* ca, uint32_t* cb) {
 #ifdef VC_FAST_BUILD
     return *cb == 10 || *cb == 8;
 #else
-    return *cb <= 32;                  // (no pipeline kernel is built for the classes of 48 / 64 columns per lane: those batches take the lock-step plan)
+    return *cb < 32;                   // (the wide classes -- 32 columns per lane and up -- run with their own ring / kept-row parameters, kKeptWide and
+                                       //  bt->ring: build_pipe and k_pipe_fwd are written for kKept / kRing, so those batches take the lock-step plan)
 #endif
 }
 int launch_pipe_fwd(vc_ctx* c, const Batch* bt, hipStream_t st, const VcPipeFwdArgs& a, uint32_t grid, uint32_t lds) {
@@ -698,7 +699,7 @@ int launch_pipe_fwd(vc_ctx* c, const Batch* bt, hipStream_t st, const VcPipeFwdA
     VC_PF(8, 10) VC_PF(8, 8) VC_PF(10, 10) VC_PF(6, 8)
 #ifndef VC_FAST_BUILD
     VC_PF(4, 4) VC_PF(4, 6) VC_PF(6, 6) VC_PF(10, 12) VC_PF(12, 12) VC_PF(12, 16) VC_PF(16, 16) VC_PF(16, 20) VC_PF(20, 20)
-    VC_PF(20, 24) VC_PF(24, 24) VC_PF(24, 32) VC_PF(32, 32)
+    VC_PF(20, 24) VC_PF(24, 24)
 #endif
 #undef VC_PF
     return fail(c, VC_ERR_ARG, "persistent pipeline: width classes %u..%u not built", lo, hi);
