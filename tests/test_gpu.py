@@ -184,6 +184,19 @@ def test_tie_resolution_by_exact_dfs(built, monkeypatch):
     c.close()
 
 
+def test_raw_rows_with_a_stored_band(built, monkeypatch):
+    """VC_BAND_RAW=1 (round 6, off by default: slower on 3 kb windows): rows that stay raw int16 -- scores outside the byte form -- store the band
+    of the rank diagonal like byte-packed rows do, and the backtrack reads it.  Same bytes as the oracle; alignments that leave the band are redone."""
+    monkeypatch.setenv("VC_BAND_RAW", "1")
+    c = HipContext(device=0, match=12, mismatch=-12, gap=-20)            # (cpl - 1) * (m - 2 g) > 255 from 6 columns per lane up: raw rows, still int16
+    for seed, L, D, n, kw in [(31, 500, 24, 8, {}), (32, 300, 16, 8, dict(frac_partial=0.3, n_haplotypes=2, snp_rate=0.02))]:
+        _check(c, capi.synth_batch(capi.synth_cfg(seed, L, D, **kw), 0, n), f"raw band seed{seed}")
+    c.close()
+    c = HipContext(device=0)                                             # default scores at 48 columns per lane (the shape of the bench's config W): raw rows as well
+    st = _check(c, capi.synth_batch(capi.synth_cfg(33, 2100, 6, profile=capi.ONT), 0, 4), "raw band, 2.1 kb windows")
+    c.close()
+
+
 def test_lds_row_backtrack_agrees_with_the_speculative_one(built, monkeypatch):
     """k_traceb (vc_traceb.h): the backtrack walked out of LDS-resident blocks of stored rows, an experiment of round 6 (bit-identical, slower;
     profiles/r6_ab_traceb.txt) that only VC_EXPERIMENTS=1 builds carry.  Same pairs -> same bytes, statuses and work counters as k_tracew, on

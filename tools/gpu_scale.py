@@ -13,7 +13,8 @@ fp = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
 t0 = time.time()
 b = capi.synth_batch(capi.synth_cfg(int(os.environ.get("VC_SEED", "1002")), L, D, frac_partial=fp, profile=capi.ONT if os.environ.get("VC_PROFILE") == "ont" else capi.PACBIO), 0, n)
 print(f"generated {n} windows in {time.time()-t0:.1f}s, {b.bases.size/1e6:.1f} MB bases", flush=True)
-ctx = HipContext(device=0, profile=1, chunk_windows=chunk, n_streams=streams, num_prune=int(os.environ.get('VC_NUM_PRUNE', '3')),
+_sc = [int(x) for x in os.environ['VC_SCORES'].split(',')] if os.environ.get('VC_SCORES') else None      # e.g. VC_SCORES=5,-4,-8: scores whose rows stay raw int16
+ctx = HipContext(device=0, profile=1, chunk_windows=chunk, n_streams=streams, num_prune=int(os.environ.get('VC_NUM_PRUNE', '3')), **(dict(match=_sc[0], mismatch=_sc[1], gap=_sc[2]) if _sc else {}),
                  scratch_bytes=int(float(os.environ.get('VC_SCRATCH_GB', '0')) * (1 << 30)))
 t0 = time.time(); ctx.submit(b); ts = time.time() - t0
 print(f"vc_submit (validation + H2D of {2*b.bases.size/1e6:.0f} MB): {ts:.3f}s = {n/ts:.0f} win/s", flush=True)

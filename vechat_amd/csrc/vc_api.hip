@@ -195,6 +195,8 @@ struct vc_ctx {
     bool trace_block = false;     // VC_EXPERIMENTS builds, VC_TRACEB=1: k_traceb (the walk out of LDS, vc_traceb.h) for byte-packed rows
     uint32_t trace_tl = 8;        // lanes per alignment of the lock-step k_tracew (development: VC_TRACE_TL=16)
     bool dt = true;               // global alignments on byte-packed rows run on k_fwd_dt (development: VC_DT=0 keeps them on k_fwd)
+    bool band_raw = false;        // VC_BAND_RAW=1: raw int16 rows (widest classes, scores outside the byte form) store the band as well -- bit-identical,
+                                  //   6 % slower on 3 kb windows (profiles/r6_ab_raw_band.txt: 4.7 % of their alignments leave 384 columns), so off
     bool inline_redo = false;     // development (VC_INLINE_REDO=1, read once at vc_create): the redo pair inside every build round instead of catch-up rounds
     bool fold = true;             // launch_fwd: more than two width classes in one launch (development: VC_NO_FOLD=1 launches once per class)
     uint32_t dup = 0;             // development (VC_DUP): launch idempotent kernel classes twice to measure their marginal cost inside the job
@@ -447,7 +449,7 @@ int alloc_work(vc_ctx* c, Work* wk) {
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.rank2node, CW * NC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->dp.ovf, CW * EC)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_hmat, c->hmat_dwords + 64)) ||      // (+ 64: k_traceb reads whole 48-byte windows of a row)
-        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, (c->ws_packed ? c->hmat_dwords / 4 + (size_t)c->jobs_cap * VC_BAND_JOB_PAD_DWORDS : 0) + 64)) ||
+        (rc = dalloc(c, c->chunk_allocs, &wk->d_bmat, ((c->ws_packed || c->band_raw) ? c->hmat_dwords / 4 + (size_t)c->jobs_cap * VC_BAND_JOB_PAD_DWORDS : 0) + 64)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_band_par, (size_t)c->jobs_cap * 2)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_list, c->jobs_cap)) ||
         (rc = dalloc(c, c->chunk_allocs, &wk->d_redo_n, 4)) ||
@@ -1165,6 +1167,7 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     c->fold = getenv("VC_NO_FOLD") == nullptr;
     if (const char* d = getenv("VC_INLINE_REDO")) c->inline_redo = std::atoi(d) != 0;
+    if (const char* d = getenv("VC_BAND_RAW")) c->band_raw = std::atoi(d) != 0;
     if (const char* d = getenv("VC_TRACE_TL")) c->trace_tl = std::atoi(d) == 16 ? 16u : 8u;
     if (const char* d = getenv("VC_TRACEB")) c->trace_block = std::atoi(d) != 0;
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep
@@ -1538,8 +1541,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
         !vc_int16_ok(c->prm.sw_match, c->prm.sw_mismatch, c->prm.sw_gap, NC, cpl, false)) maybe_wide = true;
     if (cpl >= 32 && bt->lean != 3u) maybe_wide = true;       // classes of 32+ columns per lane exist in the lean form only: other alphabets / scores take k_fwd_wide
     const uint32_t wcols = maybe_wide ? ((ws_max_len + 64 * VC_WIDE_CPL - 1) / (64 * VC_WIDE_CPL)) * (64 * VC_WIDE_CPL) : 0;
-    // whole rows, + a quarter for the band where rows are byte-packed (raw int16 rows -- wide classes, unusual scores -- have no band)
-    const uint64_t per_job = NC * rowd * (bt->packed ? 5 : 4) + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
+    // whole rows, + a quarter for the band (byte-packed rows; raw int16 rows -- wide classes, unusual scores -- only with VC_BAND_RAW=1)
+    const uint64_t per_job = NC * rowd * ((bt->packed || c->band_raw) ? 5 : 4) + NC * 2 + 24 + 2 * VC_MAXTIE + 8 + (maybe_wide ? (uint64_t)NC * wcols * 4 + NC * 4ull : 0ull);
     // big alignments (3 kb reads: 58 MB of raw rows each; the int32 matrices of k_fwd_wide: 86 MB more): there the chunk size IS the
     // budget, and the 96-GiB cap would leave a few hundred alignments per stream -- take the 60 % whole
     if (!c->prm.scratch_bytes && c->arena.empty() && (per_slot_fixed + per_job) * 1024ull > budget) budget = std::max<uint64_t>(budget, (uint64_t)(free_b * 0.6) / S);
@@ -1594,7 +1597,8 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     const bool wide_cls = bt->cpl >= 32;                 // (launch_fwd_t instantiates the forward kernel with the same numbers)
     bt->kept = (kKept && NC < 32768 && !getenv("VC_PLAIN_RING")) ? (uint32_t)(wide_cls ? kKeptWide : kKept) : 0u;
     bt->ring = (uint32_t)(wide_cls ? kRingWide : kRing); bt->ring_pruned = (uint32_t)(wide_cls ? kRingPrunedWide : kRingPruned);
-    bt->band = bt->packed && bt->kept && c->trace_wave && !getenv("VC_NO_BAND");
+    // (round 6, VC_BAND_RAW=1: raw int16 rows banded too -- the widest classes and scores outside the byte form; measured slower, off)
+    bt->band = (bt->packed || c->band_raw) && bt->kept && c->trace_wave && !getenv("VC_NO_BAND");
     if ((rc = salloc(c, bt, 12, &b.cons, (size_t)nw * b.cons_cap))) return rc;
     HIPCHK(c, hipMemsetAsync(b.status, 0, nw, c->stream));
     HIPCHK(c, hipMemsetAsync(b.cons_len, 0, nw * 4, c->stream));

@@ -1482,7 +1482,8 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     uint32_t* const hrow0 = a.hmat + (uint64_t)job * a.hstride;
     constexpr bool packed = PACKED;           // the stored row form is a property of the launch (host: both score sets fit the byte bound)
     // banded store: global alignments only (a local alignment may end and start anywhere), byte-packed rows only
-    const bool band = NWT && PACKED && a.band && !redo;
+    // (round 6: raw int16 rows too -- the widest classes, and scores whose rows do not fit the byte form: [row][band lane][ND dwords])
+    const bool band = NWT && a.band && !redo;
     const char* const brow0 = reinterpret_cast<const char*>(a.bmat + (uint64_t)job * vc_band_job_dwords(a.hstride));
     __amdgpu_buffer_rsrc_t brs;                                // the job's band rows behind a buffer descriptor (wave-uniform by construction)
     {
@@ -1495,7 +1496,7 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     const uint32_t band_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)vc_band_slope(len, nrows, CPL));   // a scalar: the band of a row is worked out on the scalar side
     if (band && lane == 0) a.band_par[job] = band_ql;
     constexpr uint32_t BL = vc_band_lanes(CPL, !KEPT);          // lanes of a band row in this width class and phase
-    constexpr uint32_t TLB = NDS * 4u, TBB = BL * TLB;          // a lane's bytes in a band row, a band row
+    constexpr uint32_t TLB = (PACKED ? NDS : ND) * 4u, TBB = BL * TLB;   // a lane's bytes in a band row, a band row
     uint32_t t_off = 0u - TBB;                                 // byte offset of the band row in work (scalar)
     uint32_t b_rin = 0;                                        // rows left in the current band block (vc_band_row_start)
     unsigned long long t_mask = 0;                             // lanes of the block's band
@@ -1660,6 +1661,28 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
 #pragma unroll
             for (int q = 0; q < ND; ++q) wp[q * 64] = acc[q];
         }
+        // the band of this row: its byte offset (scalar) and, every VC_BAND_ROWS rows, the lanes of the next block
+        auto band_advance = [&]() __attribute__((always_inline)) {
+            t_off += TBB;
+            const bool newblock = b_rin == 0;         // the band moves every VC_BAND_ROWS rows
+            if (newblock) b_rin = VC_BAND_ROWS;
+            b_rin--;
+            if (newblock) {                           // next row block: its band, on the scalar side
+                // vc_band_start of the block's middle row in scalar arithmetic (row and slope are uniform; the product stays below 2^23,
+                // so the plain multiply equals the 24-bit one the backtrack uses).  As vector code, once per row -- v_mul_u32_u24, a
+                // clamped subtract, a minimum, v_readfirstlane and a quarter-rate v_mul_lo_u32 for the lane offset -- this was 5 of a
+                // row's ~59 vector instructions
+                const uint32_t bt_ = ((i + VC_BAND_ROWS / 2u) * band_ql) >> 16;
+                // (in assembly: left to itself the compiler clamps with v_med3_u32 / a saturating v_sub -- only the vector ALU has those --
+                // and multiplies the lane offset with a quarter-rate v_mad_u64_u32)
+                constexpr uint32_t BLO = BL / 2 - 1, BHI = BLO + 64u - BL;
+                uint32_t bs, bso;
+                asm("s_max_u32 %0, %2, %3\n\ts_min_u32 %0, %0, %4\n\ts_sub_u32 %0, %0, %3\n\ts_mul_i32 %1, %0, %5"
+                    : "=&s"(bs), "=s"(bso) : "s"(bt_), "n"(BLO), "n"(BHI), "n"(TLB) : "scc");
+                t_mask = (unsigned long long)((1u << BL) - 1u) << bs;
+                t_lane = lane_tlb - bso;
+            }
+        };
         if (VC_LABF(1)) {                                    // development (tools/gpu_fwd_lab.py): time the row loop without its stores
         } else if (PACKED) {
             uint32_t wv[NDS];
@@ -1676,25 +1699,7 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
             // whole row: always without the band; with it only where a later row reads the row back (VC_RF_FULL)
             if (!band || (r0 & (VC_RF_FULL << 8))) put(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + srow + loff));
             if (band) {
-                t_off += TBB;
-                const bool newblock = b_rin == 0;         // the band moves every VC_BAND_ROWS rows
-                if (newblock) b_rin = VC_BAND_ROWS;
-                b_rin--;
-                if (newblock) {                           // next row block: its band, on the scalar side
-                    // vc_band_start of the block's middle row in scalar arithmetic (row and slope are uniform; the product stays below 2^23,
-                    // so the plain multiply equals the 24-bit one the backtrack uses).  As vector code, once per row -- v_mul_u32_u24, a
-                    // clamped subtract, a minimum, v_readfirstlane and a quarter-rate v_mul_lo_u32 for the lane offset -- this was 5 of a
-                    // row's ~59 vector instructions
-                    const uint32_t bt_ = ((i + VC_BAND_ROWS / 2u) * band_ql) >> 16;
-                    // (in assembly: left to itself the compiler clamps with v_med3_u32 / a saturating v_sub -- only the vector ALU has those --
-                    // and multiplies the lane offset with a quarter-rate v_mad_u64_u32)
-                    constexpr uint32_t BLO = BL / 2 - 1, BHI = BLO + 64u - BL;
-                    uint32_t bs, bso;
-                    asm("s_max_u32 %0, %2, %3\n\ts_min_u32 %0, %0, %4\n\ts_sub_u32 %0, %0, %3\n\ts_mul_i32 %1, %0, %5"
-                        : "=&s"(bs), "=s"(bso) : "s"(bt_), "n"(BLO), "n"(BHI), "n"(TLB) : "scc");
-                    t_mask = (unsigned long long)((1u << BL) - 1u) << bs;
-                    t_lane = lane_tlb - bso;
-                }
+                band_advance();
                 // the band lanes store through a raw buffer descriptor over the job's band rows: a lane outside the band carries an offset beyond
                 // every range and the hardware drops it (tools/buffer_probe.hip).  (Until round 6: exec-mask writes around a store inside an asm
                 // block -- invisible to the compiler's hazard pass; a gfx950 store-data hazard there cost round 5 a day, NOTES.md.)
@@ -1715,9 +1720,24 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
         } else {
             // full 256-B rows on purpose: masking the lanes past the sequence end was measured SLOWER
             // (partial cache-line writes), although it would save 20 % of the bytes
-            uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + srow + loff);
+            // (with the band: only the rows a later row reads back, VC_RF_FULL -- as for the byte-packed rows)
+            if (!band || (r0 & (VC_RF_FULL << 8))) {
+                uint32_t* hr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hrow0) + srow + loff);
 #pragma unroll
-            for (int q = 0; q < ND; ++q) hr[q * 64] = acc[q];
+                for (int q = 0; q < ND; ++q) hr[q * 64] = acc[q];
+            }
+            if (band) {
+                // raw band row: [band lane][ND dwords], a lane's cells side by side; lanes outside the band are dropped by the descriptor's range check
+                band_advance();
+                const uint32_t soff = t_off;
+                const uint32_t voff = ((t_mask >> lane) & 1ull) ? t_lane : 0x80000000u;
+                typedef uint32_t vc_u2 __attribute__((ext_vector_type(2)));
+                typedef uint32_t vc_u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int q = 0; q + 4 <= ND; q += 4) { const vc_u4 d = {acc[q], acc[q + 1], acc[q + 2], acc[q + 3]}; __builtin_amdgcn_raw_buffer_store_b128(d, brs, voff + 4u * q, soff, 0); }
+                if constexpr ((ND & 3) >= 2) { const vc_u2 d = {acc[ND & ~3], acc[(ND & ~3) + 1]}; __builtin_amdgcn_raw_buffer_store_b64(d, brs, voff + 4u * (ND & ~3), soff, 0); }
+                if constexpr (ND & 1) __builtin_amdgcn_raw_buffer_store_b32(acc[ND - 1], brs, voff + 4u * (ND - 1), soff, 0);
+            }
         }
         srow += rowdw * 4u;
         __builtin_amdgcn_wave_barrier();
@@ -2406,7 +2426,7 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
     const bool band = a.band != 0 && !redo && valid && type == 1;
     const uint32_t* bm32 = a.bmat + (uint64_t)(valid ? job : 0) * vc_band_job_dwords(a.hstride);
     const uint32_t band_ql = band ? a.band_par[job] : 0u;
-    const uint32_t blk_dw = band_lanes * nds;                  // dwords of a band row
+    const uint32_t blk_dw = band_lanes * (a.packed != 0 ? nds : nd);   // dwords of a band row (byte-packed or raw int16 pairs)
     bool oob = false;                                          // this lane asked for a cell outside the band (its value is then meaningless)
     const uint32_t nrows = valid ? min(a.dp.nrows[slot], a.tab_rows) : 0;
     // stored matrix (tilted, see vc_fwd_body): diagonal T == T' + (score - g), vertical T == T' + g,
@@ -2420,6 +2440,10 @@ __device__ __forceinline__ bool vc_tracew_body(const VcTraceArgs& a, uint8_t* sm
         if (band) {
             const uint32_t bl = lc - vc_band_row_start(r - 1, band_ql, band_lanes);
             if (bl >= band_lanes) { oob = true; return 0; }
+            if (!packed) {                                       // raw band row: [band lane][nd dwords]
+                const uint32_t wv = bm32[(r - 1) * blk_dw + bl * nd + (cc >> 1)];
+                return (int)(short)((cc & 1u) ? (wv >> 16) : (wv & 0xFFFFu));
+            }
             const int v = vc_packed_cell(bm32 + (r - 1) * blk_dw + bl * nds, cc, cpl);
             return dtj ? vc_dt_cell(v, r, g) : v;
         }
