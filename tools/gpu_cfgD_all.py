@@ -1,7 +1,8 @@
 """Config D (1 M windows of config C's distribution over 8 ranks) on the one GPU there is: the eight ranks' shares one after the other through
 ONE warm context, host arrays -> host bytes (submit / run / collect in slices, HipContext.consensus_batched), with a sample of every share run
 through the reference itself (oracle/_ref) and compared byte for byte.  Shows that the rate holds over a million windows (no growth of the
-workspaces, no drift) and what an 8-GPU node's ranks each do.      usage: python tools/gpu_cfgD_all.py [ranks=8] [windows_per_rank=125000] [check=128]"""
+workspaces, no drift) and what an 8-GPU node's ranks each do.      usage: python tools/gpu_cfgD_all.py [ranks=8] [windows_per_rank=125000] [check=128] [D|E]
+(E: BASELINE config E -- 50 000 windows of 1 kb x 128 reads, ONT profile, seed 1005 -- 6 250 per rank)"""
 import hashlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -18,7 +19,8 @@ have_ref = oa.have_ref("sse41")
 if have_ref:
     oa.load_ref("sse41")
 ctx = HipContext(device=0)
-cfg = capi.synth_cfg(1002, 500, 64, profile=capi.PACBIO)
+which = sys.argv[4] if len(sys.argv) > 4 else "D"
+cfg = capi.synth_cfg(1005, 1000, 128, profile=capi.ONT) if which == "E" else capi.synth_cfg(1002, 500, 64, profile=capi.PACBIO)
 tot_w = tot_t = 0.0
 rows = []
 for r in range(ranks):
@@ -43,6 +45,6 @@ for r in range(ranks):
     print(json.dumps(row), flush=True)
     del b, cons, status
 ctx.close()
-print(json.dumps({"config": "D on one GPU, rank after rank", "windows": int(tot_w), "device_seconds": tot_t, "windows_per_s": tot_w / tot_t,
+print(json.dumps({"config": which + " on one GPU, rank after rank", "windows": int(tot_w), "device_seconds": tot_t, "windows_per_s": tot_w / tot_t,
                   "slowest_rank": min(x["windows_per_s_host_to_host"] for x in rows), "fastest_rank": max(x["windows_per_s_host_to_host"] for x in rows),
                   "mismatches": sum(max(0, x["mismatches"]) for x in rows), "checked": sum(x["checked_against_reference"] for x in rows)}))
