@@ -185,8 +185,10 @@ def test_tie_resolution_by_exact_dfs(built, monkeypatch):
 
 
 def test_raw_rows_with_a_stored_band(built, monkeypatch):
-    """VC_BAND_RAW=1 (round 6, off by default: slower on 3 kb windows): rows that stay raw int16 -- scores outside the byte form -- store the band
+    """VC_BAND_RAW=1 in a VC_EXPERIMENTS=1 build (round 6; measured slower on 3 kb windows, so not in the default library): rows that stay raw int16 -- scores outside the byte form -- store the band
     of the rank diagonal like byte-packed rows do, and the backtrack reads it.  Same bytes as the oracle; alignments that leave the band are redone."""
+    if not capi.load_hip().vc_has_experiments():
+        pytest.skip("library built without VC_EXPERIMENTS")
     monkeypatch.setenv("VC_BAND_RAW", "1")
     c = HipContext(device=0, match=12, mismatch=-12, gap=-20)            # (cpl - 1) * (m - 2 g) > 255 from 6 columns per lane up: raw rows, still int16
     for seed, L, D, n, kw in [(31, 500, 24, 8, {}), (32, 300, 16, 8, dict(frac_partial=0.3, n_haplotypes=2, snp_rate=0.02))]:

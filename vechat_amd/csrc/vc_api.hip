@@ -195,7 +195,7 @@ struct vc_ctx {
     bool trace_block = false;     // VC_EXPERIMENTS builds, VC_TRACEB=1: k_traceb (the walk out of LDS, vc_traceb.h) for byte-packed rows
     uint32_t trace_tl = 8;        // lanes per alignment of the lock-step k_tracew (development: VC_TRACE_TL=16)
     bool dt = true;               // global alignments on byte-packed rows run on k_fwd_dt (development: VC_DT=0 keeps them on k_fwd)
-    bool band_raw = false;        // VC_BAND_RAW=1: raw int16 rows (widest classes, scores outside the byte form) store the band as well -- bit-identical,
+    bool band_raw = false;        // -DVC_EXPERIMENTS builds, VC_BAND_RAW=1: raw int16 rows (widest classes, scores outside the byte form) store the band as well -- bit-identical,
                                   //   6 % slower on 3 kb windows (profiles/r6_ab_raw_band.txt: 4.7 % of their alignments leave 384 columns), so off
     bool inline_redo = false;     // development (VC_INLINE_REDO=1, read once at vc_create): the redo pair inside every build round instead of catch-up rounds
     bool fold = true;             // launch_fwd: more than two width classes in one launch (development: VC_NO_FOLD=1 launches once per class)
@@ -1167,7 +1167,9 @@ int vc_create(vc_ctx** out, const vc_params* p) {
     if (const char* d = getenv("VC_DUP")) c->dup = (uint32_t)std::atoi(d);
     c->fold = getenv("VC_NO_FOLD") == nullptr;
     if (const char* d = getenv("VC_INLINE_REDO")) c->inline_redo = std::atoi(d) != 0;
+#ifdef VC_EXPERIMENTS
     if (const char* d = getenv("VC_BAND_RAW")) c->band_raw = std::atoi(d) != 0;
+#endif
     if (const char* d = getenv("VC_TRACE_TL")) c->trace_tl = std::atoi(d) == 16 ? 16u : 8u;
     if (const char* d = getenv("VC_TRACEB")) c->trace_block = std::atoi(d) != 0;
     if (const char* d = getenv("VC_HOST_THREADS")) c->host_threads = std::atoi(d) != 0;      // development: 0 = one host thread walks the streams in lockstep

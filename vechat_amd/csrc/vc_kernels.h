@@ -1482,8 +1482,14 @@ __device__ __forceinline__ uint32_t vc_fwd_body(const VcFwdArgs& a, uint32_t* ri
     uint32_t* const hrow0 = a.hmat + (uint64_t)job * a.hstride;
     constexpr bool packed = PACKED;           // the stored row form is a property of the launch (host: both score sets fit the byte bound)
     // banded store: global alignments only (a local alignment may end and start anywhere), byte-packed rows only
-    // (round 6: raw int16 rows too -- the widest classes, and scores whose rows do not fit the byte form: [row][band lane][ND dwords])
-    const bool band = NWT && a.band && !redo;
+    // (round 6, -DVC_EXPERIMENTS builds with VC_BAND_RAW=1: raw int16 rows too -- the widest classes, and scores whose rows do not fit the byte
+    // form: [row][band lane][ND dwords]; bit-identical and 6 % slower on 3 kb windows, profiles/r6_ab_raw_band.txt)
+#ifdef VC_EXPERIMENTS
+    constexpr bool RAW_BAND = true;
+#else
+    constexpr bool RAW_BAND = false;
+#endif
+    const bool band = NWT && (PACKED || RAW_BAND) && a.band && !redo;
     const char* const brow0 = reinterpret_cast<const char*>(a.bmat + (uint64_t)job * vc_band_job_dwords(a.hstride));
     __amdgpu_buffer_rsrc_t brs;                                // the job's band rows behind a buffer descriptor (wave-uniform by construction)
     {
