@@ -27,7 +27,7 @@
 // * the banded store is a RAW BUFFER store: descriptor = the job's band rows, scalar offset = the row, vector offset = the lane's place in
 //   the band or 0x80000000 for the 48 lanes outside it (the range check drops those; tools/buffer_probe.hip) -- no exec-mask writes, no
 //   asm block around a store (the gfx950 store-data hazard of round 5 is the compiler's to see again), one s_add per row; the band's
-//   vector offset is worked out once per 8 rows in the loop that walks the band blocks;
+//   vector offset is worked out once per VC_BAND_ROWS rows in the loop that walks the band blocks;
 // * a row whose only predecessor is the row above, that is no sink and is not read back from the stored matrix ("fast": one test of the
 //   record word) touches nothing but its base, its keep bit and the loop counter.
 #pragma once

@@ -1231,10 +1231,10 @@ __host__ __device__ inline uint64_t vc_band_job_dwords(uint64_t hstride) {      
     return hstride / 4 + VC_BAND_JOB_PAD_DWORDS;
 }
 // The band MOVES only every VC_BAND_ROWS rows (a power of two) -- rows (b * VC_BAND_ROWS + 1 ...) share the lanes of the diagonal at the
-// block's middle.  The diagonal advances ~0.04 lanes per row, so a block of 8 rows shifts the band by a third of a lane at most, and
-// k_fwd works out a band (scalar multiply, clamps, lane offsets) once per 8 rows instead of once per row.
+// block's middle.  The diagonal advances ~0.04 lanes per row, so a block of 16 rows shifts the band by two thirds of a lane at most, and
+// k_fwd works out a band (scalar multiply, clamps, lane offsets) once per block instead of once per row.
 #ifndef VC_BAND_ROWS
-#define VC_BAND_ROWS 8
+#define VC_BAND_ROWS 16     // (8 until the end of round 6; 16: + 0.5 % on config C, + 0.2 ... 1.9 % on the other shapes of the bench line, 4 % more alignments redone: profiles/r6_ab_band_rows_kept_ring.txt)
 #endif
 static_assert(VC_BAND_ROWS >= 1 && (VC_BAND_ROWS & (VC_BAND_ROWS - 1)) == 0, "rows per band block: a power of two");
 __device__ __forceinline__ uint32_t vc_band_row_start(uint32_t r1, uint32_t ql, uint32_t bl) {        // r1 = row - 1

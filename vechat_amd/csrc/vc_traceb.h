@@ -6,8 +6,8 @@
 //
 //   * every alignment (8 lanes of a wave, as in k_tracew<8>) keeps the last VC_TB_SLOTS BLOCKS of 8 stored rows in LDS -- of every
 //     row a WINDOW of 48 bytes (the band lanes around the column the walk is expected to cross that block at: 4 lanes of 8 / 10
-//     columns, 2 of 16 / 20) and the row's 16-byte record.  A block is what vc_band_row_start gives one band position to, so its
-//     window is one rectangle of the stored band;
+//     columns, 2 of 16 / 20) and the row's 16-byte record.  The rows of a block share one band position (vc_band_row_start: blocks of
+//     VC_BAND_ROWS rows, a multiple of 8), so its window is one rectangle of the stored band;
 //   * blocks are fetched with global_load_lds (16 bytes per lane straight into LDS, no registers, nothing to wait for until the
 //     data is used): 3 instructions for the rows and 1 for the records of a block, issued when the walk enters the block
 //     VC_TB_SLOTS - 1 blocks above it;
@@ -27,7 +27,7 @@
 #define VC_TB_SLOTS 4          // blocks of 8 rows in LDS per alignment (a power of two)
 #endif
 #define VC_TB_NCH 3u           // 16-byte pieces of a row's window
-static_assert(VC_BAND_ROWS == 8, "k_traceb caches blocks of 8 rows = the rows that share a band position");
+static_assert(VC_BAND_ROWS % 8 == 0, "k_traceb caches blocks of 8 rows: they must share a band position (vc_band_row_start)");
 static_assert((VC_TB_SLOTS & (VC_TB_SLOTS - 1)) == 0 && VC_TB_SLOTS >= 2 && VC_TB_SLOTS <= 4, "slots: 2 or 4 (their windows' lanes share one register)");
 __host__ __device__ inline uint32_t vc_traceb_lds_bytes() { return VC_TB_SLOTS * (VC_TB_NCH + 1u) * 1024u; }
 
