@@ -70,7 +70,7 @@ typedef struct vc_params {
     uint32_t max_nodes;                     /* per-window graph capacity; 0 = derive from batch    */
     uint32_t max_edges;                     /* 0 = derive                                          */
     uint32_t chunk_windows;                 /* windows resident per pass; 0 = derive from memory   */
-    uint64_t scratch_bytes;                 /* device scratch budget; 0 = 60 % of free memory, at most 96 GiB */
+    uint64_t scratch_bytes;                 /* device scratch budget; 0 = 60 % of free memory, at most 128 GiB (VC_SCRATCH_CAP_GB) */
     int32_t  profile;                       /* 1 = bracket every kernel launch with HIP events, 2 = only the forward kernel's */
     uint32_t n_streams;                     /* chunks in flight on separate chunk streams (<= 16); 0 = chosen per batch: 8 from 12 288 windows up, else 4 */
 } vc_params;
@@ -167,7 +167,7 @@ int   vc_set_pipeline(vc_ctx* ctx, int on, uint32_t forward_waves, uint32_t back
  * then returns VC_ERR_ARG, as do vc_debug_pipe_state / vc_debug_pipe_prof. */
 int   vc_has_experiments(void);
 /* Allocates the workspaces' memory now, in one piece (bytes = 0: the default budget, vc_params.scratch_bytes or 60 % of the free
- * memory up to 96 GiB), instead of under the first vc_submit; batches of any shape are then laid out inside it without further
+ * memory up to 128 GiB), instead of under the first vc_submit; batches of any shape are then laid out inside it without further
  * allocations.  The counterpart of createCUDABatch sizing a batch's device memory at construction (mem_per_batch, src/cuda/cudapolisher.cpp:229-243):
  * a caller does it while its input is still being parsed.  Optional; without it vc_submit allocates what a batch needs. */
 int   vc_reserve(vc_ctx* ctx, uint64_t bytes);

@@ -65,7 +65,7 @@ constexpr int kRingPruned = VC_RING_PRUNED;
 // (re-alignment rounds and the final alignment: a pruned graph is nearly a chain, four rows hold its non-adjacent predecessors, and the
 // smaller ring lets a fifth / sixth wave onto each SIMD)
 constexpr int kMaxStreams = 16;
-constexpr uint32_t kArenaSegs = 4;         // segments of the workspace arena (vc_ctx::arena): each a quarter of the budget, 24 GiB by default
+constexpr uint32_t kArenaSegs = 4;         // segments of the workspace arena (vc_ctx::arena): each a quarter of the budget
 constexpr uint32_t kAutoStreamsMany = 8, kAutoStreamsFew = 4, kAutoStreamsFrom = 12288;   // windows from which a batch runs on the larger number of chunk streams
 constexpr uint32_t kTraceTabRows = 8188;           // rows covered by k_tracew's first-in-edge table (4 tables x 2 B x 8192 = 64 KB); later rows are walked without speculation
 constexpr uint32_t kLdsCap = 160 * 1024 - 1024;   // dynamic LDS a kernel may ask for (160 KB per CU minus room for static __shared__)
@@ -384,13 +384,22 @@ void free_arena(vc_ctx* c) {
     c->arena.clear();
     c->arena_bytes = 0; c->arena_cur = 0;
 }
-// bytes = 0: the default budget (vc_params.scratch_bytes, or 60 % of the free memory up to 96 GiB).  One segment per chunk stream.
+// Default workspace budget: 60 % of what is free, capped.  The cap was 96 GiB until the end of round 6; larger chunks run faster (config C,
+// tools/gpu_scale.py 100000 64 500: 64 GiB 36.0 k, 96 GiB 38.6 k, 160 GiB 39.1 k, 220 GiB 39.5 k windows/s -- profiles/r6_ab_workspace_budget.txt), and an
+// MI355X has 288 GB.  The cap is 128 GiB now: four arena segments of 32 GiB, the largest hipMalloc that comes back at once -- 4 x 43 GiB (a cap of 176)
+// take 3.4 s and turn the cold start of a process from 2.9 into 6.3 s.  VC_SCRATCH_CAP_GB overrides the cap, vc_params.scratch_bytes the whole rule.
+uint64_t default_budget(size_t free_b) {
+    uint64_t cap = 128ull << 30;
+    if (const char* d = getenv("VC_SCRATCH_CAP_GB")) { const double g = std::atof(d); if (g >= 1.0) cap = (uint64_t)(g * 1073741824.0); }
+    return std::min<uint64_t>((uint64_t)(free_b * 0.6), cap);
+}
+// bytes = 0: the default budget (vc_params.scratch_bytes, or 60 % of the free memory up to the cap of default_budget).  One segment per chunk stream.
 int make_arena(vc_ctx* c, uint64_t bytes) {
     free_arena(c);
     if (!bytes) {
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-        bytes = c->prm.scratch_bytes ? c->prm.scratch_bytes : std::min<uint64_t>((uint64_t)(free_b * 0.6), 96ull << 30);
+        bytes = c->prm.scratch_bytes ? c->prm.scratch_bytes : default_budget(free_b);
     }
     const bool tm = getenv("VC_TIME_SUBMIT") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1524,9 +1533,9 @@ int vc_submit(vc_ctx* c, const vc_batch* hb) {
     // the workspaces of more streams than this batch wants are kept (it simply uses the first few): a small batch in a stream of
     // large ones must not re-create them
     const uint32_t S = c->have_ws ? std::max(want_streams, c->n_streams) : want_streams;
-    // default budget: 60 % of what is free, but no more than 96 GiB -- config C runs at 97 % of its unrestricted rate with 64 GiB
+    // default budget: 60 % of what is free, capped (default_budget) -- config C runs at 91 % of its 220-GiB rate with 64 GiB, 97.7 % with 96
     // (chunks of 4 096 windows) and at 86 % with 32 GiB (2 048), so holding more than that buys nothing (profiles/r3c_footprint.txt)
-    uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : std::min<uint64_t>((uint64_t)(free_b * 0.6), 96ull << 30)) / S;
+    uint64_t budget = (c->prm.scratch_bytes ? c->prm.scratch_bytes : default_budget(free_b)) / S;
     const uint64_t budget_default = budget;
     if (!c->arena.empty()) {                             // the arena IS the budget: a segment per stream (less the padding between its pieces)
         const uint64_t per_seg = (S + c->arena.size() - 1) / c->arena.size();          // workspaces that share a segment
